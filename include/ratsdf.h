@@ -1,0 +1,210 @@
+/*
+ * ratsdf.h -- C ABI of the MI355X-native voxel-hashed TSDF + semantic integration engine.
+ *
+ * This is the drop-in boundary for RA-SLAM's TSDF hot path.  The reference exposes the path as an
+ * in-process C++ class API (no FFI of its own); every entry point below names the reference
+ * interface it replaces (paths relative to the reference tree).  Types are PODs with the
+ * reference's exact layouts so buffers can be handed to reference-side consumers unchanged.
+ *
+ * All functions return a ratsdf_status (0 = OK) and never throw across the boundary.
+ * One engine handle = one GPU context + one HIP stream; calls on one handle must be serialised by
+ * the caller (the reference's TSDFSystem does so with mtx_read_, modules/tsdf_module.h:152-164);
+ * distinct handles are independent.
+ *
+ * The same ABI, with the prefix ratsdf_oracle_ instead of ratsdf_, is implemented by the CPU
+ * restatement under oracle/ (test infrastructure only).
+ */
+#ifndef RATSDF_H_
+#define RATSDF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants of the reference (defaults; create_ex can override the two *_BITS) ---------- */
+#define RATSDF_BLOCK_LEN 8            /* utils/tsdf/voxel_mem.cuh:17-22  BLOCK_LEN            */
+#define RATSDF_BLOCK_VOLUME 512       /* utils/tsdf/voxel_mem.cuh:22     BLOCK_VOLUME         */
+#define RATSDF_DEFAULT_BLOCK_BITS 18  /* utils/tsdf/voxel_mem.cuh:11-13  NUM_BLOCK = 2^18     */
+#define RATSDF_DEFAULT_BUCKET_BITS 21 /* utils/tsdf/voxel_hash.cuh:13-15 NUM_BUCKET = 2^21    */
+#define RATSDF_ENTRIES_PER_BUCKET 2   /* utils/tsdf/voxel_hash.cuh:18-20                      */
+
+typedef enum ratsdf_status {
+  RATSDF_OK = 0,
+  RATSDF_ERR_BAD_ARGUMENT = 1,   /* reference: assert()s in TSDFGrid::Integrate, voxel_tsdf.cu:419-428 */
+  RATSDF_ERR_DEVICE = 2,         /* reference: CUDA_SAFE_CALL prints in debug builds, errors.cuh:13-20  */
+  RATSDF_ERR_POOL_EXHAUSTED = 3, /* reference: device assert(idx >= 1), voxel_mem.cu:39                 */
+  RATSDF_ERR_CAPACITY = 4,       /* an internal work list overflowed (no reference counterpart)        */
+  RATSDF_ERR_NO_DEVICE = 5,      /* HIP engine only: no gfx950 device / runtime available              */
+  RATSDF_ERR_NOT_IMPLEMENTED = 6
+} ratsdf_status;
+
+/* CameraIntrinsics<float>, utils/cuda/camera.cuh:13-52 */
+typedef struct ratsdf_intrinsics {
+  float fx, fy, cx, cy;
+} ratsdf_intrinsics;
+
+/* SE3<float> = Eigen quaternion + translation, utils/cuda/lie_group.cuh:8-45.  The reference turns
+ * the 4x4 pose matrix into a quaternion on the HOST (lie_group.cuh:15-19) before any kernel runs,
+ * so the pose crosses the ABI as (q, t).  Maps world -> camera (cam_T_world). */
+typedef struct ratsdf_pose {
+  float qx, qy, qz, qw;
+  float tx, ty, tz;
+} ratsdf_pose;
+
+/* BoundingCube<float>, utils/tsdf/voxel_tsdf.cuh:19-34 (member order preserved) */
+typedef struct ratsdf_bounds {
+  float xmin, xmax, ymin, ymax, zmin, zmax;
+} ratsdf_bounds;
+
+/* VoxelSpatialTSDF (16 B), utils/tsdf/voxel_types.cuh:46-56 */
+typedef struct ratsdf_voxel_tsdf {
+  float x, y, z;
+  float tsdf;
+} ratsdf_voxel_tsdf;
+
+/* VoxelSpatialTSDFSEGM (20 B), utils/tsdf/voxel_types.cuh:61-70; also the DownloadAll file record,
+ * modules/tsdf_module.cc:57-64 */
+typedef struct ratsdf_voxel_segm {
+  float x, y, z;
+  float tsdf;
+  float prob;
+} ratsdf_voxel_segm;
+
+/* VoxelBlock (12 B), utils/tsdf/voxel_mem.cuh:75-95: block position on the integer block grid,
+ * chain offset (0 = tail / normal entry, >0 = distance in entries to next chain element,
+ * <0 only in lookup results = "known absent"), pool index (-1 = empty). */
+typedef struct ratsdf_block {
+  int16_t x, y, z;
+  int16_t offset;
+  int32_t idx;
+} ratsdf_block;
+
+/* VoxelRGBW (4 B), utils/tsdf/voxel_types.cuh:10-19 */
+typedef struct ratsdf_rgbw {
+  uint8_t r, g, b, weight;
+} ratsdf_rgbw;
+
+/* Per-frame counters (the reference only logs active-block counts, voxel_tsdf.cu:442,451,865). */
+typedef struct ratsdf_frame_stats {
+  int32_t visible_blocks;   /* V: length of the visible list (GatherVisible, voxel_tsdf.cu:465-474) */
+  int32_t updated_voxels;   /* U: voxels that passed every test in tsdf_integrate_kernel            */
+  int32_t allocated_blocks; /* blocks inserted by the allocation pass                               */
+  int32_t deleted_blocks;   /* blocks removed by space carving                                      */
+  int32_t active_blocks;    /* NumActiveBlock() after the frame, voxel_hash.cu:225                  */
+  int32_t slow_requests;    /* allocation requests that went through the chained-bucket resolver    */
+} ratsdf_frame_stats;
+
+typedef struct ratsdf_config {
+  float voxel_size;     /* TSDFGrid ctor arg, voxel_tsdf.cuh:47 */
+  float truncation;     /* TSDFGrid ctor arg, voxel_tsdf.cuh:47 */
+  int32_t device;       /* HIP device ordinal (ignored by the oracle) */
+  int32_t block_bits;   /* 0 -> RATSDF_DEFAULT_BLOCK_BITS  */
+  int32_t bucket_bits;  /* 0 -> RATSDF_DEFAULT_BUCKET_BITS */
+  /* Block-ownership sharding across GPUs (no reference counterpart): a candidate block
+   * is inserted only if owner(block) == shard_rank, owner = floormod(x >> shard_slab_bits, count).
+   * shard_count <= 1 disables the filter. */
+  int32_t shard_rank;
+  int32_t shard_count;
+  int32_t shard_slab_bits;
+  int32_t threads;      /* oracle only: worker threads for the multithreaded CPU baseline (0/1 = serial) */
+  int32_t reserved[7];
+} ratsdf_config;
+
+typedef struct ratsdf_engine ratsdf_engine;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* TSDFGrid::TSDFGrid(voxel_size, truncation) + VoxelHashTable/VoxelMemPool ctors,
+ * voxel_tsdf.cu:376-395, voxel_hash.cu:25-33, voxel_mem.cu:13-27 */
+int ratsdf_create(float voxel_size, float truncation, int device, ratsdf_engine** out);
+int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out);
+/* TSDFGrid::~TSDFGrid, voxel_tsdf.cu:397-414 */
+int ratsdf_destroy(ratsdf_engine* e);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* TSDFGrid::Integrate(img_rgb, img_depth, img_ht, img_lt, max_depth, intrinsics, cam_T_world),
+ * voxel_tsdf.cu:416-452.  Host buffers: rgb = H*W*3 u8 (RGB order), depth/ht/lt = H*W f32
+ * (metres / probabilities).  ht == NULL or lt == NULL means all-ones images, as
+ * TSDFSystem::Integrate substitutes (modules/tsdf_module.cc:27-31).  Caller buffers are not
+ * retained after return.  Blocks until the frame is integrated, like the reference. */
+int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, const float* ht,
+                     const float* lt, int height, int width, float max_depth,
+                     const ratsdf_intrinsics* intrinsics, const ratsdf_pose* cam_T_world);
+
+/* Same frame, inputs already resident in device memory (HBM); enqueues on the engine's stream and
+ * returns without a host synchronisation.  This removes the reference's PCIe copies and its three
+ * mid-frame host syncs (voxel_tsdf.cu:433-451, 862-864).  HIP engine only. */
+int ratsdf_integrate_device(ratsdf_engine* e, const void* d_rgb, const void* d_depth,
+                            const void* d_ht, const void* d_lt, int height, int width,
+                            float max_depth, const ratsdf_intrinsics* intrinsics,
+                            const ratsdf_pose* cam_T_world);
+/* cudaStreamSynchronize(stream_), voxel_tsdf.cu:450; also surfaces sticky device-side errors
+ * (pool exhausted, work-list overflow). */
+int ratsdf_synchronize(ratsdf_engine* e);
+/* Native handle of the engine's stream (hipStream_t) so callers can order their own work / events. */
+int ratsdf_stream(ratsdf_engine* e, void** out_stream);
+
+/* VoxelHashTable::NumActiveBlock, voxel_hash.cu:225 */
+int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out);
+/* Counters of the most recently completed frame (synchronises). */
+int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out);
+
+/* ---- query side ---------------------------------------------------------------------------- */
+/* TSDFGrid::GatherVoxels(BoundingCube<float>) == TSDFSystem::Query, voxel_tsdf.cu:532-559,
+ * modules/tsdf_module.cc:39-43.  Output: every voxel of every allocated block that lies wholly
+ * inside the bounds, ordered by ascending hash-entry index then x + 8y + 64z.  *out is owned by
+ * the library until ratsdf_free_buffer. */
+int ratsdf_query(ratsdf_engine* e, const ratsdf_bounds* bounds, ratsdf_voxel_tsdf** out, size_t* n);
+/* TSDFGrid::GatherValid, voxel_tsdf.cu:476-502 */
+int ratsdf_gather_valid(ratsdf_engine* e, ratsdf_voxel_tsdf** out, size_t* n);
+/* TSDFGrid::GatherValidSemantic, voxel_tsdf.cu:504-530 (the DownloadAll payload) */
+int ratsdf_gather_valid_semantic(ratsdf_engine* e, ratsdf_voxel_segm** out, size_t* n);
+/* TSDFSystem::DownloadAll(file_path): raw 20-byte records, modules/tsdf_module.cc:57-64 */
+int ratsdf_download_all(ratsdf_engine* e, const char* file_path);
+int ratsdf_free_buffer(void* p);
+
+/* ---- multi-GPU support --------------------------------------------------------------------- */
+/* Writes the compact block directory (allocated entries in ascending entry order, 12 B each) into a
+ * caller-provided DEVICE buffer so it can be all-gathered with RCCL without touching the host.
+ * d_count (device int32) receives the number of entries; entries beyond `capacity` are dropped.
+ * Enqueued on the engine's stream.  HIP engine only. */
+int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t capacity,
+                                   void* d_count);
+
+/* ---- test / inspection hooks (mirror the reference's gtest kernels) ------------------------- */
+/* One allocation pass over an explicit list of block positions (3 x int16 each), request i having
+ * raster rank i, followed by ResetLocks: the Allocate<<<>>> kernel + ResetLocks of
+ * utils/tests/voxel_hash_test.cu:36-39,98-99,140-141. */
+int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* block_pos, int32_t n);
+/* One carve pass that requests deletion of the listed blocks, processed in list order, then
+ * ResetLocks: VoxelHashTable::Delete, voxel_hash.cu:110-159. */
+int ratsdf_test_delete(ratsdf_engine* e, const int16_t* block_pos, int32_t n);
+/* VoxelHashTable::Retrieve<Voxel>(point, cache) with a fresh cache per point,
+ * voxel_hash.cuh:104-143; voxel_hash_test.cu:41-45.  points = 3 x int16 voxel coordinates.
+ * Any output array may be NULL.  Misses return the default voxel (weight 0 / tsdf -10 / prob 0,
+ * voxel_types.cu:3,8,11) and block {pos, offset -1, idx -1} (voxel_hash.cu:214-217). */
+int ratsdf_test_retrieve(ratsdf_engine* e, const int16_t* points, int32_t n, ratsdf_rgbw* rgbw,
+                         float* tsdf, float* prob, ratsdf_block* blocks);
+/* *RetrieveMutable<VoxelRGBW>(point) = value, voxel_hash_test.cu:47-54.  Points whose block is
+ * not allocated are skipped (the reference asserts). */
+int ratsdf_test_assign_rgbw(ratsdf_engine* e, const int16_t* points, const ratsdf_rgbw* values,
+                            int32_t n);
+/* Compact dump of the hash directory: allocated entries in ascending entry order. */
+int ratsdf_dump_directory(ratsdf_engine* e, int32_t** entry_index, ratsdf_block** blocks,
+                          size_t* n);
+/* Raw voxel storage of the given pool blocks: 512 voxels each, index x + 8y + 64z. */
+int ratsdf_dump_voxels(ratsdf_engine* e, const int32_t* pool_idx, int32_t n, float* tsdf,
+                       ratsdf_rgbw* rgbw, float* prob);
+/* Free-list state: num_free and the heap array (2^block_bits ints), voxel_mem.cu:15-24. */
+int ratsdf_dump_heap(ratsdf_engine* e, int32_t* num_free, int32_t* heap);
+
+const char* ratsdf_status_string(int status);
+/* "hip-gfx950" for the engine, "cpu-oracle" for the oracle. */
+const char* ratsdf_backend(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RATSDF_H_ */

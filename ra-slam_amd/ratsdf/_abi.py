@@ -1,0 +1,326 @@
+"""ctypes view of the C ABI declared in include/ratsdf.h.
+
+The same ABI is exported by the HIP engine (prefix ``ratsdf_``) and, for tests only, by the CPU
+oracle (prefix ``ratsdf_oracle_``).  This module only knows the ABI's shape; which shared library
+and prefix to bind is the caller's choice (the product binds libratsdf.so, see ``__init__``).
+"""
+import ctypes as C
+
+import numpy as np
+
+BLOCK_VOLUME = 512
+
+STATUS = {
+    0: "ok",
+    1: "bad argument",
+    2: "device error",
+    3: "voxel block pool exhausted",
+    4: "internal work list overflow",
+    5: "no device",
+    6: "not implemented",
+}
+
+
+class RatsdfError(RuntimeError):
+    def __init__(self, status, what):
+        super().__init__(f"{what}: status {status} ({STATUS.get(status, 'unknown')})")
+        self.status = status
+
+
+class Intrinsics(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
+class Pose(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("qx", "qy", "qz", "qw", "tx", "ty", "tz")]
+
+
+class Bounds(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("visible_blocks", "updated_voxels", "allocated_blocks",
+                                         "deleted_blocks", "active_blocks", "slow_requests")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Config(C.Structure):
+    _fields_ = [("voxel_size", C.c_float), ("truncation", C.c_float), ("device", C.c_int32),
+                ("block_bits", C.c_int32), ("bucket_bits", C.c_int32), ("shard_rank", C.c_int32),
+                ("shard_count", C.c_int32), ("shard_slab_bits", C.c_int32), ("threads", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
+
+
+# numpy views of the POD records (layouts fixed by the reference, see ratsdf.h)
+BLOCK_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("z", "<i2"), ("offset", "<i2"), ("idx", "<i4")])
+RGBW_DTYPE = np.dtype([("r", "u1"), ("g", "u1"), ("b", "u1"), ("weight", "u1")])
+VOXEL_TSDF_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("tsdf", "<f4")])
+VOXEL_SEGM_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("tsdf", "<f4"),
+                             ("prob", "<f4")])
+assert BLOCK_DTYPE.itemsize == 12 and VOXEL_TSDF_DTYPE.itemsize == 16
+assert VOXEL_SEGM_DTYPE.itemsize == 20 and RGBW_DTYPE.itemsize == 4
+
+# every symbol include/ratsdf.h declares (without prefix)
+SYMBOLS = [
+    "create", "create_ex", "destroy", "integrate", "integrate_device", "synchronize", "stream",
+    "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
+    "download_all", "free_buffer", "export_directory_device", "test_allocate", "test_delete",
+    "test_retrieve", "test_assign_rgbw", "dump_directory", "dump_voxels", "dump_heap",
+    "status_string", "backend",
+]
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+class Library:
+    """A loaded shared library exporting the ABI under ``prefix``."""
+
+    def __init__(self, path, prefix="ratsdf_"):
+        self.path = str(path)
+        self.prefix = prefix
+        self.dll = C.CDLL(self.path)
+        self.fn = {}
+        for s in SYMBOLS:
+            self.fn[s] = getattr(self.dll, prefix + s)  # AttributeError = missing export
+        for s in SYMBOLS:
+            self.fn[s].restype = C.c_int
+        self.fn["status_string"].restype = C.c_char_p
+        self.fn["backend"].restype = C.c_char_p
+        vp = C.c_void_p
+        self.fn["create"].argtypes = [C.c_float, C.c_float, C.c_int, C.POINTER(vp)]
+        self.fn["create_ex"].argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        self.fn["destroy"].argtypes = [vp]
+        self.fn["integrate"].argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float,
+                                         C.POINTER(Intrinsics), C.POINTER(Pose)]
+        self.fn["integrate_device"].argtypes = self.fn["integrate"].argtypes
+        self.fn["synchronize"].argtypes = [vp]
+        self.fn["stream"].argtypes = [vp, C.POINTER(vp)]
+        self.fn["num_active_blocks"].argtypes = [vp, C.POINTER(C.c_int32)]
+        self.fn["last_frame_stats"].argtypes = [vp, C.POINTER(FrameStats)]
+        self.fn["query"].argtypes = [vp, C.POINTER(Bounds), C.POINTER(vp), C.POINTER(C.c_size_t)]
+        self.fn["gather_valid"].argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        self.fn["gather_valid_semantic"].argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        self.fn["download_all"].argtypes = [vp, C.c_char_p]
+        self.fn["free_buffer"].argtypes = [vp]
+        self.fn["export_directory_device"].argtypes = [vp, vp, C.c_int32, vp]
+        self.fn["test_allocate"].argtypes = [vp, vp, C.c_int32]
+        self.fn["test_delete"].argtypes = [vp, vp, C.c_int32]
+        self.fn["test_retrieve"].argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp]
+        self.fn["test_assign_rgbw"].argtypes = [vp, vp, vp, C.c_int32]
+        self.fn["dump_directory"].argtypes = [vp, C.POINTER(vp), C.POINTER(vp),
+                                              C.POINTER(C.c_size_t)]
+        self.fn["dump_voxels"].argtypes = [vp, vp, C.c_int32, vp, vp, vp]
+        self.fn["dump_heap"].argtypes = [vp, C.POINTER(C.c_int32), vp]
+        self.fn["status_string"].argtypes = [C.c_int]
+        self.fn["backend"].argtypes = []
+
+    def backend(self):
+        return self.fn["backend"]().decode()
+
+
+def _check(st, what):
+    if st != 0:
+        raise RatsdfError(st, what)
+
+
+def _as_pose(pose):
+    if isinstance(pose, Pose):
+        return pose
+    q = [float(v) for v in pose]
+    if len(q) != 7:
+        raise ValueError("pose must be (qx, qy, qz, qw, tx, ty, tz)")
+    return Pose(*q)
+
+
+def _as_intr(k):
+    if isinstance(k, Intrinsics):
+        return k
+    return Intrinsics(*[float(v) for v in k])
+
+
+class Engine:
+    """One TSDF map (the reference's ``TSDFGrid``, utils/tsdf/voxel_tsdf.cuh:39-145)."""
+
+    def __init__(self, lib, voxel_size, truncation, device=0, block_bits=0, bucket_bits=0,
+                 shard_rank=0, shard_count=1, shard_slab_bits=0, threads=0):
+        self.lib = lib
+        self.voxel_size = float(voxel_size)
+        self.truncation = float(truncation)
+        cfg = Config()
+        cfg.voxel_size = voxel_size
+        cfg.truncation = truncation
+        cfg.device = device
+        cfg.block_bits = block_bits
+        cfg.bucket_bits = bucket_bits
+        cfg.shard_rank = shard_rank
+        cfg.shard_count = shard_count
+        cfg.shard_slab_bits = shard_slab_bits
+        cfg.threads = threads
+        self.block_bits = block_bits or 18
+        self.bucket_bits = bucket_bits or 21
+        h = C.c_void_p()
+        _check(lib.fn["create_ex"](C.byref(cfg), C.byref(h)), "create")
+        self._h = h
+
+    # -- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fn["destroy"](self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- hot path --------------------------------------------------------------------------
+    def integrate(self, rgb, depth, ht, lt, max_depth, intrinsics, pose):
+        """TSDFGrid::Integrate (voxel_tsdf.cu:416-452) on host numpy images."""
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w = depth.shape
+        if rgb.shape != (h, w, 3):
+            raise ValueError("rgb must be HxWx3 uint8 matching depth")
+        if ht is not None:
+            ht = np.ascontiguousarray(ht, dtype=np.float32)
+        if lt is not None:
+            lt = np.ascontiguousarray(lt, dtype=np.float32)
+        for a in (ht, lt):
+            if a is not None and a.shape != (h, w):
+                raise ValueError("ht/lt must match depth")
+        k, p = _as_intr(intrinsics), _as_pose(pose)
+        st = self.lib.fn["integrate"](self._h, rgb.ctypes.data, depth.ctypes.data,
+                                      ht.ctypes.data if ht is not None else None,
+                                      lt.ctypes.data if lt is not None else None, h, w,
+                                      float(max_depth), C.byref(k), C.byref(p))
+        _check(st, "integrate")
+
+    def integrate_device(self, d_rgb, d_depth, d_ht, d_lt, height, width, max_depth, intrinsics,
+                         pose):
+        """Frame already in HBM (raw device pointers as ints); asynchronous."""
+        k, p = _as_intr(intrinsics), _as_pose(pose)
+        st = self.lib.fn["integrate_device"](self._h, d_rgb, d_depth, d_ht or None, d_lt or None,
+                                             height, width, float(max_depth), C.byref(k),
+                                             C.byref(p))
+        _check(st, "integrate_device")
+
+    def synchronize(self):
+        _check(self.lib.fn["synchronize"](self._h), "synchronize")
+
+    def stream(self):
+        s = C.c_void_p()
+        _check(self.lib.fn["stream"](self._h, C.byref(s)), "stream")
+        return s.value or 0
+
+    def num_active_blocks(self):
+        n = C.c_int32()
+        _check(self.lib.fn["num_active_blocks"](self._h, C.byref(n)), "num_active_blocks")
+        return n.value
+
+    def last_frame_stats(self):
+        s = FrameStats()
+        _check(self.lib.fn["last_frame_stats"](self._h, C.byref(s)), "last_frame_stats")
+        return s.as_dict()
+
+    # -- query side ------------------------------------------------------------------------
+    def _take(self, ptr, n, dtype):
+        if n == 0:
+            out = np.empty(0, dtype=dtype)
+        else:
+            buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr.value)
+            out = np.frombuffer(buf, dtype=dtype).copy()
+        if ptr.value:
+            self.lib.fn["free_buffer"](ptr)
+        return out
+
+    def query(self, bounds):
+        """TSDFSystem::Query / TSDFGrid::GatherVoxels (voxel_tsdf.cu:532-559)."""
+        b = bounds if isinstance(bounds, Bounds) else Bounds(*[float(v) for v in bounds])
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib.fn["query"](self._h, C.byref(b), C.byref(p), C.byref(n)), "query")
+        return self._take(p, n.value, VOXEL_TSDF_DTYPE)
+
+    def gather_valid(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib.fn["gather_valid"](self._h, C.byref(p), C.byref(n)), "gather_valid")
+        return self._take(p, n.value, VOXEL_TSDF_DTYPE)
+
+    def gather_valid_semantic(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib.fn["gather_valid_semantic"](self._h, C.byref(p), C.byref(n)),
+               "gather_valid_semantic")
+        return self._take(p, n.value, VOXEL_SEGM_DTYPE)
+
+    def download_all(self, path):
+        _check(self.lib.fn["download_all"](self._h, str(path).encode()), "download_all")
+
+    def export_directory_device(self, d_blocks, capacity, d_count):
+        _check(self.lib.fn["export_directory_device"](self._h, d_blocks, capacity, d_count),
+               "export_directory_device")
+
+    # -- test hooks ------------------------------------------------------------------------
+    @staticmethod
+    def _s3(a):
+        a = np.ascontiguousarray(a, dtype=np.int16).reshape(-1, 3)
+        return a, a.shape[0]
+
+    def test_allocate(self, block_pos):
+        a, n = self._s3(block_pos)
+        _check(self.lib.fn["test_allocate"](self._h, a.ctypes.data, n), "test_allocate")
+
+    def test_delete(self, block_pos):
+        a, n = self._s3(block_pos)
+        _check(self.lib.fn["test_delete"](self._h, a.ctypes.data, n), "test_delete")
+
+    def test_retrieve(self, points):
+        a, n = self._s3(points)
+        rgbw = np.zeros(n, dtype=RGBW_DTYPE)
+        tsdf = np.zeros(n, dtype=np.float32)
+        prob = np.zeros(n, dtype=np.float32)
+        blocks = np.zeros(n, dtype=BLOCK_DTYPE)
+        _check(self.lib.fn["test_retrieve"](self._h, a.ctypes.data, n, rgbw.ctypes.data,
+                                            tsdf.ctypes.data, prob.ctypes.data,
+                                            blocks.ctypes.data), "test_retrieve")
+        return rgbw, tsdf, prob, blocks
+
+    def test_assign_rgbw(self, points, values):
+        a, n = self._s3(points)
+        v = np.ascontiguousarray(values, dtype=RGBW_DTYPE).reshape(-1)
+        if v.shape[0] != n:
+            raise ValueError("values must match points")
+        _check(self.lib.fn["test_assign_rgbw"](self._h, a.ctypes.data, v.ctypes.data, n),
+               "test_assign_rgbw")
+
+    def dump_directory(self):
+        pe, pb, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _check(self.lib.fn["dump_directory"](self._h, C.byref(pe), C.byref(pb), C.byref(n)),
+               "dump_directory")
+        return (self._take(pe, n.value, np.dtype("<i4")), self._take(pb, n.value, BLOCK_DTYPE))
+
+    def dump_voxels(self, pool_idx):
+        idx = np.ascontiguousarray(pool_idx, dtype=np.int32).reshape(-1)
+        n = idx.shape[0]
+        tsdf = np.zeros((n, BLOCK_VOLUME), dtype=np.float32)
+        rgbw = np.zeros((n, BLOCK_VOLUME), dtype=RGBW_DTYPE)
+        prob = np.zeros((n, BLOCK_VOLUME), dtype=np.float32)
+        _check(self.lib.fn["dump_voxels"](self._h, idx.ctypes.data, n, tsdf.ctypes.data,
+                                          rgbw.ctypes.data, prob.ctypes.data), "dump_voxels")
+        return tsdf, rgbw, prob
+
+    def dump_heap(self):
+        nf = C.c_int32()
+        heap = np.zeros(1 << self.block_bits, dtype=np.int32)
+        _check(self.lib.fn["dump_heap"](self._h, C.byref(nf), heap.ctypes.data), "dump_heap")
+        return nf.value, heap
