@@ -146,6 +146,13 @@ int ratsdf_synchronize(ratsdf_engine* e);
 /* Native handle of the engine's stream (hipStream_t) so callers can order their own work / events. */
 int ratsdf_stream(ratsdf_engine* e, void** out_stream);
 
+/* Optional in-stream timing of the dominant kernel (k_integrate) with HIP events on the engine's
+ * stream: enable, run frames, read back the summed kernel time and the number of timed launches
+ * (read synchronises and resets the accumulators).  The reference's counterpart is the wall-clock
+ * log line around Integrate (modules/tsdf_module.cc:108-112).  HIP engine only. */
+int ratsdf_profile_enable(ratsdf_engine* e, int enable);
+int ratsdf_profile_read(ratsdf_engine* e, double* integrate_ms, int64_t* launches);
+
 /* VoxelHashTable::NumActiveBlock, voxel_hash.cu:225 */
 int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out);
 /* Counters of the most recently completed frame (synchronises). */

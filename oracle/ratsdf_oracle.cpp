@@ -234,6 +234,7 @@ struct ratsdf_engine {
         return false;
       }
     }
+    stats.slow_requests += 1;  // chained-bucket path (diagnostic counter only)
     last = e0 + 1;
     while (table[last].offset) last = (last + table[last].offset) & entry_mask;
     const uint32_t bucket_last = last >> 1;
@@ -640,6 +641,11 @@ int ratsdf_oracle_integrate_device(ratsdf_engine*, const void*, const void*, con
 int ratsdf_oracle_synchronize(ratsdf_engine* e) { return e ? e->sticky : RATSDF_ERR_BAD_ARGUMENT; }
 int ratsdf_oracle_stream(ratsdf_engine*, void** s) {
   if (s) *s = nullptr;
+  return RATSDF_ERR_NOT_IMPLEMENTED;
+}
+
+int ratsdf_oracle_profile_enable(ratsdf_engine*, int) { return RATSDF_ERR_NOT_IMPLEMENTED; }
+int ratsdf_oracle_profile_read(ratsdf_engine*, double*, int64_t*) {
   return RATSDF_ERR_NOT_IMPLEMENTED;
 }
 

@@ -1,0 +1,107 @@
+// device_math.h -- fp32 camera / pose arithmetic of the TSDF path, in the reference's evaluation
+// order.  Compiled with -ffp-contract=off: every multiply and add below is a separate rounding, as
+// in the reference's nvcc device code for these expressions is NOT guaranteed (nvcc contracts), so
+// the canonical order is the one fixed by the oracle and restated here operation by operation.
+//
+// Follows utils/cuda/camera.cuh:35-51 (K, K^-1), utils/cuda/lie_group.cuh:25-40 (SE3) and Eigen's
+// quaternion * vector (uv = 2 q.vec x v; v + w uv + q.vec x uv), hnormalized (per-component
+// division) and norm().
+#pragma once
+#include "device_types.h"
+
+namespace ratsdf {
+
+__host__ __device__ inline V3 cross3(const V3& a, const V3& b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+__host__ __device__ inline V3 quat_rotate(const Quat& q, const V3& v) {
+  const V3 qv{q.x, q.y, q.z};
+  V3 uv = cross3(qv, v);
+  uv.x += uv.x;
+  uv.y += uv.y;
+  uv.z += uv.z;
+  const V3 c = cross3(qv, uv);
+  return V3{(v.x + q.w * uv.x) + c.x, (v.y + q.w * uv.y) + c.y, (v.z + q.w * uv.z) + c.z};
+}
+
+__host__ __device__ inline V3 se3_apply(const Se3& T, const V3& v) {
+  const V3 r = quat_rotate(T.q, v);
+  return V3{r.x + T.t.x, r.y + T.t.y, r.z + T.t.z};
+}
+
+// SE3::Inverse (lie_group.cuh:25-27), host side like the reference (voxel_tsdf.cu:459)
+inline Se3 se3_inverse(const Se3& T) {
+  const Quat& q = T.q;
+  const float n2 = (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+  Quat qi;
+  if (n2 > 0.f) {
+    qi = Quat{(-q.x) / n2, (-q.y) / n2, (-q.z) / n2, q.w / n2};
+  } else {
+    qi = Quat{0.f, 0.f, 0.f, 0.f};
+  }
+  const V3 nt{-T.t.x, -T.t.y, -T.t.z};
+  return Se3{qi, quat_rotate(qi, nt)};
+}
+
+__host__ __device__ inline V3 intr_mul(const Intr& K, const V3& v) {
+  return V3{K.fx * v.x + K.cx * v.z, K.fy * v.y + K.cy * v.z, v.z};
+}
+
+inline Intr intr_inverse(const Intr& K) {
+  const float fxi = 1 / K.fx;
+  const float fyi = 1 / K.fy;
+  return Intr{fxi, fyi, -K.cx * fxi, -K.cy * fyi};
+}
+
+// float -> int, CUDA cvt.rzi semantics: NaN -> 0, saturating
+__device__ inline int f2i(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.f) return 2147483647;
+  if (f <= -2147483648.f) return (-2147483647 - 1);
+  return (int)f;
+}
+
+// Hash(), utils/tsdf/voxel_hash.cu:19-23
+__host__ __device__ inline uint32_t block_hash(int x, int y, int z, uint32_t mask) {
+  return (((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349669u) ^ ((uint32_t)z * 83492791u)) & mask;
+}
+
+// is_voxel_visible, utils/tsdf/voxel_tsdf.cu:64-73
+__device__ inline bool voxel_visible(int gx, int gy, int gz, const FrameParams& P) {
+  const V3 pw{(float)gx * P.vs, (float)gy * P.vs, (float)gz * P.vs};
+  const V3 pc = se3_apply(P.T, pw);
+  const V3 ph = intr_mul(P.K, pc);
+  const float u = ph.x / ph.z;
+  const float v = ph.y / ph.z;
+  return (u >= 0 && u <= (float)(P.W - 1) && v >= 0 && v <= (float)(P.H - 1) && ph.z >= 0);
+}
+
+// is_block_visible<Full>, utils/tsdf/voxel_tsdf.cu:75-96 (corner coordinates in short arithmetic)
+template <bool Full>
+__device__ inline bool block_visible(int bx, int by, int bz, const FrameParams& P) {
+  const int x = (int16_t)(bx << 3), y = (int16_t)(by << 3), z = (int16_t)(bz << 3);
+  bool vis = Full;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int cx = (int16_t)(x + ((i >> 0) & 1) * 7);
+    const int cy = (int16_t)(y + ((i >> 1) & 1) * 7);
+    const int cz = (int16_t)(z + ((i >> 2) & 1) * 7);
+    const bool v = voxel_visible(cx, cy, cz, P);
+    if (Full)
+      vis = vis && v;
+    else
+      vis = vis || v;
+  }
+  return vis;
+}
+
+__device__ inline bool shard_owned(int bx, const FrameParams& P) {
+  if (P.shard_count <= 1) return true;
+  const int s = bx >> P.shard_slab_bits;
+  int m = s % P.shard_count;
+  if (m < 0) m += P.shard_count;
+  return m == P.shard_rank;
+}
+
+}  // namespace ratsdf

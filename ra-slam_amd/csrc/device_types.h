@@ -1,0 +1,116 @@
+// device_types.h -- PODs shared by the gfx950 kernels and the host engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ratsdf.h"
+
+namespace ratsdf {
+
+constexpr uint32_t kInf = 0xFFFFFFFFu;      // "no claim" in the per-bucket claim table
+constexpr int32_t kPlaceholderIdx = 0x40000000;  // entry placed by the resolver, pool idx pending
+
+// VoxelBlock (utils/tsdf/voxel_mem.cuh:75-95): 12-byte hash directory entry.
+struct Entry {
+  int16_t x, y, z;
+  int16_t offset;
+  int32_t idx;
+};
+static_assert(sizeof(Entry) == 12, "directory entry is 12 bytes");
+
+// one element of the per-frame visible list: directory entry copy + where it lives
+struct VisItem {
+  int16_t x, y, z;
+  int16_t offset;
+  int32_t idx;
+  uint32_t entry;
+};
+static_assert(sizeof(VisItem) == 16, "visible item is 16 bytes");
+
+// allocation request that survived the claim filter (or was placed by the resolver)
+struct Request {
+  int16_t x, y, z;
+  uint16_t flags;
+  uint32_t rank;
+  uint32_t entry;
+};
+static_assert(sizeof(Request) == 16, "request is 16 bytes");
+constexpr uint16_t kReqWinner = 1;
+constexpr uint16_t kReqPlaced = 2;
+
+struct SlowRequest {
+  int16_t x, y, z;
+  uint16_t pad;
+  uint32_t rank;
+};
+static_assert(sizeof(SlowRequest) == 12, "slow request is 12 bytes");
+
+struct SlowDelete {
+  int16_t x, y, z;
+  uint16_t pad;
+  uint32_t vis;  // index in the visible list (= rank of the carve pass)
+};
+
+// Device-resident control block.  Words [0, kCtlFrameWords) are zeroed at the start of every frame.
+struct Ctl {
+  // --- per-frame (zeroed by a memset node) ---
+  uint32_t n_req;         // requests appended this pass
+  uint32_t n_slow;        // slow (chained-bucket) requests appended this pass
+  uint32_t n_win;         // winners of the allocation pass
+  uint32_t n_vis;         // V
+  uint32_t n_updated;     // U
+  uint32_t n_slow_del;    // slow deletes appended
+  uint32_t n_del;         // successful deletes
+  uint32_t alloc_base;    // num_free at the start of the allocation pass
+  uint32_t free_base;     // num_free at the start of the carve pass
+  uint32_t n_sel;         // selected blocks of a query / export
+  uint32_t pad0[6];
+  // --- persistent ---
+  int32_t num_free;       // VoxelMemPool::num_free_blocks_
+  uint32_t error;         // sticky ratsdf_status
+  uint32_t pad1[14];
+};
+constexpr int kCtlFrameBytes = 64;
+
+struct Quat {
+  float x, y, z, w;
+};
+struct V3 {
+  float x, y, z;
+};
+struct Se3 {
+  Quat q;
+  V3 t;
+};
+struct Intr {
+  float fx, fy, cx, cy;
+};
+
+// everything a frame's kernels need, passed by value
+struct FrameParams {
+  Se3 T;        // cam_T_world
+  Se3 Ti;       // world_T_cam (host-computed, voxel_tsdf.cu:459)
+  Intr K;
+  Intr Ki;
+  float vs, trunc, md;
+  int W, H;
+  int S;        // rank stride: max ray samples per pixel
+  int has_sem;
+  int shard_rank, shard_count, shard_slab_bits;
+};
+
+struct Table {
+  Entry* entries;
+  uint32_t* claim;
+  uint32_t num_bucket, num_entry, bucket_mask, entry_mask;
+  int32_t num_block;
+};
+
+struct Pool {
+  uint32_t* rgbw;
+  float* tsdf;
+  float* segm;
+  int32_t* heap;
+};
+
+}  // namespace ratsdf

@@ -1,0 +1,479 @@
+// kernels_alloc.h -- voxel-block allocation pass for gfx950.
+//
+// Replaces block_allocate_kernel + VoxelHashTable::Allocate + VoxelMemPool::AquireBlock +
+// ResetLocks (utils/tsdf/voxel_tsdf.cu:120-168,454-463; voxel_hash.cu:46-108; voxel_mem.cu:37-54).
+//
+// The reference serialises insertions with per-bucket try-locks that are only released after the
+// pass, so which thread wins a bucket and which pool block it pops are timing dependent.  Here the
+// outcome is made a pure function of the input: every candidate carries its raster rank
+// (pixel * S + sample) and the pass computes exactly what a sequential, rank-ordered execution of
+// the reference code would:
+//   k_alloc_pixels  per pixel: candidates, directory lookup, atomicMin(claim[bucket], rank) for
+//                   ordinary buckets ("first requester in raster order wins the bucket lock"),
+//                   append to a small slow list for chained / full buckets
+//   k_alloc_resolve one workgroup: replays the slow list in rank order against the claim table
+//                   (time-dependent lock / fill queries), so chain appends lock, link and defeat
+//                   later claims exactly as the sequential code would
+//   k_alloc_mark    winners (claim == own rank) set their bit in a rank-indexed bitmap
+//   k_alloc_scan    one workgroup: popcount prefix of the bitmap = order of AquireBlock calls
+//   k_alloc_commit  one wave per winner: pool index heap[free-1-k], directory entry, block init
+#pragma once
+#include "device_math.h"
+
+namespace ratsdf {
+
+__device__ inline void set_error(Ctl* ctl, uint32_t code) { atomicCAS(&ctl->error, 0u, code); }
+
+struct EntryWords {
+  uint32_t w0, w1;  // x | y << 16,  z | offset << 16
+  int32_t idx;
+};
+
+__device__ inline EntryWords load_entry(const Entry* entries, uint32_t e) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(entries + e);
+  EntryWords r;
+  r.w0 = p[0];
+  r.w1 = p[1];
+  r.idx = (int32_t)p[2];
+  return r;
+}
+__device__ inline int entry_offset(const EntryWords& w) { return (int16_t)(w.w1 >> 16); }
+__device__ inline bool entry_matches(const EntryWords& w, uint32_t k0, uint32_t k1) {
+  return w.idx >= 0 && w.w0 == k0 && (w.w1 & 0xFFFFu) == k1;
+}
+__device__ inline uint32_t key0(int x, int y) { return ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16); }
+__device__ inline uint32_t key1(int z) { return (uint32_t)z & 0xFFFFu; }
+
+// VoxelHashTable::GetBlock(pos, out), voxel_hash.cu:190-218.  Returns the entry index or kInf.
+__device__ inline uint32_t find_block(const Table& t, int x, int y, int z, EntryWords* out) {
+  const uint32_t k0 = key0(x, y), k1 = key1(z);
+  const uint32_t e0 = block_hash(x, y, z, t.bucket_mask) << 1;
+  EntryWords w = load_entry(t.entries, e0);
+  if (entry_matches(w, k0, k1)) { *out = w; return e0; }
+  w = load_entry(t.entries, e0 + 1);
+  if (entry_matches(w, k0, k1)) { *out = w; return e0 + 1; }
+  uint32_t last = e0 + 1;
+  int off = entry_offset(w);
+  uint32_t guard = 0;
+  while (off && guard++ < t.num_entry) {
+    last = (last + (uint32_t)off) & t.entry_mask;
+    w = load_entry(t.entries, last);
+    if (entry_matches(w, k0, k1)) { *out = w; return last; }
+    off = entry_offset(w);
+  }
+  out->w0 = k0;
+  out->w1 = k1 | 0xFFFF0000u;  // offset -1
+  out->idx = -1;
+  return kInf;
+}
+
+// One allocation request with raster rank `rank` for block (x,y,z), against the pre-pass directory.
+__device__ inline void alloc_request(const Table& t, int x, int y, int z, uint32_t rank, Request* req,
+                                     uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap,
+                                     Ctl* ctl) {
+  const uint32_t k0 = key0(x, y), k1 = key1(z);
+  const uint32_t bucket = block_hash(x, y, z, t.bucket_mask);
+  const uint32_t e0 = bucket << 1;
+  const EntryWords a = load_entry(t.entries, e0);
+  const EntryWords b = load_entry(t.entries, e0 + 1);
+  if (entry_matches(a, k0, k1) || entry_matches(b, k0, k1)) return;  // voxel_hash.cu:50-56
+  uint32_t last = e0 + 1;
+  int off = entry_offset(b);
+  uint32_t guard = 0;
+  while (off && guard++ < t.num_entry) {                               // voxel_hash.cu:58-65
+    last = (last + (uint32_t)off) & t.entry_mask;
+    const EntryWords w = load_entry(t.entries, last);
+    if (entry_matches(w, k0, k1)) return;
+    off = entry_offset(w);
+  }
+  // Buckets whose two home entries are full, or that head a chain, can reach the list-append code
+  // (voxel_hash.cu:79-106), which touches other buckets' locks: those go to the resolver.
+  const bool special = (a.idx >= 0 && b.idx >= 0) || entry_offset(b) != 0;
+  if (!special) {
+    const uint32_t old = atomicMin(&t.claim[bucket], rank);
+    if (rank < old) {
+      const uint32_t slot = atomicAdd(&ctl->n_req, 1u);
+      if (slot < req_cap) {
+        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, 0};
+      } else {
+        set_error(ctl, RATSDF_ERR_CAPACITY);
+      }
+    }
+  } else {
+    const uint32_t slot = atomicAdd(&ctl->n_slow, 1u);
+    if (slot < slow_cap) {
+      slow[slot] = SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank};
+    } else {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_alloc_pixels: block_allocate_kernel, voxel_tsdf.cu:120-168.  One lane per pixel, 64 consecutive
+// pixels of a row per wave (coalesced depth / ht / lt reads).  Also writes the packed per-pixel
+// texels the integration kernel gathers from: texA = {depth, range, log ht, log lt},
+// texB = {rgb, w_new}.  log(ht), log(lt) and w_new = (1 - d/max_depth)*4 are functions of the pixel
+// only (voxel_tsdf.cu:226,243,246), so evaluating them once per pixel instead of once per voxel is
+// value-identical.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_alloc_pixels(Table tab, FrameParams P, const float* depth,
+                                                      const uint8_t* rgb, const float* ht,
+                                                      const float* lt, float4* texA, uint2* texB,
+                                                      Request* req, uint32_t req_cap,
+                                                      SlowRequest* slow, uint32_t slow_cap,
+                                                      Ctl* ctl) {
+  const int npix = P.W * P.H;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool inb = pix < npix;
+  const int px = inb ? pix % P.W : 0;
+  const int py = inb ? pix / P.W : 0;
+  const float d = inb ? depth[pix] : 0.f;
+
+  const V3 pimg{(float)px, (float)py, 1.f};
+  const V3 pc = intr_mul(P.Ki, pimg);                                   // :137
+  const float r = sqrtf(pc.x * pc.x + (pc.y * pc.y + pc.z * pc.z));     // :140 (Eigen norm order)
+  if (inb) {
+    float lh = 0.f, ll = 0.f;
+    if (P.has_sem) {
+      lh = logf(ht[pix]);
+      ll = logf(lt[pix]);
+    }
+    const float wn = (1 - d / P.md) * 4;
+    const uint32_t c = (uint32_t)rgb[3 * pix] | ((uint32_t)rgb[3 * pix + 1] << 8) |
+                       ((uint32_t)rgb[3 * pix + 2] << 16);
+    texA[pix] = make_float4(d, r, lh, ll);
+    texB[pix] = make_uint2(c, __float_as_uint(wn));
+  }
+  const bool valid = inb && !(d == 0 || d > P.md);                      // :141
+
+  const V3 pcd{pc.x * d, pc.y * d, pc.z * d};
+  const V3 pw = se3_apply(P.Ti, pcd);                                   // :146
+  const V3 dc{pc.x / r, pc.y / r, pc.z / r};                            // :148
+  const V3 dw = quat_rotate(P.Ti.q, dc);                                // :150
+  const V3 sw{pw.x - dw.x * P.trunc, pw.y - dw.y * P.trunc, pw.z - dw.z * P.trunc};  // :151
+  const V3 dg{dw.x / P.vs, dw.y / P.vs, dw.z / P.vs};                   // :153
+  const V3 sg{sw.x / P.vs, sw.y / P.vs, sw.z / P.vs};                   // :154
+  const float two_tr = 2 * P.trunc;
+  const V3 rg{two_tr * dg.x, two_tr * dg.y, two_tr * dg.z};             // :155
+  int steps = f2i(ceilf(fmaxf(fmaxf(fabsf(rg.x), fabsf(rg.y)), fabsf(rg.z)) / RATSDF_BLOCK_LEN));
+  const float den = fmaxf((float)steps, 1);
+  const V3 st{rg.x / den, rg.y / den, rg.z / den};                      // :159
+  if (valid && steps >= P.S) {  // cannot happen for |dir| <= 1; keep ranks unique regardless
+    set_error(ctl, RATSDF_ERR_CAPACITY);
+    steps = P.S - 1;
+  }
+  V3 p = sg;
+  uint32_t prev0 = kInf, prev1 = kInf;  // this lane's previous sample
+  for (int i = 0; i < P.S; ++i) {       // uniform trip count: the shuffles below need every lane
+    const bool act = valid && i <= steps;
+    const int gx = (int16_t)f2i(roundf(p.x)), gy = (int16_t)f2i(roundf(p.y)),
+              gz = (int16_t)f2i(roundf(p.z));                           // :163-164
+    const int bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
+    const uint32_t k0 = act ? key0(bx, by) : kInf;
+    const uint32_t k1 = act ? key1(bz) : kInf;
+    // A later request for the same block never matters (the earlier one either inserts it or fails
+    // on a lock that stays taken), so drop repeats of the previous sample / the previous pixel.
+    const uint32_t n0 = __shfl_up(k0, 1), n1 = __shfl_up(k1, 1);
+    const bool dup = (k0 == prev0 && k1 == prev1) || (lane > 0 && k0 == n0 && k1 == n1);
+    if (act && !dup && shard_owned(bx, P)) {
+      // lookup first (cheap, usually a hit), the 8-corner frustum test only for absent blocks
+      // (both are pure predicates; the reference tests visibility first, :165-166)
+      EntryWords w;
+      if (find_block(tab, bx, by, bz, &w) == kInf && block_visible<true>(bx, by, bz, P)) {
+        alloc_request(tab, bx, by, bz, (uint32_t)pix * (uint32_t)P.S + (uint32_t)i, req, req_cap,
+                      slow, slow_cap, ctl);
+      }
+    }
+    if (act) {
+      prev0 = k0;
+      prev1 = k1;
+    }
+    p.x += st.x;
+    p.y += st.y;
+    p.z += st.z;
+  }
+}
+
+// test hook: explicit request list, rank = list index (utils/tests/voxel_hash_test.cu:36-39)
+__global__ void k_alloc_list(Table tab, FrameParams P, const int16_t* pos, int n, Request* req,
+                             uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap, Ctl* ctl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+  if (!shard_owned(x, P)) return;
+  alloc_request(tab, x, y, z, (uint32_t)i, req, req_cap, slow, slow_cap, ctl);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_alloc_resolve: exact rank-ordered replay of VoxelHashTable::Allocate (voxel_hash.cu:46-108) for
+// requests whose home bucket is full or heads a chain.  Single workgroup; returns at once when the
+// slow list is empty (the common case).  Everything an ordinary bucket does during the pass is
+// summarised by its claim (min rank): bucket x is locked from time claim[x] on, and its leader
+// fills the first empty home entry at that time unless an earlier slow request locked x first.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSlowSortCap = 16384;   // slow requests per pass (LDS bitonic sort, 128 KiB)
+constexpr int kSlowDistinctCap = 1024;
+constexpr int kXLockCap = 2048;
+
+struct XLock {
+  uint32_t bucket, time;
+};
+
+__global__ __launch_bounds__(1024) void k_alloc_resolve(Table tab, Request* req, uint32_t req_cap,
+                                                        const SlowRequest* slow, uint32_t slow_cap,
+                                                        XLock* xlocks, SlowRequest* distinct,
+                                                        Ctl* ctl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  uint32_t n = ctl->n_slow;
+  if (n == 0) return;
+  if (n > slow_cap) n = slow_cap;
+  if (n > (uint32_t)kSlowSortCap) {
+    if (threadIdx.x == 0) set_error(ctl, RATSDF_ERR_CAPACITY);
+    n = kSlowSortCap;
+  }
+  uint32_t m = 1;
+  while (m < n) m <<= 1;
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
+    skeys[i] = i < n ? (((unsigned long long)slow[i].rank << 32) | i) : ~0ull;
+  __syncthreads();
+  for (uint32_t k = 2; k <= m; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = skeys[i], b = skeys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            skeys[i] = b;
+            skeys[l] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x != 0) return;
+
+  uint32_t n_x = 0, n_d = 0;
+  auto locked_at = [&](uint32_t bucket, uint32_t time) -> bool {
+    const uint32_t c = tab.claim[bucket];
+    if (c != kInf && c < time) return true;
+    for (uint32_t i = 0; i < n_x; ++i)
+      if (xlocks[i].bucket == bucket) return true;  // every recorded lock is earlier than `time`
+    return false;
+  };
+  auto take_lock = [&](uint32_t bucket, uint32_t time) {
+    if (n_x < (uint32_t)kXLockCap) {
+      xlocks[n_x++] = XLock{bucket, time};
+    } else {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+    }
+    const uint32_t c = tab.claim[bucket];
+    if (c != kInf && c > time) tab.claim[bucket] = kInf;  // a later leader finds the lock taken
+  };
+  auto place = [&](uint32_t e, const SlowRequest& s) {
+    uint32_t* p = reinterpret_cast<uint32_t*>(tab.entries + e);
+    p[0] = key0(s.x, s.y);
+    p[1] = key1(s.z);  // offset 0
+    p[2] = (uint32_t)kPlaceholderIdx;
+    const uint32_t slot = atomicAdd(&ctl->n_req, 1u);
+    if (slot < req_cap) {
+      req[slot] = Request{s.x, s.y, s.z, (uint16_t)(kReqWinner | kReqPlaced), s.rank, e};
+    } else {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+    }
+  };
+
+  for (uint32_t si = 0; si < n; ++si) {
+    const SlowRequest s = slow[(uint32_t)(skeys[si] & 0xFFFFFFFFu)];
+    bool seen = false;
+    for (uint32_t i = 0; i < n_d && !seen; ++i)
+      seen = distinct[i].x == s.x && distinct[i].y == s.y && distinct[i].z == s.z;
+    if (seen) continue;  // same block, later rank: irrelevant
+    if (n_d < (uint32_t)kSlowDistinctCap) {
+      distinct[n_d++] = s;
+    } else {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+      break;
+    }
+    const uint32_t time = s.rank;
+    const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
+    const uint32_t e0 = bucket << 1;
+    EntryWords w;
+    if (find_block(tab, s.x, s.y, s.z, &w) != kInf) continue;          // :48-65
+    bool handled = false;
+    for (uint32_t i = 0; i < 2 && !handled; ++i) {                      // :67-78
+      if (load_entry(tab.entries, e0 + i).idx < 0) {
+        if (!locked_at(bucket, time)) {
+          take_lock(bucket, time);
+          place(e0 + i, s);
+        }
+        handled = true;
+      }
+    }
+    if (handled) continue;
+    uint32_t last = e0 + 1;                                             // :80-84
+    for (uint32_t g = 0; g < tab.num_entry; ++g) {
+      const int off = entry_offset(load_entry(tab.entries, last));
+      if (!off) break;
+      last = (last + (uint32_t)off) & tab.entry_mask;
+    }
+    const uint32_t bucket_last = last >> 1;
+    uint32_t next = last;
+    bool found = false;
+    for (uint32_t g = 0; g < tab.num_entry && !found; ++g) {            // :86-91
+      next = (next + 1) & tab.entry_mask;
+      if ((next & 1u) == 1u) continue;  // never the last slot of a bucket
+      if (load_entry(tab.entries, next).idx >= 0) continue;
+      const uint32_t c = tab.claim[next >> 1];
+      if (c != kInf && c < time) continue;  // that bucket's leader has filled its slot 0 by now
+      found = true;
+    }
+    if (!found) continue;
+    const uint32_t bucket_next = next >> 1;
+    if (!locked_at(bucket_last, time)) {                                // :93-94 (short-circuit &&)
+      take_lock(bucket_last, time);
+      if (!locked_at(bucket_next, time)) {
+        take_lock(bucket_next, time);
+        const uint32_t wrap = next > last ? 0u : tab.num_entry;
+        uint32_t* pl = reinterpret_cast<uint32_t*>(tab.entries + last);
+        const int16_t link = (int16_t)(next + wrap - last);             // :98-99
+        pl[1] = (pl[1] & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16);
+        place(next, s);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_alloc_mark(Table tab, Request* req, uint32_t req_cap,
+                                                    uint32_t* bitmap, Ctl* ctl) {
+  uint32_t n = ctl->n_req;
+  if (n > req_cap) n = req_cap;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    Request r = req[i];
+    bool win = (r.flags & kReqWinner) != 0;
+    if (!(r.flags & kReqPlaced)) {
+      const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
+      win = tab.claim[bucket] == r.rank;
+      if (win) req[i].flags = kReqWinner;
+    }
+    if (win) atomicOr(&bitmap[r.rank >> 5], 1u << (r.rank & 31));
+  }
+}
+
+// One workgroup: exclusive popcount prefix over `nwords` bitmap words; total -> *total_out.
+// Also zeroes the other (next pass's) bitmap.
+__device__ inline uint32_t bitmap_prefix_scan(const uint32_t* bitmap, uint32_t* prefix,
+                                              uint32_t nwords, uint32_t* lds /* 1024 words */) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t chunk = (nwords + nt - 1) / nt;
+  const uint32_t lo = tid * chunk;
+  const uint32_t hi = lo + chunk < nwords ? lo + chunk : nwords;
+  uint32_t sum = 0;
+  for (uint32_t w = lo; w < hi; ++w)
+    sum += __popc(__hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  lds[tid] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < nt; d <<= 1) {  // Hillis-Steele inclusive scan over the thread sums
+    const uint32_t v = tid >= d ? lds[tid - d] : 0;
+    __syncthreads();
+    lds[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = lds[tid] - sum;
+  for (uint32_t w = lo; w < hi; ++w) {
+    prefix[w] = run;
+    run += __popc(__hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  return lds[nt - 1];
+}
+
+__global__ __launch_bounds__(1024) void k_alloc_scan(const uint32_t* bitmap, uint32_t* prefix,
+                                                     uint32_t nwords, uint32_t* next_bitmap,
+                                                     uint32_t next_words, Ctl* ctl) {
+  __shared__ uint32_t lds[1024];
+  const uint32_t total = bitmap_prefix_scan(bitmap, prefix, nwords, lds);
+  for (uint32_t w = threadIdx.x; w < next_words; w += blockDim.x) next_bitmap[w] = 0;
+  if (threadIdx.x == 0) {
+    const int32_t nf = ctl->num_free;
+    uint32_t take = total;
+    if ((int64_t)total > (int64_t)nf) {  // voxel_mem.cu:39 assert(idx >= 1)
+      set_error(ctl, RATSDF_ERR_POOL_EXHAUSTED);
+      take = (uint32_t)nf;
+    }
+    ctl->alloc_base = (uint32_t)nf;
+    ctl->n_win = take;
+    ctl->num_free = nf - (int32_t)take;
+  }
+}
+
+// One wave per request.  Winner k (in rank order) takes heap[alloc_base - 1 - k]
+// (AquireBlock, voxel_mem.cu:37-41), gets its directory entry written (voxel_hash.cu:72-74,101-103)
+// and its 512 voxels initialised to weight 1 / tsdf -1 / probability .5 with rgb left untouched
+// (voxel_mem.cu:43-51).  Every request also releases its bucket's claim (ResetLocks).
+__global__ __launch_bounds__(256) void k_alloc_commit(Table tab, Pool pool, const Request* req,
+                                                      uint32_t req_cap, const uint32_t* bitmap,
+                                                      const uint32_t* prefix, Ctl* ctl) {
+  uint32_t n = ctl->n_req;
+  if (n > req_cap) n = req_cap;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t base = ctl->alloc_base;
+  for (uint32_t i = wave; i < n; i += nwaves) {
+    const Request r = req[i];
+    const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
+    const bool placed = (r.flags & kReqPlaced) != 0;
+    if (!(r.flags & kReqWinner)) {
+      if (lane == 0 && !placed) tab.claim[bucket] = kInf;
+      continue;
+    }
+    const uint32_t word = bitmap[r.rank >> 5];
+    const uint32_t k = prefix[r.rank >> 5] + __popc(word & ((1u << (r.rank & 31)) - 1u));
+    uint32_t e = r.entry;
+    if (!placed) {
+      const uint32_t e0 = bucket << 1;
+      e = (load_entry(tab.entries, e0).idx < 0) ? e0 : e0 + 1;
+    }
+    uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + e);
+    if (k >= base) {  // pool exhausted: this insertion does not happen
+      if (lane == 0) {
+        if (placed) pe[2] = (uint32_t)-1;
+        else tab.claim[bucket] = kInf;
+      }
+      continue;
+    }
+    const int32_t idx = pool.heap[base - 1 - k];
+    if (lane == 0) {
+      if (!placed) {
+        pe[0] = key0(r.x, r.y);
+        pe[1] = key1(r.z);
+        tab.claim[bucket] = kInf;
+      }
+      pe[2] = (uint32_t)idx;
+    }
+    const size_t v = ((size_t)idx << 9) + lane * 8;
+    float4* pt = reinterpret_cast<float4*>(pool.tsdf + v);
+    float4* ps = reinterpret_cast<float4*>(pool.segm + v);
+    uint4* pc = reinterpret_cast<uint4*>(pool.rgbw + v);
+    const float4 m1 = make_float4(-1.f, -1.f, -1.f, -1.f);
+    const float4 hf = make_float4(.5f, .5f, .5f, .5f);
+    pt[0] = m1;
+    pt[1] = m1;
+    ps[0] = hf;
+    ps[1] = hf;
+    uint4 c0 = pc[0], c1 = pc[1];
+    const uint32_t keep = 0x00FFFFFFu, one = 0x01000000u;
+    c0.x = (c0.x & keep) | one; c0.y = (c0.y & keep) | one;
+    c0.z = (c0.z & keep) | one; c0.w = (c0.w & keep) | one;
+    c1.x = (c1.x & keep) | one; c1.y = (c1.y & keep) | one;
+    c1.z = (c1.z & keep) | one; c1.w = (c1.w & keep) | one;
+    pc[0] = c0;
+    pc[1] = c1;
+  }
+}
+
+}  // namespace ratsdf

@@ -1,0 +1,775 @@
+// ratsdf_engine.hip -- host side of the MI355X-native TSDF engine: device memory, the per-frame
+// launch sequence on one HIP stream, and the C ABI of include/ratsdf.h.
+//
+// Replaces TSDFGrid (utils/tsdf/voxel_tsdf.cu:376-559,847-883), VoxelHashTable / VoxelMemPool host
+// parts (voxel_hash.cu:25-44,225; voxel_mem.cu:13-35,63-67).  gfx950 only; there is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kernels_integrate.h"
+
+using namespace ratsdf;
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t err__ = (expr);                                                            \
+    if (err__ != hipSuccess) {                                                            \
+      fprintf(stderr, "[ratsdf] HIP error %s at %s:%d: %s\n", hipGetErrorName(err__),     \
+              __FILE__, __LINE__, #expr);                                                 \
+      return RATSDF_ERR_DEVICE;                                                           \
+    }                                                                                     \
+  } while (0)
+
+namespace {
+
+__global__ void k_init_table(Entry* entries, uint32_t* claim, uint32_t num_entry,
+                             uint32_t num_bucket) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < num_entry) entries[i] = Entry{0, 0, 0, 0, -1};  // init_hash_table_kernel, voxel_hash.cu:14-17
+  if (i < num_bucket) claim[i] = kInf;
+}
+__global__ void k_init_heap(int32_t* heap, int32_t n) {   // heap_init_kernel, voxel_mem.cu:6-11
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) heap[i] = i;
+}
+
+constexpr uint32_t kSlowCap = kSlowSortCap;
+constexpr uint32_t kSlowDelCap = 1u << 16;
+
+}  // namespace
+
+struct ratsdf_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  float vs = 0, trunc = 0;
+  int block_bits = 0, bucket_bits = 0;
+  int shard_rank = 0, shard_count = 1, shard_slab_bits = 2;
+  int S = 3;
+
+  Table tab{};
+  Pool pool{};
+  Ctl* ctl = nullptr;
+  ratsdf_frame_stats* d_stats = nullptr;
+
+  // image-sized scratch
+  size_t pix_cap = 0, rank_cap = 0;
+  float4* texA = nullptr;
+  uint2* texB = nullptr;
+  Request* req = nullptr;
+  uint32_t req_cap = 0;
+  uint32_t* abitmap[2] = {nullptr, nullptr};
+  uint32_t* aprefix = nullptr;
+  uint32_t awords_cap = 0;
+  int apass = 0;
+
+  SlowRequest* slow = nullptr;
+  XLock* xlocks = nullptr;
+  SlowRequest* distinct = nullptr;
+
+  // directory-sized scratch
+  unsigned long long* masks = nullptr;
+  uint32_t* wg_count = nullptr;
+  uint32_t* wg_offset = nullptr;
+  uint32_t nwg = 0;
+  VisItem* vis = nullptr;
+  uint8_t* carve_flag = nullptr;
+  uint32_t* dbitmap[2] = {nullptr, nullptr};
+  uint32_t* dprefix = nullptr;
+  uint32_t dwords = 0;
+  int dpass = 0;
+  int32_t* del_idx = nullptr;
+  SlowDelete* slowdel = nullptr;
+
+  // staging for the host-image entry point
+  size_t stage_pix = 0;
+  uint8_t* h_stage = nullptr;  // pinned
+  uint8_t* d_stage = nullptr;
+
+  // profiling of the dominant kernel
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_ms = 0;
+  int64_t prof_n = 0;
+
+  int free_all();
+  int ensure_image(size_t npix, size_t nranks);
+  int ensure_stage(size_t npix);
+  int alloc_tail(uint32_t nranks);
+  int carve_tail();
+  int select(int mode, const GridBounds& gb, uint32_t* count_slot);
+  int frame(const void* d_rgb, const void* d_depth, const void* d_ht, const void* d_lt, int H, int W,
+            float md, const ratsdf_intrinsics* K, const ratsdf_pose* T);
+  int sticky();
+  int drain_profile();
+  FrameParams base_params() const;
+};
+
+FrameParams ratsdf_engine::base_params() const {
+  FrameParams P;
+  memset(&P, 0, sizeof(P));
+  P.T = Se3{Quat{0, 0, 0, 1}, V3{0, 0, 0}};
+  P.Ti = P.T;
+  P.K = Intr{1, 1, 0, 0};
+  P.Ki = P.K;
+  P.vs = vs;
+  P.trunc = trunc;
+  P.md = 0;
+  P.W = P.H = 0;
+  P.S = 1;
+  P.has_sem = 0;
+  P.shard_rank = shard_rank;
+  P.shard_count = shard_count;
+  P.shard_slab_bits = shard_slab_bits;
+  return P;
+}
+
+int ratsdf_engine::free_all() {
+  if (stream) (void)hipStreamSynchronize(stream);
+  void* ptrs[] = {tab.entries, tab.claim, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl, d_stats,
+                  texA, texB, req, abitmap[0], abitmap[1], aprefix, slow, xlocks, distinct, masks,
+                  wg_count, wg_offset, vis, carve_flag, dbitmap[0], dbitmap[1], dprefix, del_idx,
+                  slowdel, d_stage};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h_stage) (void)hipHostFree(h_stage);
+  for (auto& ev : prof_events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (stream) (void)hipStreamDestroy(stream);
+  return RATSDF_OK;
+}
+
+int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
+  if (npix <= pix_cap && nranks <= rank_cap) return RATSDF_OK;
+  HIPCHK(hipStreamSynchronize(stream));
+  if (npix > pix_cap) {
+    if (texA) (void)hipFree(texA);
+    if (texB) (void)hipFree(texB);
+    HIPCHK(hipMalloc(&texA, npix * sizeof(float4)));
+    HIPCHK(hipMalloc(&texB, npix * sizeof(uint2)));
+    pix_cap = npix;
+  }
+  if (nranks > rank_cap) {
+    if (req) (void)hipFree(req);
+    if (abitmap[0]) (void)hipFree(abitmap[0]);
+    if (abitmap[1]) (void)hipFree(abitmap[1]);
+    if (aprefix) (void)hipFree(aprefix);
+    req_cap = (uint32_t)nranks;
+    awords_cap = (uint32_t)((nranks + 31) / 32);
+    HIPCHK(hipMalloc(&req, (size_t)req_cap * sizeof(Request)));
+    HIPCHK(hipMalloc(&abitmap[0], (size_t)awords_cap * 4));
+    HIPCHK(hipMalloc(&abitmap[1], (size_t)awords_cap * 4));
+    HIPCHK(hipMalloc(&aprefix, (size_t)awords_cap * 4));
+    rank_cap = nranks;
+  }
+  // both rank bitmaps must be clean whenever the rank space changes
+  HIPCHK(hipMemsetAsync(abitmap[0], 0, (size_t)awords_cap * 4, stream));
+  HIPCHK(hipMemsetAsync(abitmap[1], 0, (size_t)awords_cap * 4, stream));
+  return RATSDF_OK;
+}
+
+int ratsdf_engine::ensure_stage(size_t npix) {
+  if (npix <= stage_pix) return RATSDF_OK;
+  HIPCHK(hipStreamSynchronize(stream));
+  if (h_stage) (void)hipHostFree(h_stage);
+  if (d_stage) (void)hipFree(d_stage);
+  h_stage = nullptr;
+  d_stage = nullptr;
+  const size_t bytes = npix * 16;  // rgb 3 (padded to 4) + depth 4 + ht 4 + lt 4
+  HIPCHK(hipHostMalloc(&h_stage, bytes, hipHostMallocDefault));
+  HIPCHK(hipMalloc(&d_stage, bytes));
+  stage_pix = npix;
+  return RATSDF_OK;
+}
+
+// resolve -> mark -> scan -> commit on a rank space of `nranks`
+int ratsdf_engine::alloc_tail(uint32_t nranks) {
+  const uint32_t nwords = (nranks + 31) / 32;
+  uint32_t* bm = abitmap[apass & 1];
+  uint32_t* bm_next = abitmap[(apass + 1) & 1];
+  hipLaunchKernelGGL(k_alloc_resolve, dim3(1), dim3(1024), kSlowSortCap * sizeof(unsigned long long),
+                     stream, tab, req, req_cap, slow, kSlowCap, xlocks, distinct, ctl);
+  hipLaunchKernelGGL(k_alloc_mark, dim3(128), dim3(256), 0, stream, tab, req, req_cap, bm, ctl);
+  hipLaunchKernelGGL(k_alloc_scan, dim3(1), dim3(1024), 0, stream, bm, aprefix, nwords, bm_next,
+                     nwords, ctl);
+  hipLaunchKernelGGL(k_alloc_commit, dim3(512), dim3(256), 0, stream, tab, pool, req, req_cap, bm,
+                     aprefix, ctl);
+  ++apass;
+  HIPCHK(hipGetLastError());
+  return RATSDF_OK;
+}
+
+int ratsdf_engine::carve_tail() {
+  uint32_t* bm = dbitmap[dpass & 1];
+  uint32_t* bm_next = dbitmap[(dpass + 1) & 1];
+  hipLaunchKernelGGL(k_carve_mark, dim3(128), dim3(256), 0, stream, tab, vis, carve_flag, bm,
+                     del_idx, slowdel, kSlowDelCap, ctl);
+  hipLaunchKernelGGL(k_carve_scan, dim3(1), dim3(1024), 0, stream, tab, slowdel, kSlowDelCap, bm,
+                     dprefix, del_idx, bm_next, dwords, ctl, d_stats);
+  hipLaunchKernelGGL(k_carve_commit, dim3(128), dim3(256), 0, stream, pool, bm, dprefix, del_idx,
+                     ctl);
+  ++dpass;
+  HIPCHK(hipGetLastError());
+  return RATSDF_OK;
+}
+
+// ordered compaction of the directory into `vis`; the count lands in *count_slot (device)
+int ratsdf_engine::select(int mode, const GridBounds& gb, uint32_t* count_slot) {
+  FrameParams P = base_params();
+  if (mode == kSelValid)
+    hipLaunchKernelGGL(k_select_flags<kSelValid>, dim3(nwg), dim3(kSelWG), 0, stream, tab, P, gb,
+                       masks, wg_count);
+  else
+    hipLaunchKernelGGL(k_select_flags<kSelBounds>, dim3(nwg), dim3(kSelWG), 0, stream, tab, P, gb,
+                       masks, wg_count);
+  hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, stream, wg_count, wg_offset, nwg,
+                     count_slot);
+  hipLaunchKernelGGL(k_select_scatter, dim3(nwg), dim3(kSelWG), 0, stream, tab, masks, wg_count,
+                     wg_offset, vis, (uint32_t)tab.num_block);
+  HIPCHK(hipGetLastError());
+  return RATSDF_OK;
+}
+
+int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_ht, const void* d_lt,
+                         int H, int W, float md, const ratsdf_intrinsics* K, const ratsdf_pose* T) {
+  const size_t npix = (size_t)H * W;
+  if (npix * (size_t)S >= 0xFFFFFFFFull) return RATSDF_ERR_BAD_ARGUMENT;
+  int st = ensure_image(npix, npix * (size_t)S);
+  if (st != RATSDF_OK) return st;
+  FrameParams P = base_params();
+  P.T = Se3{Quat{T->qx, T->qy, T->qz, T->qw}, V3{T->tx, T->ty, T->tz}};
+  P.Ti = se3_inverse(P.T);                       // voxel_tsdf.cu:459
+  P.K = Intr{K->fx, K->fy, K->cx, K->cy};
+  P.Ki = intr_inverse(P.K);                      // camera.cuh:67
+  P.md = md;
+  P.W = W;
+  P.H = H;
+  P.S = S;
+  P.has_sem = (d_ht && d_lt) ? 1 : 0;
+
+  HIPCHK(hipMemsetAsync(ctl, 0, kCtlFrameBytes, stream));
+  hipLaunchKernelGGL(k_alloc_pixels, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, tab,
+                     P, (const float*)d_depth, (const uint8_t*)d_rgb, (const float*)d_ht,
+                     (const float*)d_lt, texA, texB, req, req_cap, slow, kSlowCap, ctl);
+  st = alloc_tail((uint32_t)(npix * (size_t)S));
+  if (st != RATSDF_OK) return st;
+
+  hipLaunchKernelGGL(k_select_flags<kSelVisible>, dim3(nwg), dim3(kSelWG), 0, stream, tab, P,
+                     GridBounds{}, masks, wg_count);
+  hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, stream, wg_count, wg_offset, nwg,
+                     &ctl->n_vis);
+  hipLaunchKernelGGL(k_select_scatter, dim3(nwg), dim3(kSelWG), 0, stream, tab, masks, wg_count,
+                     wg_offset, vis, (uint32_t)tab.num_block);
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (profiling) {
+    if (prof_used == prof_events.size()) {
+      hipEvent_t a, b;
+      HIPCHK(hipEventCreate(&a));
+      HIPCHK(hipEventCreate(&b));
+      prof_events.emplace_back(a, b);
+    }
+    ev0 = prof_events[prof_used].first;
+    ev1 = prof_events[prof_used].second;
+    ++prof_used;
+    HIPCHK(hipEventRecord(ev0, stream));
+  }
+  hipLaunchKernelGGL(k_integrate, dim3(2048), dim3(256), 0, stream, pool, P, vis, texA, texB,
+                     carve_flag, ctl);
+  if (profiling) HIPCHK(hipEventRecord(ev1, stream));
+
+  st = carve_tail();
+  if (st != RATSDF_OK) return st;
+  if (profiling && prof_used >= 4096) return drain_profile();
+  return RATSDF_OK;
+}
+
+int ratsdf_engine::drain_profile() {
+  if (!prof_used) return RATSDF_OK;
+  HIPCHK(hipStreamSynchronize(stream));
+  for (size_t i = 0; i < prof_used; ++i) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, prof_events[i].first, prof_events[i].second));
+    prof_ms += ms;
+    ++prof_n;
+  }
+  prof_used = 0;
+  return RATSDF_OK;
+}
+
+int ratsdf_engine::sticky() {
+  uint32_t err = 0;
+  HIPCHK(hipMemcpyAsync(&err, &ctl->error, sizeof(err), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  return (int)err;
+}
+
+// ================================== C ABI =====================================================
+extern "C" {
+
+int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
+  if (!cfg || !out) return RATSDF_ERR_BAD_ARGUMENT;
+  if (!(cfg->voxel_size > 0) || !(cfg->truncation > 0)) return RATSDF_ERR_BAD_ARGUMENT;
+  const int bb = cfg->block_bits ? cfg->block_bits : RATSDF_DEFAULT_BLOCK_BITS;
+  const int kb = cfg->bucket_bits ? cfg->bucket_bits : RATSDF_DEFAULT_BUCKET_BITS;
+  if (bb < 1 || bb > 24 || kb < 9 || kb > 26) return RATSDF_ERR_BAD_ARGUMENT;
+  if (cfg->shard_count > 1 && (cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_count))
+    return RATSDF_ERR_BAD_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RATSDF_ERR_NO_DEVICE;
+  if (cfg->device < 0 || cfg->device >= ndev) return RATSDF_ERR_BAD_ARGUMENT;
+  HIPCHK(hipSetDevice(cfg->device));
+  ratsdf_engine* e = new (std::nothrow) ratsdf_engine();
+  if (!e) return RATSDF_ERR_DEVICE;
+  e->device = cfg->device;
+  e->vs = cfg->voxel_size;
+  e->trunc = cfg->truncation;
+  e->block_bits = bb;
+  e->bucket_bits = kb;
+  e->shard_rank = cfg->shard_rank;
+  e->shard_count = cfg->shard_count > 1 ? cfg->shard_count : 1;
+  e->shard_slab_bits = cfg->shard_slab_bits > 0 ? cfg->shard_slab_bits : 2;
+  e->S = (int)ceilf(2.f * e->trunc / e->vs / RATSDF_BLOCK_LEN) + 2;
+  Table& t = e->tab;
+  t.num_block = 1 << bb;
+  t.num_bucket = 1u << kb;
+  t.num_entry = t.num_bucket << 1;
+  t.bucket_mask = t.num_bucket - 1;
+  t.entry_mask = t.num_entry - 1;
+  e->nwg = t.num_entry / kSelWG;
+  e->dwords = ((uint32_t)t.num_block + 31) / 32;
+  const size_t nvox = (size_t)t.num_block << 9;
+
+#define CREATE_CHK(expr)                 \
+  do {                                   \
+    if ((expr) != hipSuccess) {          \
+      fprintf(stderr, "[ratsdf] create failed: %s\n", #expr); \
+      e->free_all();                     \
+      delete e;                          \
+      return RATSDF_ERR_DEVICE;          \
+    }                                    \
+  } while (0)
+
+  CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  CREATE_CHK(hipMalloc(&t.entries, (size_t)t.num_entry * sizeof(Entry)));
+  CREATE_CHK(hipMalloc(&t.claim, (size_t)t.num_bucket * 4));
+  CREATE_CHK(hipMalloc(&e->pool.rgbw, nvox * 4));
+  CREATE_CHK(hipMalloc(&e->pool.tsdf, nvox * 4));
+  CREATE_CHK(hipMalloc(&e->pool.segm, nvox * 4));
+  CREATE_CHK(hipMalloc(&e->pool.heap, (size_t)t.num_block * 4));
+  CREATE_CHK(hipMalloc(&e->ctl, sizeof(Ctl)));
+  CREATE_CHK(hipMalloc(&e->d_stats, sizeof(ratsdf_frame_stats)));
+  CREATE_CHK(hipMalloc(&e->slow, (size_t)kSlowCap * sizeof(SlowRequest)));
+  CREATE_CHK(hipMalloc(&e->xlocks, (size_t)kXLockCap * sizeof(XLock)));
+  CREATE_CHK(hipMalloc(&e->distinct, (size_t)kSlowDistinctCap * sizeof(SlowRequest)));
+  CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * (kSelWG / 64) * 8));
+  CREATE_CHK(hipMalloc(&e->wg_count, (size_t)e->nwg * 4));
+  CREATE_CHK(hipMalloc(&e->wg_offset, (size_t)e->nwg * 4));
+  CREATE_CHK(hipMalloc(&e->vis, (size_t)t.num_block * sizeof(VisItem)));
+  CREATE_CHK(hipMalloc(&e->carve_flag, (size_t)t.num_block));
+  CREATE_CHK(hipMalloc(&e->dbitmap[0], (size_t)e->dwords * 4));
+  CREATE_CHK(hipMalloc(&e->dbitmap[1], (size_t)e->dwords * 4));
+  CREATE_CHK(hipMalloc(&e->dprefix, (size_t)e->dwords * 4));
+  CREATE_CHK(hipMalloc(&e->del_idx, (size_t)t.num_block * 4));
+  CREATE_CHK(hipMalloc(&e->slowdel, (size_t)kSlowDelCap * sizeof(SlowDelete)));
+  // voxel memory starts zeroed (defined value for the reference's uninitialised rgb)
+  CREATE_CHK(hipMemsetAsync(e->pool.rgbw, 0, nvox * 4, e->stream));
+  CREATE_CHK(hipMemsetAsync(e->pool.tsdf, 0, nvox * 4, e->stream));
+  CREATE_CHK(hipMemsetAsync(e->pool.segm, 0, nvox * 4, e->stream));
+  CREATE_CHK(hipMemsetAsync(e->ctl, 0, sizeof(Ctl), e->stream));
+  CREATE_CHK(hipMemsetAsync(e->d_stats, 0, sizeof(ratsdf_frame_stats), e->stream));
+  CREATE_CHK(hipMemsetAsync(e->dbitmap[0], 0, (size_t)e->dwords * 4, e->stream));
+  CREATE_CHK(hipMemsetAsync(e->dbitmap[1], 0, (size_t)e->dwords * 4, e->stream));
+  hipLaunchKernelGGL(k_init_table, dim3((t.num_entry + 255) / 256), dim3(256), 0, e->stream,
+                     t.entries, t.claim, t.num_entry, t.num_bucket);
+  hipLaunchKernelGGL(k_init_heap, dim3((t.num_block + 255) / 256), dim3(256), 0, e->stream,
+                     e->pool.heap, t.num_block);
+  const int32_t nf = t.num_block;
+  CREATE_CHK(hipMemcpyAsync(&e->ctl->num_free, &nf, 4, hipMemcpyHostToDevice, e->stream));
+  CREATE_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_alloc_resolve),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 kSlowSortCap * (int)sizeof(unsigned long long)));
+  CREATE_CHK(hipStreamSynchronize(e->stream));
+  CREATE_CHK(hipGetLastError());
+#undef CREATE_CHK
+  *out = e;
+  return RATSDF_OK;
+}
+
+int ratsdf_create(float voxel_size, float truncation, int device, ratsdf_engine** out) {
+  ratsdf_config c;
+  memset(&c, 0, sizeof(c));
+  c.voxel_size = voxel_size;
+  c.truncation = truncation;
+  c.device = device;
+  return ratsdf_create_ex(&c, out);
+}
+
+int ratsdf_destroy(ratsdf_engine* e) {
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  (void)hipSetDevice(e->device);
+  e->free_all();
+  delete e;
+  return RATSDF_OK;
+}
+
+int ratsdf_integrate_device(ratsdf_engine* e, const void* d_rgb, const void* d_depth,
+                            const void* d_ht, const void* d_lt, int height, int width,
+                            float max_depth, const ratsdf_intrinsics* K, const ratsdf_pose* T) {
+  if (!e || !d_rgb || !d_depth || !K || !T || height <= 0 || width <= 0)
+    return RATSDF_ERR_BAD_ARGUMENT;
+  if (!d_ht || !d_lt) d_ht = d_lt = nullptr;
+  return e->frame(d_rgb, d_depth, d_ht, d_lt, height, width, max_depth, K, T);
+}
+
+int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, const float* ht,
+                     const float* lt, int height, int width, float max_depth,
+                     const ratsdf_intrinsics* K, const ratsdf_pose* T) {
+  if (!e || !rgb || !depth || !K || !T || height <= 0 || width <= 0)
+    return RATSDF_ERR_BAD_ARGUMENT;
+  if (!ht || !lt) ht = lt = nullptr;  // modules/tsdf_module.cc:27-31
+  const size_t npix = (size_t)height * width;
+  int st = e->ensure_stage(npix);
+  if (st != RATSDF_OK) return st;
+  // layout of the staging block: depth | ht | lt | rgb
+  uint8_t* h = e->h_stage;
+  memcpy(h, depth, npix * 4);
+  if (ht) {
+    memcpy(h + npix * 4, ht, npix * 4);
+    memcpy(h + npix * 8, lt, npix * 4);
+  }
+  memcpy(h + npix * 12, rgb, npix * 3);
+  HIPCHK(hipMemcpyAsync(e->d_stage, h, npix * 16, hipMemcpyHostToDevice, e->stream));
+  uint8_t* d = e->d_stage;
+  st = e->frame(d + npix * 12, d, ht ? d + npix * 4 : nullptr, ht ? d + npix * 8 : nullptr, height,
+                width, max_depth, K, T);
+  if (st != RATSDF_OK) return st;
+  return e->sticky();  // cudaStreamSynchronize(stream_), voxel_tsdf.cu:450
+}
+
+int ratsdf_synchronize(ratsdf_engine* e) {
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  return e->sticky();
+}
+
+int ratsdf_stream(ratsdf_engine* e, void** out) {
+  if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
+  *out = (void*)e->stream;
+  return RATSDF_OK;
+}
+
+int ratsdf_profile_enable(ratsdf_engine* e, int enable) {
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  const int st = e->drain_profile();
+  e->profiling = enable != 0;
+  return st;
+}
+
+int ratsdf_profile_read(ratsdf_engine* e, double* ms, int64_t* launches) {
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  const int st = e->drain_profile();
+  if (ms) *ms = e->prof_ms;
+  if (launches) *launches = e->prof_n;
+  e->prof_ms = 0;
+  e->prof_n = 0;
+  return st;
+}
+
+int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out) {
+  if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
+  int32_t nf = 0;
+  HIPCHK(hipMemcpyAsync(&nf, &e->ctl->num_free, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *out = e->tab.num_block - nf;
+  return RATSDF_OK;
+}
+
+int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
+  if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
+  HIPCHK(hipMemcpyAsync(out, e->d_stats, sizeof(*out), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RATSDF_OK;
+}
+
+static int download_selected(ratsdf_engine* e, bool semantic, void** out, size_t* n) {
+  uint32_t cnt = 0;
+  HIPCHK(hipMemcpyAsync(&cnt, &e->ctl->n_sel, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const size_t rec = semantic ? sizeof(ratsdf_voxel_segm) : sizeof(ratsdf_voxel_tsdf);
+  const size_t total = (size_t)cnt * RATSDF_BLOCK_VOLUME;
+  void* host = malloc(total ? total * rec : 1);
+  if (!host) return RATSDF_ERR_DEVICE;
+  if (total) {
+    float* dev = nullptr;
+    if (hipMalloc(&dev, total * rec) != hipSuccess) {
+      free(host);
+      return RATSDF_ERR_DEVICE;
+    }
+    const unsigned grid = cnt < 4096u ? (cnt + 3) / 4 : 1024u;
+    if (semantic)
+      hipLaunchKernelGGL(k_download<true>, dim3(grid), dim3(256), 0, e->stream, e->pool, e->vis,
+                         &e->ctl->n_sel, e->vs, dev);
+    else
+      hipLaunchKernelGGL(k_download<false>, dim3(grid), dim3(256), 0, e->stream, e->pool, e->vis,
+                         &e->ctl->n_sel, e->vs, dev);
+    hipError_t err = hipMemcpyAsync(host, dev, total * rec, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(dev);
+    if (err != hipSuccess) {
+      free(host);
+      return RATSDF_ERR_DEVICE;
+    }
+  }
+  *out = host;
+  *n = total;
+  return RATSDF_OK;
+}
+
+static inline int16_t host_f2s(float f) {  // static_cast<short>, BoundingCube::Scale
+  if (f != f) return 0;
+  if (f >= 2147483648.f) return (int16_t)2147483647;
+  if (f <= -2147483648.f) return (int16_t)(-2147483647 - 1);
+  return (int16_t)(int)f;
+}
+
+int ratsdf_query(ratsdf_engine* e, const ratsdf_bounds* b, ratsdf_voxel_tsdf** out, size_t* n) {
+  if (!e || !b || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
+  const float scale = (float)(1. / e->vs);  // volumn.Scale<short>(1. / voxel_size_), voxel_tsdf.cu:534
+  GridBounds gb{host_f2s(b->xmin * scale), host_f2s(b->xmax * scale), host_f2s(b->ymin * scale),
+                host_f2s(b->ymax * scale), host_f2s(b->zmin * scale), host_f2s(b->zmax * scale)};
+  int st = e->select(kSelBounds, gb, &e->ctl->n_sel);
+  if (st != RATSDF_OK) return st;
+  return download_selected(e, false, (void**)out, n);
+}
+
+int ratsdf_gather_valid(ratsdf_engine* e, ratsdf_voxel_tsdf** out, size_t* n) {
+  if (!e || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
+  int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
+  if (st != RATSDF_OK) return st;
+  return download_selected(e, false, (void**)out, n);
+}
+
+int ratsdf_gather_valid_semantic(ratsdf_engine* e, ratsdf_voxel_segm** out, size_t* n) {
+  if (!e || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
+  int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
+  if (st != RATSDF_OK) return st;
+  return download_selected(e, true, (void**)out, n);
+}
+
+int ratsdf_download_all(ratsdf_engine* e, const char* path) {
+  if (!e || !path) return RATSDF_ERR_BAD_ARGUMENT;
+  ratsdf_voxel_segm* buf = nullptr;
+  size_t n = 0;
+  const int st = ratsdf_gather_valid_semantic(e, &buf, &n);
+  if (st != RATSDF_OK) return st;
+  FILE* f = fopen(path, "wb");
+  if (!f) {
+    free(buf);
+    return RATSDF_ERR_BAD_ARGUMENT;
+  }
+  fwrite(buf, sizeof(ratsdf_voxel_segm), n, f);
+  fclose(f);
+  free(buf);
+  return RATSDF_OK;
+}
+
+int ratsdf_free_buffer(void* p) {
+  free(p);
+  return RATSDF_OK;
+}
+
+int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t capacity,
+                                   void* d_count) {
+  if (!e || !d_blocks || capacity < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
+  if (st != RATSDF_OK) return st;
+  hipLaunchKernelGGL(k_export_entries, dim3(256), dim3(256), 0, e->stream, e->vis, &e->ctl->n_sel,
+                     (Entry*)d_blocks, (int32_t*)nullptr, (uint32_t)capacity, (int32_t*)d_count);
+  HIPCHK(hipGetLastError());
+  return RATSDF_OK;
+}
+
+// ---- test hooks ------------------------------------------------------------------------------
+static int upload_s3(ratsdf_engine* e, const int16_t* src, int32_t n, int16_t** dev) {
+  *dev = nullptr;
+  if (n == 0) return RATSDF_OK;
+  HIPCHK(hipMalloc(dev, (size_t)n * 6));
+  HIPCHK(hipMemcpyAsync(*dev, src, (size_t)n * 6, hipMemcpyHostToDevice, e->stream));
+  return RATSDF_OK;
+}
+
+int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
+  if (!e || (!bp && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  if (n == 0) return e->sticky();
+  int st = e->ensure_image(0, (size_t)n);
+  if (st != RATSDF_OK) return st;
+  int16_t* d = nullptr;
+  st = upload_s3(e, bp, n, &d);
+  if (st != RATSDF_OK) return st;
+  FrameParams P = e->base_params();
+  HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
+  hipLaunchKernelGGL(k_alloc_list, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->tab, P, d, n,
+                     e->req, e->req_cap, e->slow, kSlowCap, e->ctl);
+  st = e->alloc_tail((uint32_t)n);
+  const int st2 = e->sticky();
+  (void)hipFree(d);
+  return st != RATSDF_OK ? st : st2;
+}
+
+int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
+  if (!e || (!bp && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  // keep the first occurrence of every position (a repeated Delete is a no-op in list order)
+  std::vector<int16_t> uniq;
+  uniq.reserve((size_t)n * 3);
+  for (int i = 0; i < n; ++i) {
+    bool dup = false;
+    for (size_t j = 0; j + 2 < uniq.size() && !dup; j += 3)
+      dup = uniq[j] == bp[3 * i] && uniq[j + 1] == bp[3 * i + 1] && uniq[j + 2] == bp[3 * i + 2];
+    if (!dup) uniq.insert(uniq.end(), bp + 3 * i, bp + 3 * i + 3);
+  }
+  const int32_t m = (int32_t)(uniq.size() / 3);
+  if (m == 0) return e->sticky();
+  if (m > e->tab.num_block) return RATSDF_ERR_BAD_ARGUMENT;
+  int16_t* d = nullptr;
+  int st = upload_s3(e, uniq.data(), m, &d);
+  if (st != RATSDF_OK) return st;
+  HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
+  hipLaunchKernelGGL(k_lookup_list, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->tab, d, m,
+                     e->vis, e->carve_flag, e->ctl);
+  st = e->carve_tail();
+  const int st2 = e->sticky();
+  (void)hipFree(d);
+  return st != RATSDF_OK ? st : st2;
+}
+
+int ratsdf_test_retrieve(ratsdf_engine* e, const int16_t* pts, int32_t n, ratsdf_rgbw* rgbw,
+                         float* tsdf, float* prob, ratsdf_block* blocks) {
+  if (!e || (!pts && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  if (n == 0) return RATSDF_OK;
+  int16_t* d = nullptr;
+  int st = upload_s3(e, pts, n, &d);
+  if (st != RATSDF_OK) return st;
+  uint8_t* o = nullptr;
+  HIPCHK(hipMalloc(&o, (size_t)n * 24));
+  uint32_t* o_rgbw = (uint32_t*)o;
+  float* o_tsdf = (float*)(o + (size_t)n * 4);
+  float* o_prob = (float*)(o + (size_t)n * 8);
+  Entry* o_blk = (Entry*)(o + (size_t)n * 12);
+  hipLaunchKernelGGL(k_retrieve, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->tab, e->pool, d,
+                     n, o_rgbw, o_tsdf, o_prob, o_blk);
+  std::vector<uint8_t> h((size_t)n * 24);
+  HIPCHK(hipMemcpyAsync(h.data(), o, h.size(), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (rgbw) memcpy(rgbw, h.data(), (size_t)n * 4);
+  if (tsdf) memcpy(tsdf, h.data() + (size_t)n * 4, (size_t)n * 4);
+  if (prob) memcpy(prob, h.data() + (size_t)n * 8, (size_t)n * 4);
+  if (blocks) memcpy(blocks, h.data() + (size_t)n * 12, (size_t)n * 12);
+  (void)hipFree(o);
+  (void)hipFree(d);
+  return RATSDF_OK;
+}
+
+int ratsdf_test_assign_rgbw(ratsdf_engine* e, const int16_t* pts, const ratsdf_rgbw* vals,
+                            int32_t n) {
+  if (!e || ((!pts || !vals) && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  if (n == 0) return RATSDF_OK;
+  int16_t* d = nullptr;
+  int st = upload_s3(e, pts, n, &d);
+  if (st != RATSDF_OK) return st;
+  uint32_t* v = nullptr;
+  HIPCHK(hipMalloc(&v, (size_t)n * 4));
+  HIPCHK(hipMemcpyAsync(v, vals, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_assign_rgbw, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->tab, e->pool,
+                     d, v, n);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  (void)hipFree(v);
+  (void)hipFree(d);
+  return RATSDF_OK;
+}
+
+int ratsdf_dump_directory(ratsdf_engine* e, int32_t** entry_index, ratsdf_block** blocks,
+                          size_t* n) {
+  if (!e || !entry_index || !blocks || !n) return RATSDF_ERR_BAD_ARGUMENT;
+  int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
+  if (st != RATSDF_OK) return st;
+  uint32_t cnt = 0;
+  HIPCHK(hipMemcpyAsync(&cnt, &e->ctl->n_sel, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int32_t* ei = (int32_t*)malloc(cnt ? (size_t)cnt * 4 : 1);
+  ratsdf_block* bl = (ratsdf_block*)malloc(cnt ? (size_t)cnt * 12 : 1);
+  if (cnt) {
+    Entry* d_b = nullptr;
+    int32_t* d_e = nullptr;
+    HIPCHK(hipMalloc(&d_b, (size_t)cnt * 12));
+    HIPCHK(hipMalloc(&d_e, (size_t)cnt * 4));
+    hipLaunchKernelGGL(k_export_entries, dim3(256), dim3(256), 0, e->stream, e->vis, &e->ctl->n_sel,
+                       d_b, d_e, cnt, (int32_t*)nullptr);
+    HIPCHK(hipMemcpyAsync(bl, d_b, (size_t)cnt * 12, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(ei, d_e, (size_t)cnt * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    (void)hipFree(d_b);
+    (void)hipFree(d_e);
+  }
+  *entry_index = ei;
+  *blocks = bl;
+  *n = cnt;
+  return RATSDF_OK;
+}
+
+int ratsdf_dump_voxels(ratsdf_engine* e, const int32_t* pool_idx, int32_t n, float* tsdf,
+                       ratsdf_rgbw* rgbw, float* prob) {
+  if (!e || (!pool_idx && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  if (n == 0) return RATSDF_OK;
+  for (int i = 0; i < n; ++i)
+    if (pool_idx[i] < 0 || pool_idx[i] >= e->tab.num_block) return RATSDF_ERR_BAD_ARGUMENT;
+  int32_t* d_idx = nullptr;
+  uint8_t* d_out = nullptr;
+  const size_t per = (size_t)n * 512 * 4;
+  HIPCHK(hipMalloc(&d_idx, (size_t)n * 4));
+  HIPCHK(hipMalloc(&d_out, per * 3));
+  HIPCHK(hipMemcpyAsync(d_idx, pool_idx, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_gather_voxels, dim3((n + 3) / 4), dim3(256), 0, e->stream, e->pool, d_idx, n,
+                     (float*)d_out, (uint32_t*)(d_out + per), (float*)(d_out + 2 * per));
+  if (tsdf) HIPCHK(hipMemcpyAsync(tsdf, d_out, per, hipMemcpyDeviceToHost, e->stream));
+  if (rgbw) HIPCHK(hipMemcpyAsync(rgbw, d_out + per, per, hipMemcpyDeviceToHost, e->stream));
+  if (prob) HIPCHK(hipMemcpyAsync(prob, d_out + 2 * per, per, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  (void)hipFree(d_idx);
+  (void)hipFree(d_out);
+  return RATSDF_OK;
+}
+
+int ratsdf_dump_heap(ratsdf_engine* e, int32_t* num_free, int32_t* heap) {
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  if (num_free)
+    HIPCHK(hipMemcpyAsync(num_free, &e->ctl->num_free, 4, hipMemcpyDeviceToHost, e->stream));
+  if (heap)
+    HIPCHK(hipMemcpyAsync(heap, e->pool.heap, (size_t)e->tab.num_block * 4, hipMemcpyDeviceToHost,
+                          e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RATSDF_OK;
+}
+
+const char* ratsdf_status_string(int s) {
+  switch (s) {
+    case RATSDF_OK: return "ok";
+    case RATSDF_ERR_BAD_ARGUMENT: return "bad argument";
+    case RATSDF_ERR_DEVICE: return "device / allocation error";
+    case RATSDF_ERR_POOL_EXHAUSTED: return "voxel block pool exhausted";
+    case RATSDF_ERR_CAPACITY: return "internal work list overflow";
+    case RATSDF_ERR_NO_DEVICE: return "no HIP device";
+    case RATSDF_ERR_NOT_IMPLEMENTED: return "not implemented";
+    default: return "unknown status";
+  }
+}
+const char* ratsdf_backend(void) { return "hip-gfx950"; }
+
+}  // extern "C"

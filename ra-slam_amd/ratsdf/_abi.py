@@ -66,6 +66,7 @@ assert VOXEL_SEGM_DTYPE.itemsize == 20 and RGBW_DTYPE.itemsize == 4
 # every symbol include/ratsdf.h declares (without prefix)
 SYMBOLS = [
     "create", "create_ex", "destroy", "integrate", "integrate_device", "synchronize", "stream",
+    "profile_enable", "profile_read",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "export_directory_device", "test_allocate", "test_delete",
     "test_retrieve", "test_assign_rgbw", "dump_directory", "dump_voxels", "dump_heap",
@@ -100,6 +101,8 @@ class Library:
         self.fn["integrate_device"].argtypes = self.fn["integrate"].argtypes
         self.fn["synchronize"].argtypes = [vp]
         self.fn["stream"].argtypes = [vp, C.POINTER(vp)]
+        self.fn["profile_enable"].argtypes = [vp, C.c_int]
+        self.fn["profile_read"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         self.fn["num_active_blocks"].argtypes = [vp, C.POINTER(C.c_int32)]
         self.fn["last_frame_stats"].argtypes = [vp, C.POINTER(FrameStats)]
         self.fn["query"].argtypes = [vp, C.POINTER(Bounds), C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -223,6 +226,15 @@ class Engine:
         s = C.c_void_p()
         _check(self.lib.fn["stream"](self._h, C.byref(s)), "stream")
         return s.value or 0
+
+    def profile_enable(self, on=True):
+        _check(self.lib.fn["profile_enable"](self._h, 1 if on else 0), "profile_enable")
+
+    def profile_read(self):
+        """(summed k_integrate milliseconds, launches) since the last read."""
+        ms, n = C.c_double(), C.c_int64()
+        _check(self.lib.fn["profile_read"](self._h, C.byref(ms), C.byref(n)), "profile_read")
+        return ms.value, n.value
 
     def num_active_blocks(self):
         n = C.c_int32()

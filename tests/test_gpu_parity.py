@@ -1,0 +1,73 @@
+"""HIP engine vs CPU oracle on identical seeded frames, through the C ABI (needs a GPU)."""
+import numpy as np
+import pytest
+
+from parity import assert_maps_equal, assert_stats_equal
+from ratsdf import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(gpu, cpu, frames, md=4.0, check_every=1):
+    worst = dict(tsdf=0.0, prob=0.0)
+    for i, f in enumerate(frames):
+        for e in (gpu, cpu):
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+        assert_stats_equal(gpu, cpu)
+        if (i + 1) % check_every == 0 or i == len(frames) - 1:
+            w = assert_maps_equal(gpu, cpu)
+            worst = {k: max(worst[k], w[k]) for k in worst}
+    return worst
+
+
+@pytest.mark.parametrize("scene", ["wall", "room", "sphere"])
+def test_small_sequences(scene, make_engine, make_oracle):
+    vs = 0.02
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    frames = synthetic.stream(scene, 6, scale=0.25)
+    worst = run_both(gpu, cpu, frames)
+    print(scene, worst)
+
+
+def test_no_semantics_and_holes(make_engine, make_oracle):
+    vs = 0.02
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    frames = synthetic.stream("room", 4, scale=0.25, semantic=False, holes=True, noise=True)
+    run_both(gpu, cpu, frames)
+    p = gpu.gather_valid_semantic()["prob"]
+    assert np.all(p == np.float32(0.5))  # ht = lt = 1 keeps the probability at exactly .5
+
+
+def test_tum_camera_1cm(make_engine, make_oracle):
+    vs = 0.01
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=8)
+    frames = synthetic.stream("sphere", 3, cam="tum", scale=0.5)
+    run_both(gpu, cpu, frames)
+
+
+def test_full_resolution_5mm_frame(make_engine, make_oracle):
+    """BASELINE configs[1]-sized frame: 640x480, 5 mm voxels, 2 frames of the room scene."""
+    vs = 0.005
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+    frames = synthetic.stream("room", 2, scale=1.0)
+    run_both(gpu, cpu, frames)
+
+
+def test_query_and_gather_match(make_engine, make_oracle):
+    vs = 0.02
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    for f in synthetic.stream("room", 3, scale=0.25):
+        for e in (gpu, cpu):
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+    for bounds in [(-1, 1, -1, 1, 0, 2), (-5, 5, -5, 5, -5, 5), (0.1, 0.2, 0.1, 0.2, 0.1, 0.2)]:
+        qa, qb = gpu.query(bounds), cpu.query(bounds)
+        assert len(qa) == len(qb)
+        for k in ("x", "y", "z"):
+            assert np.array_equal(qa[k], qb[k])
+        assert np.max(np.abs(qa["tsdf"] - qb["tsdf"]), initial=0) <= 1e-4
+    ga, gb = gpu.gather_valid(), cpu.gather_valid()
+    assert len(ga) == len(gb) and np.array_equal(ga["x"], gb["x"])
+    sa, sb = gpu.gather_valid_semantic(), cpu.gather_valid_semantic()
+    assert len(sa) == len(sb)
+    assert np.max(np.abs(sa["prob"] - sb["prob"]), initial=0) <= 1e-4
+    assert np.max(np.abs(sa["tsdf"] - sb["tsdf"]), initial=0) <= 1e-4
