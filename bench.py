@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- depth+semantic frames/s integrated by the MI355X TSDF engine (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one batch of `--frames-per-step` synthetic 640x480 frames (depth + rgb + ht/lt, 5 mm voxels,
+truncation 30 mm, max depth 4 m, ScanNet intrinsics; the "room" stream of ratsdf.synthetic)
+integrated through the C ABI (ratsdf_integrate_device) with every input already resident in HBM.
+For N > 1 the driver launches one process per GPU with torch.distributed.run; each rank integrates
+its own stream into its own map (frame-batched config of BASELINE.json) and the ranks all-gather
+their block directories over RCCL once per step.  Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline      HBM roofline of the dominant kernel (k_integrate): algorithmic bytes per launch
+                (15 W H + 12 V + 24 U) / its average duration measured with HIP events
+                on the engine's stream inside the timed region
+  cpu_baseline  the CPU oracle (multithreaded port; the reference has no CPU path) timed on this
+                box's host cores on a bounded prefix of the same stream (rank 0, N = 1 only), after
+                asserting that it and the HIP engine produce the same map on that prefix
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "ra-slam_amd"))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-step", type=int, default=90)
+    ap.add_argument("--cam", default="scannet")
+    ap.add_argument("--scene", default="room")
+    ap.add_argument("--voxel", type=float, default=0.005)
+    ap.add_argument("--max-depth", type=float, default=4.0)
+    ap.add_argument("--cpu-frames", type=int, default=40,
+                    help="frames of the stream timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of k_integrate")
+    return ap.parse_args()
+
+
+def make_stream(scene, cam, nframes, phase):
+    """Ping-pong camera sweep so the stream can repeat forever: frames 0..n-1 then n-1..0."""
+    from ratsdf import synthetic
+    half = [synthetic.frame(scene, phase + i, cam=cam, noise=True, holes=True) for i in
+            range(nframes)]
+    return half + half[::-1]
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N "
+                             "--master-addr 127.0.0.1 bench.py --gpus N ...")
+        a.gpus = world
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the TSDF engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ratsdf
+    vs = a.voxel
+    B = a.frames_per_step
+    half = (B + 1) // 2
+    frames = make_stream(a.scene, a.cam, half, phase=45 * rank)
+    frames = frames[:B] if len(frames) >= B else frames
+    H, W = frames[0]["depth"].shape
+    # resident inputs
+    d_rgb = [torch.from_numpy(f["rgb"]).to(dev) for f in frames]
+    d_depth = [torch.from_numpy(f["depth"]).to(dev) for f in frames]
+    d_ht = [torch.from_numpy(f["ht"]).to(dev) for f in frames]
+    d_lt = [torch.from_numpy(f["lt"]).to(dev) for f in frames]
+    intr = [ratsdf.Intrinsics(*f["intrinsics"]) for f in frames]
+    pose = [ratsdf.Pose(*f["pose"]) for f in frames]
+    torch.cuda.synchronize()
+
+    eng = ratsdf.TSDFGrid(vs, 6 * vs, device=local_rank)
+    ext = torch.cuda.ExternalStream(eng.stream(), device=dev)
+
+    # ---- parity + CPU baseline on a bounded prefix (rank 0, N = 1) ---------------------------
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and world == 1 and a.cpu_frames > 0:
+        from oracle_binding import load_oracle
+        from parity import assert_maps_equal
+        from ratsdf._abi import Engine
+        ncpu = min(a.cpu_frames, len(frames))
+        cores = os.cpu_count() or 1
+        cpu = Engine(load_oracle(), vs, 6 * vs, threads=cores)
+        chk = ratsdf.TSDFGrid(vs, 6 * vs, device=local_rank)
+        t0 = time.perf_counter()
+        for f in frames[:ncpu]:
+            cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"],
+                          f["pose"])
+        t_cpu = time.perf_counter() - t0
+        for i in range(ncpu):
+            chk.integrate_device(d_rgb[i].data_ptr(), d_depth[i].data_ptr(), d_ht[i].data_ptr(),
+                                 d_lt[i].data_ptr(), H, W, a.max_depth, intr[i], pose[i])
+        chk.synchronize()
+        worst = assert_maps_equal(chk, cpu)
+        parity = dict(frames=ncpu, max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"],
+                      directory="bit-exact")
+        cpu_baseline = dict(value=ncpu / t_cpu, unit="frames/s", cores=cores, kind="port",
+                            sample=f"first {ncpu} frames of the same stream from an empty map "
+                                   f"(oracle/ratsdf_oracle.cpp, {cores} threads)")
+        chk.close()
+        cpu.close()
+
+    # ---- directory all-gather (N > 1): one fixed-capacity exchange per step -------------------
+    cap = 1 << 16
+    if world > 1:
+        dir_local = torch.zeros(cap * 3, dtype=torch.int32, device=dev)   # 12-byte entries
+        dir_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        dir_all = torch.zeros(world * cap * 3, dtype=torch.int32, device=dev)
+        cnt_all = torch.zeros(world, dtype=torch.int32, device=dev)
+
+    def exchange():
+        eng.export_directory_device(dir_local.data_ptr(), cap, dir_count.data_ptr())
+        ev = torch.cuda.Event()
+        ev.record(ext)
+        torch.cuda.current_stream().wait_event(ev)
+        dist.all_gather_into_tensor(dir_all, dir_local)
+        dist.all_gather_into_tensor(cnt_all, dir_count)
+        ev2 = torch.cuda.Event()
+        ev2.record(torch.cuda.current_stream())
+        ext.wait_event(ev2)
+
+    def step():
+        for i in range(len(frames)):
+            eng.integrate_device(d_rgb[i].data_ptr(), d_depth[i].data_ptr(), d_ht[i].data_ptr(),
+                                 d_lt[i].data_ptr(), H, W, a.max_depth, intr[i], pose[i])
+        if world > 1:
+            exchange()
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    eng.totals(reset=True)
+    if not a.no_profile:
+        eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    k_ms, k_n = (0.0, 0)
+    if not a.no_profile:
+        k_ms, k_n = eng.profile_read()
+        eng.profile_enable(False)
+    tot = eng.totals()
+    stats = eng.last_frame_stats()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    nframes = a.steps * len(frames)
+    if rank == 0:
+        fps = world * nframes / dt
+        V = tot["visible_blocks"] / max(tot["frames"], 1)
+        U = tot["updated_voxels"] / max(tot["frames"], 1)
+        b_alg = 15.0 * W * H + 12.0 * V + 24.0 * U
+        roof = None
+        if k_n:
+            k_avg_s = k_ms / k_n / 1e3
+            achieved = b_alg / k_avg_s / 1e9
+            traffic = None
+            tpath = ROOT / "profiles" / "traffic_latest.json"
+            if tpath.exists():
+                try:
+                    traffic = json.loads(tpath.read_text()).get("k_integrate_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = dict(bound="hbm", kernel="k_integrate", achieved=round(achieved, 1),
+                        peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                        traffic=traffic, alg_bytes_per_launch=round(b_alg),
+                        avg_launch_us=round(k_avg_s * 1e6, 2), launches=k_n)
+        out = {
+            "metric": "depth+semantic frames/sec integrated @640x480, 5mm voxels",
+            "value": round(fps, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic '{a.scene}' RGB-D+ht/lt stream, {a.cam} intrinsics {W}x{H}, "
+                            f"voxel {vs * 1e3:g} mm, truncation {6 * vs * 1e3:g} mm, max depth "
+                            f"{a.max_depth:g} m, 1 deg/frame ping-pong sweep, 1 mm depth noise, 1% holes",
+                "frames_per_step": len(frames),
+                "streams": world,
+                "directory_allgather_every_frames": len(frames) if world > 1 else None,
+            },
+            "frame": {"avg_visible_blocks": round(V, 1), "avg_updated_voxels": round(U, 1),
+                      "alg_bytes": round(b_alg), "alg_gbps_whole_frame": round(b_alg * fps / world / 1e9, 1),
+                      "active_blocks": stats["active_blocks"]},
+            "roofline": roof,
+            "cpu_baseline": cpu_baseline,
+            "parity": parity,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,6 +158,10 @@ int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out);
 /* Counters of the most recently completed frame (synchronises). */
 int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out);
 
+/* Running sums since creation / the last reset: {frames, sum V, sum U, sum allocated blocks, sum
+ * deleted blocks}; used to turn a timed run into algorithmic bytes (15 W H + 12 V + 24 U per frame). */
+int ratsdf_totals(ratsdf_engine* e, int64_t* out5, int reset);
+
 /* ---- query side ---------------------------------------------------------------------------- */
 /* TSDFGrid::GatherVoxels(BoundingCube<float>) == TSDFSystem::Query, voxel_tsdf.cu:532-559,
  * modules/tsdf_module.cc:39-43.  Output: every voxel of every allocated block that lies wholly

@@ -153,6 +153,7 @@ struct ratsdf_engine {
   std::vector<float> range;
   std::vector<VisBlock> visible;
   ratsdf_frame_stats stats{};
+  int64_t totals[5] = {0, 0, 0, 0, 0};
   int sticky = RATSDF_OK;
 
   // ---- geometry helpers (voxel_mem.cuh:31-70, voxel_hash.cu:19-23) -------------------------
@@ -239,7 +240,7 @@ struct ratsdf_engine {
     while (table[last].offset) last = (last + table[last].offset) & entry_mask;
     const uint32_t bucket_last = last >> 1;
     uint32_t next = last;
-    while (true) {
+    for (uint32_t guard = 0; guard < num_entry; ++guard) {  // reference: while (true)
       next = (next + 1) & entry_mask;
       if ((next & 1u) != 1u && table[next].idx < 0) {
         const uint32_t bucket_next = next >> 1;
@@ -258,6 +259,7 @@ struct ratsdf_engine {
         return false;
       }
     }
+    return false;  // no free slot anywhere (the reference would spin forever)
   }
 
   // ---- VoxelHashTable::Delete, voxel_hash.cu:110-159 -----------------------------------------
@@ -515,6 +517,11 @@ struct ratsdf_engine {
     reset_locks();
     stats.deleted_blocks = deleted;
     stats.active_blocks = (int)num_block - num_free;
+    totals[0] += 1;
+    totals[1] += stats.visible_blocks;
+    totals[2] += stats.updated_voxels;
+    totals[3] += stats.allocated_blocks;
+    totals[4] += stats.deleted_blocks;
     return sticky;
   }
 
@@ -658,6 +665,15 @@ int ratsdf_oracle_num_active_blocks(ratsdf_engine* e, int32_t* out) {
 int ratsdf_oracle_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   *out = e->stats;
+  return RATSDF_OK;
+}
+
+int ratsdf_oracle_totals(ratsdf_engine* e, int64_t* out5, int reset) {
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < 5; ++i) {
+    if (out5) out5[i] = e->totals[i];
+    if (reset) e->totals[i] = 0;
+  }
   return RATSDF_OK;
 }
 

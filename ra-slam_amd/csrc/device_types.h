@@ -68,7 +68,8 @@ struct Ctl {
   // --- persistent ---
   int32_t num_free;       // VoxelMemPool::num_free_blocks_
   uint32_t error;         // sticky ratsdf_status
-  uint32_t pad1[14];
+  unsigned long long totals[5];  // frames, sum V, sum U, sum allocated, sum deleted
+  uint32_t pad1[4];
 };
 constexpr int kCtlFrameBytes = 64;
 

@@ -364,17 +364,32 @@ __global__ __launch_bounds__(256) void k_alloc_mark(Table tab, Request* req, uin
   }
 }
 
-// One workgroup: exclusive popcount prefix over `nwords` bitmap words; total -> *total_out.
-// Also zeroes the other (next pass's) bitmap.
+// One workgroup: exclusive popcount prefix over `nwords` bitmap words; returns the total.
+// kAtomic = true reads the words with agent-scope atomic loads (needed when the bits were set by
+// atomics earlier in the SAME kernel: a plain load could hit a stale line in this CU's L1);
+// kAtomic = false uses plain loads (bits set by a previous kernel).
+template <bool kAtomic>
 __device__ inline uint32_t bitmap_prefix_scan(const uint32_t* bitmap, uint32_t* prefix,
-                                              uint32_t nwords, uint32_t* lds /* 1024 words */) {
+                                              uint32_t nwords, uint32_t* lds /* blockDim words */) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  const uint32_t chunk = (nwords + nt - 1) / nt;
-  const uint32_t lo = tid * chunk;
+  // contiguous chunk per thread, rounded to 4 words so plain loads can be 16-byte vectors
+  uint32_t chunk = (nwords + nt - 1) / nt;
+  chunk = (chunk + 3u) & ~3u;
+  const uint32_t lo = tid * chunk < nwords ? tid * chunk : nwords;
   const uint32_t hi = lo + chunk < nwords ? lo + chunk : nwords;
+  auto ld = [&](uint32_t w) -> uint32_t {
+    return kAtomic ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                   : bitmap[w];
+  };
   uint32_t sum = 0;
-  for (uint32_t w = lo; w < hi; ++w)
-    sum += __popc(__hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  uint32_t w = lo;
+  if (!kAtomic) {
+    for (; w + 4 <= hi; w += 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(bitmap + w);
+      sum += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+  }
+  for (; w < hi; ++w) sum += __popc(ld(w));
   lds[tid] = sum;
   __syncthreads();
   for (uint32_t d = 1; d < nt; d <<= 1) {  // Hillis-Steele inclusive scan over the thread sums
@@ -383,19 +398,31 @@ __device__ inline uint32_t bitmap_prefix_scan(const uint32_t* bitmap, uint32_t* 
     lds[tid] += v;
     __syncthreads();
   }
-  uint32_t run = lds[tid] - sum;
-  for (uint32_t w = lo; w < hi; ++w) {
-    prefix[w] = run;
-    run += __popc(__hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const uint32_t total = lds[nt - 1];
+  if (sum == 0) {
+    // nothing set in this chunk: every word's prefix is the running value
+    const uint32_t run = lds[tid];
+    w = lo;
+    if (!kAtomic) {
+      const uint4 r4 = make_uint4(run, run, run, run);
+      for (; w + 4 <= hi; w += 4) *reinterpret_cast<uint4*>(prefix + w) = r4;
+    }
+    for (; w < hi; ++w) prefix[w] = run;
+  } else {
+    uint32_t run = lds[tid] - sum;
+    for (w = lo; w < hi; ++w) {
+      prefix[w] = run;
+      run += __popc(ld(w));
+    }
   }
-  return lds[nt - 1];
+  return total;
 }
 
 __global__ __launch_bounds__(1024) void k_alloc_scan(const uint32_t* bitmap, uint32_t* prefix,
                                                      uint32_t nwords, uint32_t* next_bitmap,
                                                      uint32_t next_words, Ctl* ctl) {
   __shared__ uint32_t lds[1024];
-  const uint32_t total = bitmap_prefix_scan(bitmap, prefix, nwords, lds);
+  const uint32_t total = bitmap_prefix_scan<false>(bitmap, prefix, nwords, lds);
   for (uint32_t w = threadIdx.x; w < next_words; w += blockDim.x) next_bitmap[w] = 0;
   if (threadIdx.x == 0) {
     const int32_t nf = ctl->num_free;

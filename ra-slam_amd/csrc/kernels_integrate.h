@@ -227,7 +227,7 @@ __global__ __launch_bounds__(1024) void k_carve_scan(Table tab, SlowDelete* slow
   __syncthreads();
   const uint32_t nv = ctl->n_vis;
   const uint32_t nwords = (nv + 31) >> 5;
-  const uint32_t total = bitmap_prefix_scan(bitmap, prefix, nwords, lds);
+  const uint32_t total = bitmap_prefix_scan<true>(bitmap, prefix, nwords, lds);
   for (uint32_t w = threadIdx.x; w < next_words; w += blockDim.x) next_bitmap[w] = 0;
   if (threadIdx.x == 0) {
     const int32_t nf = ctl->num_free;
@@ -241,6 +241,11 @@ __global__ __launch_bounds__(1024) void k_carve_scan(Table tab, SlowDelete* slow
       stats->deleted_blocks = (int32_t)total;
       stats->active_blocks = tab.num_block - (nf + (int32_t)total);
       stats->slow_requests = (int32_t)ctl->n_slow;
+      ctl->totals[0] += 1;
+      ctl->totals[1] += nv;
+      ctl->totals[2] += ctl->n_updated;
+      ctl->totals[3] += ctl->n_win;
+      ctl->totals[4] += total;
     }
   }
 }

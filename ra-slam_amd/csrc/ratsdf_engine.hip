@@ -58,7 +58,7 @@ struct ratsdf_engine {
   ratsdf_frame_stats* d_stats = nullptr;
 
   // image-sized scratch
-  size_t pix_cap = 0, rank_cap = 0;
+  size_t pix_cap = 0, rank_cap = 0, cur_nranks = 0;
   float4* texA = nullptr;
   uint2* texB = nullptr;
   Request* req = nullptr;
@@ -102,7 +102,7 @@ struct ratsdf_engine {
   int ensure_image(size_t npix, size_t nranks);
   int ensure_stage(size_t npix);
   int alloc_tail(uint32_t nranks);
-  int carve_tail();
+  int carve_tail(bool is_frame);
   int select(int mode, const GridBounds& gb, uint32_t* count_slot);
   int frame(const void* d_rgb, const void* d_depth, const void* d_ht, const void* d_lt, int H, int W,
             float md, const ratsdf_intrinsics* K, const ratsdf_pose* T);
@@ -148,7 +148,7 @@ int ratsdf_engine::free_all() {
 }
 
 int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
-  if (npix <= pix_cap && nranks <= rank_cap) return RATSDF_OK;
+  if (npix <= pix_cap && nranks == cur_nranks) return RATSDF_OK;
   HIPCHK(hipStreamSynchronize(stream));
   if (npix > pix_cap) {
     if (texA) (void)hipFree(texA);
@@ -170,9 +170,13 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
     HIPCHK(hipMalloc(&aprefix, (size_t)awords_cap * 4));
     rank_cap = nranks;
   }
-  // both rank bitmaps must be clean whenever the rank space changes
-  HIPCHK(hipMemsetAsync(abitmap[0], 0, (size_t)awords_cap * 4, stream));
-  HIPCHK(hipMemsetAsync(abitmap[1], 0, (size_t)awords_cap * 4, stream));
+  // Each pass's scan kernel cleans the other bitmap only over the current rank space, so both must
+  // be cleaned whenever the rank space (image size / list length) changes.
+  if (nranks != cur_nranks) {
+    HIPCHK(hipMemsetAsync(abitmap[0], 0, (size_t)awords_cap * 4, stream));
+    HIPCHK(hipMemsetAsync(abitmap[1], 0, (size_t)awords_cap * 4, stream));
+    cur_nranks = nranks;
+  }
   return RATSDF_OK;
 }
 
@@ -207,13 +211,14 @@ int ratsdf_engine::alloc_tail(uint32_t nranks) {
   return RATSDF_OK;
 }
 
-int ratsdf_engine::carve_tail() {
+int ratsdf_engine::carve_tail(bool is_frame) {
   uint32_t* bm = dbitmap[dpass & 1];
   uint32_t* bm_next = dbitmap[(dpass + 1) & 1];
   hipLaunchKernelGGL(k_carve_mark, dim3(128), dim3(256), 0, stream, tab, vis, carve_flag, bm,
                      del_idx, slowdel, kSlowDelCap, ctl);
   hipLaunchKernelGGL(k_carve_scan, dim3(1), dim3(1024), 0, stream, tab, slowdel, kSlowDelCap, bm,
-                     dprefix, del_idx, bm_next, dwords, ctl, d_stats);
+                     dprefix, del_idx, bm_next, dwords, ctl,
+                     is_frame ? d_stats : (ratsdf_frame_stats*)nullptr);
   hipLaunchKernelGGL(k_carve_commit, dim3(128), dim3(256), 0, stream, pool, bm, dprefix, del_idx,
                      ctl);
   ++dpass;
@@ -286,7 +291,7 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
                      carve_flag, ctl);
   if (profiling) HIPCHK(hipEventRecord(ev1, stream));
 
-  st = carve_tail();
+  st = carve_tail(true);
   if (st != RATSDF_OK) return st;
   if (profiling && prof_used >= 4096) return drain_profile();
   return RATSDF_OK;
@@ -499,6 +504,17 @@ int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
   return RATSDF_OK;
 }
 
+int ratsdf_totals(ratsdf_engine* e, int64_t* out5, int reset) {
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  unsigned long long t[5] = {0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(t, e->ctl->totals, sizeof(t), hipMemcpyDeviceToHost, e->stream));
+  if (reset) HIPCHK(hipMemsetAsync(e->ctl->totals, 0, sizeof(t), e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (out5)
+    for (int i = 0; i < 5; ++i) out5[i] = (int64_t)t[i];
+  return RATSDF_OK;
+}
+
 static int download_selected(ratsdf_engine* e, bool semantic, void** out, size_t* n) {
   uint32_t cnt = 0;
   HIPCHK(hipMemcpyAsync(&cnt, &e->ctl->n_sel, 4, hipMemcpyDeviceToHost, e->stream));
@@ -644,7 +660,7 @@ int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
   hipLaunchKernelGGL(k_lookup_list, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->tab, d, m,
                      e->vis, e->carve_flag, e->ctl);
-  st = e->carve_tail();
+  st = e->carve_tail(false);
   const int st2 = e->sticky();
   (void)hipFree(d);
   return st != RATSDF_OK ? st : st2;

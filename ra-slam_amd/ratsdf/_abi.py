@@ -66,7 +66,7 @@ assert VOXEL_SEGM_DTYPE.itemsize == 20 and RGBW_DTYPE.itemsize == 4
 # every symbol include/ratsdf.h declares (without prefix)
 SYMBOLS = [
     "create", "create_ex", "destroy", "integrate", "integrate_device", "synchronize", "stream",
-    "profile_enable", "profile_read",
+    "profile_enable", "profile_read", "totals",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "export_directory_device", "test_allocate", "test_delete",
     "test_retrieve", "test_assign_rgbw", "dump_directory", "dump_voxels", "dump_heap",
@@ -103,6 +103,7 @@ class Library:
         self.fn["stream"].argtypes = [vp, C.POINTER(vp)]
         self.fn["profile_enable"].argtypes = [vp, C.c_int]
         self.fn["profile_read"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        self.fn["totals"].argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
         self.fn["num_active_blocks"].argtypes = [vp, C.POINTER(C.c_int32)]
         self.fn["last_frame_stats"].argtypes = [vp, C.POINTER(FrameStats)]
         self.fn["query"].argtypes = [vp, C.POINTER(Bounds), C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -235,6 +236,13 @@ class Engine:
         ms, n = C.c_double(), C.c_int64()
         _check(self.lib.fn["profile_read"](self._h, C.byref(ms), C.byref(n)), "profile_read")
         return ms.value, n.value
+
+    def totals(self, reset=False):
+        """dict(frames, visible_blocks, updated_voxels, allocated_blocks, deleted_blocks) sums."""
+        t = (C.c_int64 * 5)()
+        _check(self.lib.fn["totals"](self._h, t, 1 if reset else 0), "totals")
+        return dict(zip(("frames", "visible_blocks", "updated_voxels", "allocated_blocks",
+                         "deleted_blocks"), [int(v) for v in t]))
 
     def num_active_blocks(self):
         n = C.c_int32()
