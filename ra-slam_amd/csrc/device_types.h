@@ -64,7 +64,8 @@ struct Ctl {
   uint32_t alloc_base;    // num_free at the start of the allocation pass
   uint32_t free_base;     // num_free at the start of the carve pass
   uint32_t n_sel;         // selected blocks of a query / export
-  uint32_t pad0[6];
+  uint32_t rank_chunk;    // words per thread-chunk of the allocation rank bitmap scan
+  uint32_t pad0[5];
   // --- persistent ---
   int32_t num_free;       // VoxelMemPool::num_free_blocks_
   uint32_t error;         // sticky ratsdf_status
@@ -103,6 +104,7 @@ struct FrameParams {
 struct Table {
   Entry* entries;
   uint32_t* claim;
+  unsigned long long* occ;  // occupancy bitmap of the directory: bit e set <=> entries[e].idx >= 0
   uint32_t num_bucket, num_entry, bucket_mask, entry_mask;
   int32_t num_block;
 };

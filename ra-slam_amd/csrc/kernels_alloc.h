@@ -8,15 +8,16 @@
 // outcome is made a pure function of the input: every candidate carries its raster rank
 // (pixel * S + sample) and the pass computes exactly what a sequential, rank-ordered execution of
 // the reference code would:
-//   k_alloc_pixels  per pixel: candidates, directory lookup, atomicMin(claim[bucket], rank) for
-//                   ordinary buckets ("first requester in raster order wins the bucket lock"),
-//                   append to a small slow list for chained / full buckets
-//   k_alloc_resolve one workgroup: replays the slow list in rank order against the claim table
-//                   (time-dependent lock / fill queries), so chain appends lock, link and defeat
-//                   later claims exactly as the sequential code would
-//   k_alloc_mark    winners (claim == own rank) set their bit in a rank-indexed bitmap
-//   k_alloc_scan    one workgroup: popcount prefix of the bitmap = order of AquireBlock calls
-//   k_alloc_commit  one wave per winner: pool index heap[free-1-k], directory entry, block init
+//   alloc_pixels_role  per pixel: candidates, directory lookup, atomicMin(claim[bucket], rank) for
+//                      ordinary buckets ("first requester in raster order wins the bucket lock"),
+//                      append to a small slow list for chained / full buckets (part of k_front)
+//   k_alloc_rank       one workgroup: (a) replays the slow list in rank order against the claim
+//                      table (time-dependent lock / fill queries), so chain appends lock, link and
+//                      defeat later claims exactly as the sequential code would; (b) winners
+//                      (claim == own rank) set their bit in a rank-indexed bitmap; (c) popcount
+//                      prefix of the bitmap = order of the AquireBlock calls
+//   k_alloc_commit     one wave per winner: pool index heap[free-1-k], directory entry, occupancy /
+//                      visibility bits, block init
 #pragma once
 #include "device_math.h"
 
@@ -48,9 +49,9 @@ __device__ inline uint32_t key1(int z) { return (uint32_t)z & 0xFFFFu; }
 __device__ inline uint32_t find_block(const Table& t, int x, int y, int z, EntryWords* out) {
   const uint32_t k0 = key0(x, y), k1 = key1(z);
   const uint32_t e0 = block_hash(x, y, z, t.bucket_mask) << 1;
-  EntryWords w = load_entry(t.entries, e0);
-  if (entry_matches(w, k0, k1)) { *out = w; return e0; }
-  w = load_entry(t.entries, e0 + 1);
+  const EntryWords a = load_entry(t.entries, e0);      // both home entries are fetched together
+  EntryWords w = load_entry(t.entries, e0 + 1);         // (24 contiguous bytes)
+  if (entry_matches(a, k0, k1)) { *out = a; return e0; }
   if (entry_matches(w, k0, k1)) { *out = w; return e0 + 1; }
   uint32_t last = e0 + 1;
   int off = entry_offset(w);
@@ -110,21 +111,20 @@ __device__ inline void alloc_request(const Table& t, int x, int y, int z, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_alloc_pixels: block_allocate_kernel, voxel_tsdf.cu:120-168.  One lane per pixel, 64 consecutive
+// alloc_pixels_role: block_allocate_kernel, voxel_tsdf.cu:120-168.  One lane per pixel, 64 consecutive
 // pixels of a row per wave (coalesced depth / ht / lt reads).  Also writes the packed per-pixel
 // texels the integration kernel gathers from: texA = {depth, range, log ht, log lt},
 // texB = {rgb, w_new}.  log(ht), log(lt) and w_new = (1 - d/max_depth)*4 are functions of the pixel
 // only (voxel_tsdf.cu:226,243,246), so evaluating them once per pixel instead of once per voxel is
 // value-identical.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_alloc_pixels(Table tab, FrameParams P, const float* depth,
-                                                      const uint8_t* rgb, const float* ht,
-                                                      const float* lt, float4* texA, uint2* texB,
-                                                      Request* req, uint32_t req_cap,
-                                                      SlowRequest* slow, uint32_t slow_cap,
-                                                      Ctl* ctl) {
+__device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P, uint32_t wg,
+                                         const float* depth, const uint8_t* rgb, const float* ht,
+                                         const float* lt, float4* texA, uint2* texB, Request* req,
+                                         uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap,
+                                         Ctl* ctl) {
   const int npix = P.W * P.H;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int pix = (int)wg * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool inb = pix < npix;
   const int px = inb ? pix % P.W : 0;
@@ -207,10 +207,10 @@ __global__ void k_alloc_list(Table tab, FrameParams P, const int16_t* pos, int n
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_alloc_resolve: exact rank-ordered replay of VoxelHashTable::Allocate (voxel_hash.cu:46-108) for
-// requests whose home bucket is full or heads a chain.  Single workgroup; returns at once when the
-// slow list is empty (the common case).  Everything an ordinary bucket does during the pass is
-// summarised by its claim (min rank): bucket x is locked from time claim[x] on, and its leader
+// Exact rank-ordered replay of VoxelHashTable::Allocate (voxel_hash.cu:46-108) for requests whose
+// home bucket is full or heads a chain.  Runs in ONE workgroup; thread 0 does the serial part after
+// an LDS bitonic sort of the slow list by rank.  Everything an ordinary bucket does during the pass
+// is summarised by its claim (min rank): bucket x is locked from time claim[x] on, and its leader
 // fills the first empty home entry at that time unless an earlier slow request locked x first.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSlowSortCap = 16384;   // slow requests per pass (LDS bitonic sort, 128 KiB)
@@ -221,13 +221,11 @@ struct XLock {
   uint32_t bucket, time;
 };
 
-__global__ __launch_bounds__(1024) void k_alloc_resolve(Table tab, Request* req, uint32_t req_cap,
-                                                        const SlowRequest* slow, uint32_t slow_cap,
-                                                        XLock* xlocks, SlowRequest* distinct,
-                                                        Ctl* ctl) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+__device__ inline void resolve_slow_requests(const Table& tab, Request* req, uint32_t req_cap,
+                                             const SlowRequest* slow, uint32_t slow_cap,
+                                             XLock* xlocks, SlowRequest* distinct, Ctl* ctl,
+                                             unsigned long long* skeys) {
   uint32_t n = ctl->n_slow;
-  if (n == 0) return;
   if (n > slow_cap) n = slow_cap;
   if (n > (uint32_t)kSlowSortCap) {
     if (threadIdx.x == 0) set_error(ctl, RATSDF_ERR_CAPACITY);
@@ -347,13 +345,77 @@ __global__ __launch_bounds__(1024) void k_alloc_resolve(Table tab, Request* req,
   }
 }
 
+// Exclusive scan of one value per thread across the workgroup (Hillis-Steele in LDS).
+// Returns the exclusive prefix; *total receives the workgroup sum.  lds: blockDim.x words.
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  __syncthreads();  // lds may still be in use by a previous scan
+  lds[tid] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < nt; d <<= 1) {
+    const uint32_t t = tid >= d ? lds[tid - d] : 0;
+    __syncthreads();
+    lds[tid] += t;
+    __syncthreads();
+  }
+  *total = lds[nt - 1];
+  return lds[tid] - v;
+}
+
+// Words per thread-chunk of a bitmap scanned by `nt` threads (multiple of 4 for 16-byte loads).
+__host__ __device__ inline uint32_t bitmap_chunk(uint32_t nwords, uint32_t nt) {
+  uint32_t c = (nwords + nt - 1) / nt;
+  c = (c + 3u) & ~3u;
+  return c ? c : 4u;
+}
+
+// Popcount of this thread's chunk of a bitmap.  The bits were set with atomics earlier in the same
+// kernel by this workgroup; the words have not been read before in this kernel (and the vector L1
+// is invalidated at kernel start), so plain loads after the barrier fetch them from L2.
+__device__ inline uint32_t chunk_popcount(const uint32_t* bitmap, uint32_t nwords, uint32_t chunk) {
+  const uint32_t lo = threadIdx.x * chunk;
+  uint32_t sum = 0;
+  for (uint32_t w = lo; w < lo + chunk && w < nwords; w += 4) {
+    if (w + 4 <= nwords) {
+      const uint4 v = *reinterpret_cast<const uint4*>(bitmap + w);
+      sum += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    } else {
+      for (uint32_t k = w; k < nwords; ++k) sum += __popc(bitmap[k]);
+    }
+  }
+  return sum;
+}
+
+// rank of bit `pos` among the set bits of the bitmap, given the per-chunk exclusive prefix
+__device__ inline uint32_t bitmap_rank(const uint32_t* bitmap, const uint32_t* chunk_prefix,
+                                       uint32_t chunk, uint32_t pos) {
+  const uint32_t w = pos >> 5;
+  const uint32_t c = w / chunk;
+  uint32_t k = chunk_prefix[c];
+  for (uint32_t i = c * chunk; i < w; ++i) k += __popc(bitmap[i]);
+  return k + __popc(bitmap[w] & ((1u << (pos & 31)) - 1u));
+}
+
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_alloc_mark(Table tab, Request* req, uint32_t req_cap,
-                                                    uint32_t* bitmap, Ctl* ctl) {
+// k_alloc_rank: one workgroup.  resolve -> mark winners -> rank scan -> free-list bookkeeping.
+// Also cleans the other (next pass's) rank bitmap.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, uint32_t req_cap,
+                                                     const SlowRequest* slow, uint32_t slow_cap,
+                                                     XLock* xlocks, SlowRequest* distinct,
+                                                     uint32_t* bitmap, uint32_t* chunk_prefix,
+                                                     uint32_t nwords, uint32_t* next_bitmap,
+                                                     uint32_t next_words, Ctl* ctl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  uint32_t* lds = reinterpret_cast<uint32_t*>(skeys);
+  if (ctl->n_slow != 0) {  // uniform
+    resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, distinct, ctl, skeys);
+    __syncthreads();
+  }
   uint32_t n = ctl->n_req;
   if (n > req_cap) n = req_cap;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    Request r = req[i];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const Request r = req[i];
     bool win = (r.flags & kReqWinner) != 0;
     if (!(r.flags & kReqPlaced)) {
       const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
@@ -362,67 +424,12 @@ __global__ __launch_bounds__(256) void k_alloc_mark(Table tab, Request* req, uin
     }
     if (win) atomicOr(&bitmap[r.rank >> 5], 1u << (r.rank & 31));
   }
-}
-
-// One workgroup: exclusive popcount prefix over `nwords` bitmap words; returns the total.
-// kAtomic = true reads the words with agent-scope atomic loads (needed when the bits were set by
-// atomics earlier in the SAME kernel: a plain load could hit a stale line in this CU's L1);
-// kAtomic = false uses plain loads (bits set by a previous kernel).
-template <bool kAtomic>
-__device__ inline uint32_t bitmap_prefix_scan(const uint32_t* bitmap, uint32_t* prefix,
-                                              uint32_t nwords, uint32_t* lds /* blockDim words */) {
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  // contiguous chunk per thread, rounded to 4 words so plain loads can be 16-byte vectors
-  uint32_t chunk = (nwords + nt - 1) / nt;
-  chunk = (chunk + 3u) & ~3u;
-  const uint32_t lo = tid * chunk < nwords ? tid * chunk : nwords;
-  const uint32_t hi = lo + chunk < nwords ? lo + chunk : nwords;
-  auto ld = [&](uint32_t w) -> uint32_t {
-    return kAtomic ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                   : bitmap[w];
-  };
-  uint32_t sum = 0;
-  uint32_t w = lo;
-  if (!kAtomic) {
-    for (; w + 4 <= hi; w += 4) {
-      const uint4 v = *reinterpret_cast<const uint4*>(bitmap + w);
-      sum += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-    }
-  }
-  for (; w < hi; ++w) sum += __popc(ld(w));
-  lds[tid] = sum;
   __syncthreads();
-  for (uint32_t d = 1; d < nt; d <<= 1) {  // Hillis-Steele inclusive scan over the thread sums
-    const uint32_t v = tid >= d ? lds[tid - d] : 0;
-    __syncthreads();
-    lds[tid] += v;
-    __syncthreads();
-  }
-  const uint32_t total = lds[nt - 1];
-  if (sum == 0) {
-    // nothing set in this chunk: every word's prefix is the running value
-    const uint32_t run = lds[tid];
-    w = lo;
-    if (!kAtomic) {
-      const uint4 r4 = make_uint4(run, run, run, run);
-      for (; w + 4 <= hi; w += 4) *reinterpret_cast<uint4*>(prefix + w) = r4;
-    }
-    for (; w < hi; ++w) prefix[w] = run;
-  } else {
-    uint32_t run = lds[tid] - sum;
-    for (w = lo; w < hi; ++w) {
-      prefix[w] = run;
-      run += __popc(ld(w));
-    }
-  }
-  return total;
-}
-
-__global__ __launch_bounds__(1024) void k_alloc_scan(const uint32_t* bitmap, uint32_t* prefix,
-                                                     uint32_t nwords, uint32_t* next_bitmap,
-                                                     uint32_t next_words, Ctl* ctl) {
-  __shared__ uint32_t lds[1024];
-  const uint32_t total = bitmap_prefix_scan<false>(bitmap, prefix, nwords, lds);
+  const uint32_t chunk = bitmap_chunk(nwords, blockDim.x);
+  const uint32_t sum = chunk_popcount(bitmap, nwords, chunk);
+  uint32_t total = 0;
+  const uint32_t excl = block_exclusive_scan(sum, lds, &total);
+  chunk_prefix[threadIdx.x] = excl;
   for (uint32_t w = threadIdx.x; w < next_words; w += blockDim.x) next_bitmap[w] = 0;
   if (threadIdx.x == 0) {
     const int32_t nf = ctl->num_free;
@@ -433,6 +440,7 @@ __global__ __launch_bounds__(1024) void k_alloc_scan(const uint32_t* bitmap, uin
     }
     ctl->alloc_base = (uint32_t)nf;
     ctl->n_win = take;
+    ctl->rank_chunk = chunk;
     ctl->num_free = nf - (int32_t)take;
   }
 }
@@ -440,16 +448,21 @@ __global__ __launch_bounds__(1024) void k_alloc_scan(const uint32_t* bitmap, uin
 // One wave per request.  Winner k (in rank order) takes heap[alloc_base - 1 - k]
 // (AquireBlock, voxel_mem.cu:37-41), gets its directory entry written (voxel_hash.cu:72-74,101-103)
 // and its 512 voxels initialised to weight 1 / tsdf -1 / probability .5 with rgb left untouched
-// (voxel_mem.cu:43-51).  Every request also releases its bucket's claim (ResetLocks).
+// (voxel_mem.cu:43-51).  A new block is visible by construction (allocation needs all 8 corners in
+// view, voxel_tsdf.cu:165), so it is also entered into this frame's visibility mask.
+// Every request releases its bucket's claim (ResetLocks).
 __global__ __launch_bounds__(256) void k_alloc_commit(Table tab, Pool pool, const Request* req,
                                                       uint32_t req_cap, const uint32_t* bitmap,
-                                                      const uint32_t* prefix, Ctl* ctl) {
+                                                      const uint32_t* chunk_prefix,
+                                                      unsigned long long* vismask,
+                                                      uint32_t* vis_wg_count, Ctl* ctl) {
   uint32_t n = ctl->n_req;
   if (n > req_cap) n = req_cap;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t base = ctl->alloc_base;
+  const uint32_t chunk = ctl->rank_chunk;
   for (uint32_t i = wave; i < n; i += nwaves) {
     const Request r = req[i];
     const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
@@ -458,8 +471,15 @@ __global__ __launch_bounds__(256) void k_alloc_commit(Table tab, Pool pool, cons
       if (lane == 0 && !placed) tab.claim[bucket] = kInf;
       continue;
     }
-    const uint32_t word = bitmap[r.rank >> 5];
-    const uint32_t k = prefix[r.rank >> 5] + __popc(word & ((1u << (r.rank & 31)) - 1u));
+    // rank among winners: chunk prefix + popcounts of the earlier words of the chunk (lanes in
+    // parallel) + bits below in the own word
+    const uint32_t w = r.rank >> 5;
+    const uint32_t c = w / chunk;
+    uint32_t part = 0;
+    for (uint32_t j = c * chunk + lane; j < w; j += 64) part += __popc(bitmap[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const uint32_t k = chunk_prefix[c] + part + __popc(bitmap[w] & ((1u << (r.rank & 31)) - 1u));
     uint32_t e = r.entry;
     if (!placed) {
       const uint32_t e0 = bucket << 1;
@@ -481,6 +501,11 @@ __global__ __launch_bounds__(256) void k_alloc_commit(Table tab, Pool pool, cons
         tab.claim[bucket] = kInf;
       }
       pe[2] = (uint32_t)idx;
+      atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
+      if (vismask) {
+        atomicOr(&vismask[e >> 6], 1ull << (e & 63));
+        atomicAdd(&vis_wg_count[e >> 14], 1u);  // 256 words of 64 entries per visibility workgroup
+      }
     }
     const size_t v = ((size_t)idx << 9) + lane * 8;
     float4* pt = reinterpret_cast<float4*>(pool.tsdf + v);

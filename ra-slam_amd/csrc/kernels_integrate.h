@@ -1,18 +1,21 @@
 // kernels_integrate.h -- per-frame voxel update and space carving for gfx950.
 //
 // k_integrate replaces tsdf_integrate_kernel AND the read half of space_carving_kernel
-// (utils/tsdf/voxel_tsdf.cu:170-276): one 64-lane wave owns one 8x8x8 voxel block, lane l owns the
-// x-row (y = l & 7, z = l >> 3), i.e. 8 consecutive voxels = 32 contiguous bytes in each of the
-// three SoA pools, moved as 16-byte vector loads/stores (the wave reads 2 KiB contiguous per pool).
-// The block's min |tsdf| (space carving) is reduced across the wave with cross-lane shuffles from
-// the values still in registers, so the reference's second pass over the block is gone.
+// (utils/tsdf/voxel_tsdf.cu:170-276).  An 8x8x8 voxel block is 512 consecutive voxels in each of the
+// three SoA pools; a lane owns VPL consecutive voxels of an x-row (VPL = 2, 4 or 8), so a wave
+// reads/writes one contiguous 64*VPL*4-byte span per pool with 8- or 16-byte vector accesses.
+// The kernel is latency bound (gathers of per-pixel data through L2 / Infinity Cache), so the order
+// inside a lane is: issue the pool loads, project all VPL voxels, issue ALL texel gathers, then do
+// the arithmetic -- every lane has 3 + 2*VPL independent memory operations in flight.  The block's
+// min |tsdf| (space carving) is reduced from registers with cross-lane shuffles (+ LDS across the
+// waves of a block), so the reference's second pass over the block is gone.
 //
 // The carve pass (VoxelHashTable::Delete, voxel_hash.cu:110-159 + ReleaseBlock, voxel_mem.cu:56-61)
 // is made deterministic the same way as allocation: deletions happen in visible-list (= ascending
 // hash entry) order; deletes of a block sitting in slot 0 of its home bucket are lock-free and
 // independent; head / chain deletes are serialised per home bucket by the bucket lock, i.e. the
 // first one in list order wins (atomicMin claim), and the released pool indices are pushed on the
-// free list in list order via a popcount prefix over a bitmap.
+// free list in list order via a popcount prefix over a bitmap.  One workgroup does the whole pass.
 #pragma once
 #include "kernels_visible.h"
 
@@ -29,108 +32,215 @@ __device__ inline uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+template <int N>
+struct VecIO;
+template <>
+struct VecIO<8> {
+  static __device__ inline void load(const uint32_t* p, uint32_t (&v)[8]) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ inline void store(uint32_t* p, const uint32_t (&v)[8]) {
+    reinterpret_cast<uint4*>(p)[0] = make_uint4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<uint4*>(p)[1] = make_uint4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <>
+struct VecIO<4> {
+  static __device__ inline void load(const uint32_t* p, uint32_t (&v)[4]) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  }
+  static __device__ inline void store(uint32_t* p, const uint32_t (&v)[4]) {
+    reinterpret_cast<uint4*>(p)[0] = make_uint4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <>
+struct VecIO<2> {
+  static __device__ inline void load(const uint32_t* p, uint32_t (&v)[2]) {
+    const uint2 a = reinterpret_cast<const uint2*>(p)[0];
+    v[0] = a.x; v[1] = a.y;
+  }
+  static __device__ inline void store(uint32_t* p, const uint32_t (&v)[2]) {
+    reinterpret_cast<uint2*>(p)[0] = make_uint2(v[0], v[1]);
+  }
+};
+
+template <int VPL>
 __global__ __launch_bounds__(256) void k_integrate(Pool pool, FrameParams P, const VisItem* vis,
                                                    const float4* texA, const uint2* texB,
-                                                   uint8_t* carve_flag, Ctl* ctl) {
+                                                   uint32_t* blk_info, Ctl* ctl) {
+  constexpr int WPB = 8 / VPL;  // waves per voxel block
+  constexpr int BPW = 4 / WPB;  // voxel blocks per 256-thread workgroup
+  __shared__ float smin[4];
+  __shared__ uint32_t supd[4];
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t blk_in_wg = wv / WPB, part = wv % WPB;
   const uint32_t nv = ctl->n_vis;
-  const int ty = lane & 7, tz = lane >> 3;
-  uint32_t updated_total = 0;
-  for (uint32_t b = wave; b < nv; b += nwaves) {
-    const VisItem it = vis[b];
-    const size_t v = ((size_t)it.idx << 9) + lane * 8;
-    float4* pt = reinterpret_cast<float4*>(pool.tsdf + v);
-    float4* ps = reinterpret_cast<float4*>(pool.segm + v);
-    uint4* pc = reinterpret_cast<uint4*>(pool.rgbw + v);
-    float4 t0 = pt[0], t1 = pt[1];
-    float4 s0 = ps[0], s1 = ps[1];
-    uint4 c0 = pc[0], c1 = pc[1];
-    float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-    float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    uint32_t cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const uint32_t vi0 = (part * 64 + lane) * VPL;  // first voxel of this lane, x + 8y + 64z
+  const int tx0 = vi0 & 7, ty = (vi0 >> 3) & 7, tz = vi0 >> 6;
+  for (uint32_t it = blockIdx.x; it * BPW < nv; it += gridDim.x) {
+    const uint32_t b = it * BPW + blk_in_wg;
+    const bool active = b < nv;
+    float m = 3.0e38f;
+    uint32_t nupd_blk = 0;
+    if (active) {
+      const VisItem item = vis[b];
+      const size_t v = ((size_t)item.idx << 9) + vi0;
+      uint32_t tv[VPL], sv[VPL], cv[VPL];
+      VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.tsdf + v), tv);
+      VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.segm + v), sv);
+      VecIO<VPL>::load(pool.rgbw + v, cv);
 
-    const int gy = (int16_t)((int16_t)(it.y << 3) + ty);
-    const int gz = (int16_t)((int16_t)(it.z << 3) + tz);
-    const float wy = (float)gy * P.vs, wz = (float)gz * P.vs;
-    uint32_t nupd = 0;
+      const int gy = (int16_t)((int16_t)(item.y << 3) + ty);
+      const int gz = (int16_t)((int16_t)(item.z << 3) + tz);
+      const float wy = (float)gy * P.vs, wz = (float)gz * P.vs;
+      float phz[VPL];
+      int kk[VPL];
+      bool inb[VPL];
 #pragma unroll
-    for (int tx = 0; tx < 8; ++tx) {
-      const int gx = (int16_t)((int16_t)(it.x << 3) + tx);               // :183-184
-      const V3 pw{(float)gx * P.vs, wy, wz};                              // :187
-      const V3 pc3 = se3_apply(P.T, pw);                                  // :190
-      const V3 ph = intr_mul(P.K, pc3);                                   // :193
-      const int u = f2i(roundf(ph.x / ph.z));                             // :196-199
-      const int w = f2i(roundf(ph.y / ph.z));                             // :202
-      if (u >= 0 && u < P.W && w >= 0 && w < P.H) {                       // :205
-        const int k = w * P.W + u;
-        const float4 a = texA[k];  // depth, range, log ht, log lt
-        const float d = a.x;
-        if (!(d == 0 || d > P.md)) {                                      // :211
-          const float sdf = a.y * (d - ph.z);                             // :216
-          if (sdf > -P.trunc) {                                           // :217
-            const uint2 bq = texB[k];  // rgb, w_new
-            const float ts = fminf(1, sdf / P.trunc);                     // :218
-            const float wn = __uint_as_float(bq.y);                       // :226
-            const uint32_t c = cv[tx];
-            const float wo = (float)(c >> 24);                            // :227
-            const float wc = wo + wn;                                     // :228
-            const float r_old = (float)(c & 0xFFu), g_old = (float)((c >> 8) & 0xFFu),
-                        b_old = (float)((c >> 16) & 0xFFu);
-            const float r_new = (float)(bq.x & 0xFFu), g_new = (float)((bq.x >> 8) & 0xFFu),
-                        b_new = (float)((bq.x >> 16) & 0xFFu);
-            const float rc = (r_old * wo + r_new * wn) / wc;              // :234-235
-            const float gc = (g_old * wo + g_new * wn) / wc;
-            const float bc = (b_old * wo + b_new * wn) / wc;
-            tv[tx] = (tv[tx] * wo + ts * wn) / wc;                        // :236
-            const uint32_t wq = (uint32_t)f2i(fminf(roundf(wc), 40)) & 0xFFu;   // :238
-            cv[tx] = ((uint32_t)f2i(roundf(rc)) & 0xFFu) | (((uint32_t)f2i(roundf(gc)) & 0xFFu) << 8) |
-                     (((uint32_t)f2i(roundf(bc)) & 0xFFu) << 16) | (wq << 24);  // :239-240
-            const float pr = sv[tx];
-            const float pos = expf((wo * logf(pr) + wn * a.z) / wc);      // :242-244
-            const float neg = expf((wo * logf(1 - pr) + wn * a.w) / wc);  // :245-247
-            sv[tx] = pos / (pos + neg);                                   // :248
-            ++nupd;
-          }
+      for (int j = 0; j < VPL; ++j) {
+        const int gx = (int16_t)((int16_t)(item.x << 3) + tx0 + j);         // :183-184
+        const V3 pw{(float)gx * P.vs, wy, wz};                              // :187
+        const V3 pc3 = se3_apply(P.T, pw);                                  // :190
+        const V3 ph = intr_mul(P.K, pc3);                                   // :193
+        const int u = f2i(roundf(ph.x / ph.z));                             // :196-199
+        const int w = f2i(roundf(ph.y / ph.z));                             // :202
+        inb[j] = u >= 0 && u < P.W && w >= 0 && w < P.H;                    // :205
+        kk[j] = inb[j] ? w * P.W + u : 0;
+        phz[j] = ph.z;
+      }
+      float4 ta[VPL];
+      uint2 tb[VPL];
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {  // all gathers in flight together
+        ta[j] = texA[kk[j]];           // depth, range, log ht, log lt
+        tb[j] = texB[kk[j]];           // rgb, w_new
+      }
+      uint32_t nupd = 0;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const float d = ta[j].x;
+        const float sdf = ta[j].y * (d - phz[j]);                           // :216
+        if (inb[j] && !(d == 0 || d > P.md) && sdf > -P.trunc) {            // :211,217
+          const float ts = fminf(1, sdf / P.trunc);                         // :218
+          const float wn = __uint_as_float(tb[j].y);                        // :226
+          const uint32_t c = cv[j];
+          const float wo = (float)(c >> 24);                                // :227
+          const float wc = wo + wn;                                         // :228
+          const float r_old = (float)(c & 0xFFu), g_old = (float)((c >> 8) & 0xFFu),
+                      b_old = (float)((c >> 16) & 0xFFu);
+          const uint32_t cn = tb[j].x;
+          const float r_new = (float)(cn & 0xFFu), g_new = (float)((cn >> 8) & 0xFFu),
+                      b_new = (float)((cn >> 16) & 0xFFu);
+          const float rc = (r_old * wo + r_new * wn) / wc;                  // :234-235
+          const float gc = (g_old * wo + g_new * wn) / wc;
+          const float bc = (b_old * wo + b_new * wn) / wc;
+          const float t_old = __uint_as_float(tv[j]);
+          tv[j] = __float_as_uint((t_old * wo + ts * wn) / wc);             // :236
+          const uint32_t wq = (uint32_t)f2i(fminf(roundf(wc), 40)) & 0xFFu; // :238
+          cv[j] = ((uint32_t)f2i(roundf(rc)) & 0xFFu) | (((uint32_t)f2i(roundf(gc)) & 0xFFu) << 8) |
+                  (((uint32_t)f2i(roundf(bc)) & 0xFFu) << 16) | (wq << 24); // :239-240
+          const float pr = __uint_as_float(sv[j]);
+          const float pos = expf((wo * logf(pr) + wn * ta[j].z) / wc);      // :242-244
+          const float neg = expf((wo * logf(1 - pr) + wn * ta[j].w) / wc);  // :245-247
+          sv[j] = __float_as_uint(pos / (pos + neg));                       // :248
+          ++nupd;
         }
       }
-    }
-    if (nupd) {
-      pt[0] = make_float4(tv[0], tv[1], tv[2], tv[3]);
-      pt[1] = make_float4(tv[4], tv[5], tv[6], tv[7]);
-      ps[0] = make_float4(sv[0], sv[1], sv[2], sv[3]);
-      ps[1] = make_float4(sv[4], sv[5], sv[6], sv[7]);
-      pc[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-      pc[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
-    }
-    // space_carving_kernel, :253-276: min |tsdf| over the block after the update
-    float m = fabsf(tv[0]);
+      if (nupd) {
+        VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.tsdf + v), tv);
+        VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), sv);
+        VecIO<VPL>::store(pool.rgbw + v, cv);
+      }
+      // space_carving_kernel, :253-276: min |tsdf| over the block after the update
+      m = fabsf(__uint_as_float(tv[0]));
 #pragma unroll
-    for (int i = 1; i < 8; ++i) m = fminf(m, fabsf(tv[i]));
+      for (int j = 1; j < VPL; ++j) m = fminf(m, fabsf(__uint_as_float(tv[j])));
+      nupd_blk = nupd;
+    }
+    // per-block result word: bit 31 = carve candidate, low bits = voxels updated.  (A single
+    // device-wide atomic counter here costs more than the whole update: ~90 atomics/us per address.)
     m = wave_min(m);
-    if (lane == 0) carve_flag[b] = (m >= .9f) ? 1 : 0;
-    updated_total += nupd;
+    nupd_blk = wave_sum(nupd_blk);
+    if (WPB == 1) {
+      if (active && lane == 0) blk_info[b] = nupd_blk | ((m >= .9f) ? 0x80000000u : 0u);
+    } else {
+      __syncthreads();  // smin / supd free again
+      if (lane == 0) {
+        smin[wv] = m;
+        supd[wv] = nupd_blk;
+      }
+      __syncthreads();
+      if (active && part == 0 && lane == 0) {
+        float mm = smin[wv];
+        uint32_t uu = supd[wv];
+#pragma unroll
+        for (int i = 1; i < WPB; ++i) {
+          mm = fminf(mm, smin[wv + i]);
+          uu += supd[wv + i];
+        }
+        blk_info[b] = uu | ((mm >= .9f) ? 0x80000000u : 0u);
+      }
+    }
   }
-  updated_total = wave_sum(updated_total);
-  if (lane == 0 && updated_total) atomicAdd(&ctl->n_updated, updated_total);
 }
 
-// ---- carve pass ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_carve_mark(Table tab, const VisItem* vis,
-                                                    const uint8_t* carve_flag, uint32_t* bitmap,
-                                                    int32_t* del_idx, SlowDelete* slow,
-                                                    uint32_t slow_cap, Ctl* ctl) {
+// explicit delete list (test hook): builds a pseudo visible list in list order
+__global__ void k_lookup_list(Table tab, const int16_t* pos, int n, VisItem* vis,
+                              uint32_t* blk_info, Ctl* ctl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) ctl->n_vis = (uint32_t)n;
+  if (i >= n) return;
+  EntryWords w;
+  const int x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+  const uint32_t e = find_block(tab, x, y, z, &w);
+  vis[i] = VisItem{(int16_t)x, (int16_t)y, (int16_t)z, (int16_t)(w.w1 >> 16), w.idx,
+                   e == kInf ? 0u : e};
+  blk_info[i] = e != kInf ? 0x80000000u : 0u;
+}
+
+__device__ inline void occ_clear(const Table& tab, uint32_t e) {
+  atomicAnd(&tab.occ[e >> 6], ~(1ull << (e & 63)));
+}
+__device__ inline uint32_t ld_agent(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_carve: the whole carve pass in ONE workgroup.
+//   (1) every flagged block: slot-0-of-home deletes happen directly (no lock, voxel_hash.cu:114-123),
+//       the others claim their home bucket with atomicMin(list index) and go to a small list
+//   (2) head / chain deletes: one winner per home bucket = the first in list order
+//       (voxel_hash.cu:125-158); claims are released (ResetLocks)
+//   (3) popcount prefix over the delete bitmap = order of the ReleaseBlock calls; heap pushes
+//   (4) free-list bookkeeping, frame statistics, and the control block is zeroed for the next frame
+// Data produced with atomics inside this kernel (bitmap words, claims, n_slow_del) is read either
+// with agent-scope atomic loads or from lines this kernel has not touched before (L1 is cold).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisItem* vis,
+                                                const uint32_t* blk_info, uint32_t* bitmap,
+                                                uint32_t* next_bitmap, uint32_t next_words,
+                                                int32_t* del_idx, SlowDelete* slow,
+                                                uint32_t slow_cap, Ctl* ctl,
+                                                ratsdf_frame_stats* stats) {
+  __shared__ uint32_t lds[1024];
+  __shared__ uint32_t cprefix[1024];
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t nv = ctl->n_vis;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
-    if (!carve_flag[i]) continue;
+  uint32_t upd_part = 0;
+  for (uint32_t i = tid; i < nv; i += nt) {
+    const uint32_t info = blk_info[i];
+    upd_part += info & 0x7FFFFFFFu;
+    if (!(info >> 31)) continue;
     const VisItem it = vis[i];
     const uint32_t bucket = block_hash(it.x, it.y, it.z, tab.bucket_mask);
     if (it.entry == (bucket << 1)) {
-      // slot 0 of the home bucket: no lock involved (voxel_hash.cu:114-123)
       uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + it.entry);
       pe[1] = pe[1] & 0xFFFFu;  // offset = 0
       pe[2] = (uint32_t)-1;
+      occ_clear(tab, it.entry);
       del_idx[i] = it.idx;
       atomicOr(&bitmap[i >> 5], 1u << (i & 31));
     } else {
@@ -143,50 +253,27 @@ __global__ __launch_bounds__(256) void k_carve_mark(Table tab, const VisItem* vi
       }
     }
   }
-}
-
-// explicit delete list (test hook): builds a pseudo visible list in list order
-__global__ void k_lookup_list(Table tab, const int16_t* pos, int n, VisItem* vis,
-                              uint8_t* carve_flag, Ctl* ctl) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) ctl->n_vis = (uint32_t)n;
-  if (i >= n) return;
-  EntryWords w;
-  const int x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
-  const uint32_t e = find_block(tab, x, y, z, &w);
-  vis[i] = VisItem{(int16_t)x, (int16_t)y, (int16_t)z, (int16_t)(w.w1 >> 16), w.idx,
-                   e == kInf ? 0u : e};
-  carve_flag[i] = e != kInf;
-}
-
-// One workgroup: (a) head / chain deletes, one winner per home bucket (the first in list order),
-// (b) popcount prefix of the delete bitmap, free-list bookkeeping and the frame's statistics.
-__global__ __launch_bounds__(1024) void k_carve_scan(Table tab, SlowDelete* slow,
-                                                     uint32_t slow_cap, uint32_t* bitmap,
-                                                     uint32_t* prefix, int32_t* del_idx,
-                                                     uint32_t* next_bitmap, uint32_t next_words,
-                                                     Ctl* ctl, ratsdf_frame_stats* stats) {
-  __shared__ uint32_t lds[1024];
-  uint32_t ns = ctl->n_slow_del;
-  if (ns > slow_cap) ns = slow_cap;
-  // pass 1: decide every winner before any claim is released (items of one bucket may sit in
-  // different strides of the loop); the flag is parked in the item itself (same thread re-reads it)
-  for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x) {
-    const SlowDelete s = slow[j];
-    const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
-    slow[j].pad = (tab.claim[bucket] == s.vis) ? 1 : 0;
-  }
   __syncthreads();
-  for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x) {
-    const SlowDelete s = slow[j];
-    const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
-    const bool win = s.pad != 0;
-    tab.claim[bucket] = kInf;  // ResetLocks
-    if (win) {
+  uint32_t ns = ld_agent(&ctl->n_slow_del);
+  if (ns > slow_cap) ns = slow_cap;
+  if (ns) {  // uniform
+    // decide every winner before any claim is released (the flag is parked in the item itself and
+    // re-read by the same thread)
+    for (uint32_t j = tid; j < ns; j += nt) {
+      const SlowDelete s = slow[j];
+      const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
+      slow[j].pad = (ld_agent(&tab.claim[bucket]) == s.vis) ? 1 : 0;
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < ns; j += nt) {
+      const SlowDelete s = slow[j];
+      const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
+      tab.claim[bucket] = kInf;  // ResetLocks
+      if (!s.pad) continue;
       const uint32_t k0 = key0(s.x, s.y), k1 = key1(s.z);
       uint32_t last = (bucket << 1) + 1;
       uint32_t* ph = reinterpret_cast<uint32_t*>(tab.entries + last);
-      EntryWords h = load_entry(tab.entries, last);
+      const EntryWords h = load_entry(tab.entries, last);
       if (entry_matches(h, k0, k1)) {                                     // voxel_hash.cu:125-140
         const uint32_t nxt = (last + (uint32_t)entry_offset(h)) & tab.entry_mask;
         uint32_t* pn = reinterpret_cast<uint32_t*>(tab.entries + nxt);
@@ -199,6 +286,7 @@ __global__ __launch_bounds__(1024) void k_carve_scan(Table tab, SlowDelete* slow
         ph[2] = (uint32_t)nw.idx;
         pn[1] = pn[1] & 0xFFFFu;
         pn[2] = (uint32_t)-1;
+        occ_clear(tab, nxt);  // the head keeps its bit unless it was its own successor
         atomicOr(&bitmap[s.vis >> 5], 1u << (s.vis & 31));
       } else {                                                            // voxel_hash.cu:142-158
         for (uint32_t g = 0; g < tab.num_entry; ++g) {
@@ -216,6 +304,7 @@ __global__ __launch_bounds__(1024) void k_carve_scan(Table tab, SlowDelete* slow
             del_idx[s.vis] = cw.idx;
             pcur[1] = pcur[1] & 0xFFFFu;
             pcur[2] = (uint32_t)-1;
+            occ_clear(tab, cur);
             atomicOr(&bitmap[s.vis >> 5], 1u << (s.vis & 31));
             break;
           }
@@ -223,44 +312,44 @@ __global__ __launch_bounds__(1024) void k_carve_scan(Table tab, SlowDelete* slow
         }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
-  const uint32_t nv = ctl->n_vis;
+  uint32_t upd = 0;
+  (void)block_exclusive_scan(upd_part, lds, &upd);
   const uint32_t nwords = (nv + 31) >> 5;
-  const uint32_t total = bitmap_prefix_scan<true>(bitmap, prefix, nwords, lds);
-  for (uint32_t w = threadIdx.x; w < next_words; w += blockDim.x) next_bitmap[w] = 0;
-  if (threadIdx.x == 0) {
-    const int32_t nf = ctl->num_free;
-    ctl->free_base = (uint32_t)nf;
-    ctl->n_del = total;
+  const uint32_t chunk = bitmap_chunk(nwords, nt);
+  const uint32_t sum = chunk_popcount(bitmap, nwords, chunk);
+  uint32_t total = 0;
+  cprefix[tid] = block_exclusive_scan(sum, lds, &total);
+  __syncthreads();
+  const int32_t nf = ctl->num_free;
+  if (total) {  // uniform
+    for (uint32_t i = tid; i < nv; i += nt) {
+      if (!((bitmap[i >> 5] >> (i & 31)) & 1u)) continue;
+      const uint32_t k = bitmap_rank(bitmap, cprefix, chunk, i);
+      pool.heap[(uint32_t)nf + k] = del_idx[i];                           // voxel_mem.cu:56-60
+    }
+  }
+  for (uint32_t w = tid; w < next_words; w += nt) next_bitmap[w] = 0;
+  __syncthreads();
+  if (tid == 0) {
     ctl->num_free = nf + (int32_t)total;
     if (stats) {
       stats->visible_blocks = (int32_t)nv;
-      stats->updated_voxels = (int32_t)ctl->n_updated;
+      stats->updated_voxels = (int32_t)upd;
       stats->allocated_blocks = (int32_t)ctl->n_win;
       stats->deleted_blocks = (int32_t)total;
       stats->active_blocks = tab.num_block - (nf + (int32_t)total);
       stats->slow_requests = (int32_t)ctl->n_slow;
       ctl->totals[0] += 1;
       ctl->totals[1] += nv;
-      ctl->totals[2] += ctl->n_updated;
+      ctl->totals[2] += upd;
       ctl->totals[3] += ctl->n_win;
       ctl->totals[4] += total;
     }
-  }
-}
-
-// ReleaseBlock in list order: heap[free_base + k] = idx, voxel_mem.cu:56-61
-__global__ __launch_bounds__(256) void k_carve_commit(Pool pool, const uint32_t* bitmap,
-                                                      const uint32_t* prefix, const int32_t* del_idx,
-                                                      Ctl* ctl) {
-  const uint32_t nv = ctl->n_vis;
-  const uint32_t base = ctl->free_base;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
-    const uint32_t word = bitmap[i >> 5];
-    if (!((word >> (i & 31)) & 1u)) continue;
-    const uint32_t k = prefix[i >> 5] + __popc(word & ((1u << (i & 31)) - 1u));
-    pool.heap[base + k] = del_idx[i];
+    // control block ready for the next pass (saves a memset node per frame)
+    uint32_t* z = reinterpret_cast<uint32_t*>(ctl);
+    for (int i = 0; i < kCtlFrameBytes / 4; ++i) z[i] = 0;
   }
 }
 

@@ -3,10 +3,13 @@
 // Replaces check_visibility_kernel / check_valid_kernel / check_bound_kernel + prefix_sum +
 // gather_visible_blocks_kernel + the blocking read-back of the count
 // (utils/tsdf/voxel_tsdf.cu:15-33,98-118,465-474,847-867; utils/cuda/arithmetic.cuh:52-172).
-// The output list is ordered by ascending hash-entry index exactly like the reference's
-// scan + gather, but is built from per-wave ballots: flags kernel (ballot mask per wave + count per
-// workgroup), one-workgroup scan of the 2^22/1024 workgroup counts, scatter kernel.  The count
-// stays on the device (Ctl::n_vis / n_sel); consumers are persistent grids that read it there.
+// The reference scans all 2^22 directory entries (48 MiB) three times per frame.  Here the engine
+// keeps a 512 KiB occupancy bitmap of the directory (one bit per entry, maintained by the commit and
+// carve kernels); a frame reads the bitmap and only the entries whose bit is set.  The output list
+// is ordered by ascending hash-entry index exactly like the reference's scan + gather: one lane per
+// 64-entry word produces a selection mask, and the scatter kernel turns per-workgroup counts into
+// offsets on the fly.  The count stays on the device (Ctl::n_vis / n_sel); consumers are
+// persistent grids that read it there.
 #pragma once
 #include "kernels_alloc.h"
 
@@ -18,93 +21,117 @@ struct GridBounds {  // BoundingCube<short>, voxel_tsdf.cuh:19-34
   int16_t xmin, xmax, ymin, ymax, zmin, zmax;
 };
 
-constexpr int kSelWG = 1024;  // entries per workgroup
+constexpr int kVisWG = 256;  // occupancy words (64 entries each) per workgroup
 
+// One lane per 64-entry occupancy word: evaluates the selection predicate for every allocated entry
+// of the word and writes the resulting 64-bit mask; the workgroup's total goes to wg_count.
+// Must be called by all threads of a kVisWG-thread workgroup (it synchronises).
 template <int Mode>
-__global__ __launch_bounds__(kSelWG) void k_select_flags(Table tab, FrameParams P, GridBounds gb,
-                                                         unsigned long long* masks,
-                                                         uint32_t* wg_count) {
-  __shared__ uint32_t wave_cnt[kSelWG / 64];
-  const uint32_t e = blockIdx.x * kSelWG + threadIdx.x;
-  const EntryWords w = load_entry(tab.entries, e);
-  bool sel = false;
-  if (w.idx >= 0) {
-    const int bx = (int16_t)(w.w0 & 0xFFFFu), by = (int16_t)(w.w0 >> 16),
-              bz = (int16_t)(w.w1 & 0xFFFFu);
-    if (Mode == kSelVisible) {
-      sel = block_visible<false>(bx, by, bz, P);                          // voxel_tsdf.cu:98-109
-    } else if (Mode == kSelValid) {
-      sel = true;                                                         // voxel_tsdf.cu:28-33
-    } else {
-      const int gx = (int16_t)(bx << 3), gy = (int16_t)(by << 3), gz = (int16_t)(bz << 3);
-      sel = gx >= gb.xmin && gy >= gb.ymin && gz >= gb.zmin && gx + 8 - 1 <= gb.xmax &&
-            gy + 8 - 1 <= gb.ymax && gz + 8 - 1 <= gb.zmax;               // voxel_tsdf.cu:15-26
+__device__ inline void select_flags_role(const Table& tab, const FrameParams& P,
+                                         const GridBounds& gb, uint32_t wg,
+                                         unsigned long long* masks, uint32_t* wg_count) {
+  __shared__ uint32_t wave_cnt[kVisWG / 64];
+  const uint32_t nwords = tab.num_entry >> 6;
+  const uint32_t w = wg * kVisWG + threadIdx.x;
+  unsigned long long occ = w < nwords ? tab.occ[w] : 0ull;
+  unsigned long long sel = 0;
+  if (Mode == kSelValid) {
+    sel = occ;                                                              // voxel_tsdf.cu:28-33
+  } else {
+    while (occ) {
+      const int b = __ffsll((long long)occ) - 1;
+      occ &= occ - 1;
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(tab.entries + ((size_t)w * 64 + b));
+      const uint32_t w0 = p[0], w1 = p[1];
+      const int bx = (int16_t)(w0 & 0xFFFFu), by = (int16_t)(w0 >> 16), bz = (int16_t)(w1 & 0xFFFFu);
+      bool s;
+      if (Mode == kSelVisible) {
+        s = block_visible<false>(bx, by, bz, P);                            // voxel_tsdf.cu:98-109
+      } else {
+        const int gx = (int16_t)(bx << 3), gy = (int16_t)(by << 3), gz = (int16_t)(bz << 3);
+        s = gx >= gb.xmin && gy >= gb.ymin && gz >= gb.zmin && gx + 8 - 1 <= gb.xmax &&
+            gy + 8 - 1 <= gb.ymax && gz + 8 - 1 <= gb.zmax;                 // voxel_tsdf.cu:15-26
+      }
+      if (s) sel |= 1ull << b;
     }
   }
-  const unsigned long long m = __ballot(sel);
-  const uint32_t wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    masks[blockIdx.x * (kSelWG / 64) + wv] = m;
-    wave_cnt[wv] = __popcll(m);
-  }
+  if (w < nwords) masks[w] = sel;
+  uint32_t cnt = __popcll(sel);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t s = 0;
+    uint32_t t = 0;
 #pragma unroll
-    for (int i = 0; i < kSelWG / 64; ++i) s += wave_cnt[i];
-    wg_count[blockIdx.x] = s;
+    for (int i = 0; i < kVisWG / 64; ++i) t += wave_cnt[i];
+    wg_count[wg] = t;
   }
 }
 
-// one workgroup: exclusive scan of the workgroup counts; total -> *total_out
-__global__ __launch_bounds__(1024) void k_select_scan(const uint32_t* wg_count, uint32_t* wg_offset,
-                                                      uint32_t nwg, uint32_t* total_out) {
-  __shared__ uint32_t lds[1024];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t chunk = (nwg + 1023) / 1024;
-  const uint32_t lo = tid * chunk;
-  const uint32_t hi = lo + chunk < nwg ? lo + chunk : nwg;
-  uint32_t sum = 0;
-  for (uint32_t i = lo; i < hi; ++i) sum += wg_count[i];
-  lds[tid] = sum;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    const uint32_t v = tid >= d ? lds[tid - d] : 0;
-    __syncthreads();
-    lds[tid] += v;
-    __syncthreads();
+// k_front: the two directory-read-only jobs of a frame in one launch.
+//   workgroups [0, n_pix_wg)          allocation candidates + packed texels (alloc_pixels_role)
+//   workgroups [n_pix_wg, gridDim.x)  visibility of the blocks that exist before this frame
+// Blocks inserted by this frame are added to the visibility mask by k_alloc_commit.
+__global__ __launch_bounds__(256) void k_front(Table tab, FrameParams P, uint32_t n_pix_wg,
+                                               const float* depth, const uint8_t* rgb,
+                                               const float* ht, const float* lt, float4* texA,
+                                               uint2* texB, Request* req, uint32_t req_cap,
+                                               SlowRequest* slow, uint32_t slow_cap,
+                                               unsigned long long* vismask, uint32_t* vis_wg_count,
+                                               Ctl* ctl) {
+  if (blockIdx.x < n_pix_wg) {
+    alloc_pixels_role(tab, P, blockIdx.x, depth, rgb, ht, lt, texA, texB, req, req_cap, slow,
+                      slow_cap, ctl);
+  } else {
+    select_flags_role<kSelVisible>(tab, P, GridBounds{}, blockIdx.x - n_pix_wg, vismask,
+                                   vis_wg_count);
   }
-  uint32_t run = lds[tid] - sum;
-  for (uint32_t i = lo; i < hi; ++i) {
-    wg_offset[i] = run;
-    run += wg_count[i];
-  }
-  if (tid == 1023) *total_out = lds[1023];
 }
 
-// scatter selected entries, in entry order, as 16-byte items {entry copy, entry index}
-__global__ __launch_bounds__(kSelWG) void k_select_scatter(Table tab,
+template <int Mode>
+__global__ __launch_bounds__(kVisWG) void k_select_flags(Table tab, FrameParams P, GridBounds gb,
+                                                         unsigned long long* masks,
+                                                         uint32_t* wg_count) {
+  select_flags_role<Mode>(tab, P, gb, blockIdx.x, masks, wg_count);
+}
+
+// Scatter the selected entries, in ascending entry order, as 16-byte items {entry copy, entry
+// index}.  Each workgroup derives its output offset from the (<= a few hundred) workgroup counts,
+// so no separate scan launch is needed; the last workgroup publishes the total.
+__global__ __launch_bounds__(kVisWG) void k_select_scatter(Table tab,
                                                            const unsigned long long* masks,
-                                                           const uint32_t* wg_count,
-                                                           const uint32_t* wg_offset, VisItem* out,
-                                                           uint32_t out_cap) {
-  if (wg_count[blockIdx.x] == 0) return;
-  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const unsigned long long* wm = masks + blockIdx.x * (kSelWG / 64);
-  const unsigned long long m = wm[wv];
-  if (!((m >> lane) & 1ull)) return;
-  uint32_t pos = wg_offset[blockIdx.x];
-  for (uint32_t i = 0; i < wv; ++i) pos += __popcll(wm[i]);
-  pos += __popcll(m & ((1ull << lane) - 1ull));
-  if (pos >= out_cap) return;
-  const uint32_t e = blockIdx.x * kSelWG + threadIdx.x;
-  const EntryWords w = load_entry(tab.entries, e);
-  uint4 v;
-  v.x = w.w0;
-  v.y = w.w1;
-  v.z = (uint32_t)w.idx;
-  v.w = e;
-  reinterpret_cast<uint4*>(out)[pos] = v;
+                                                           const uint32_t* wg_count, VisItem* out,
+                                                           uint32_t out_cap, uint32_t* total_out) {
+  __shared__ uint32_t lds[kVisWG];
+  const uint32_t wg = blockIdx.x, tid = threadIdx.x;
+  uint32_t before = 0;
+  for (uint32_t j = tid; j < wg; j += kVisWG) before += wg_count[j];
+  uint32_t wg_base = 0;
+  (void)block_exclusive_scan(before, lds, &wg_base);
+  const uint32_t own = wg_count[wg];
+  if (wg == gridDim.x - 1 && tid == 0) *total_out = wg_base + own;
+  if (own == 0) return;  // uniform
+  const uint32_t nwords = tab.num_entry >> 6;
+  const uint32_t w = wg * kVisWG + tid;
+  unsigned long long m = w < nwords ? masks[w] : 0ull;
+  uint32_t dummy = 0;
+  uint32_t pos = wg_base + block_exclusive_scan((uint32_t)__popcll(m), lds, &dummy);
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const uint32_t e = w * 64 + b;
+    if (pos < out_cap) {
+      const EntryWords ew = load_entry(tab.entries, e);
+      uint4 v;
+      v.x = ew.w0;
+      v.y = ew.w1;
+      v.z = (uint32_t)ew.idx;
+      v.w = e;
+      reinterpret_cast<uint4*>(out)[pos] = v;
+    }
+    ++pos;
+  }
 }
 
 // download_tsdf_kernel / download_semantic_kernel, voxel_tsdf.cu:35-62: one wave per selected

@@ -28,11 +28,12 @@ using namespace ratsdf;
 
 namespace {
 
-__global__ void k_init_table(Entry* entries, uint32_t* claim, uint32_t num_entry,
-                             uint32_t num_bucket) {
+__global__ void k_init_table(Entry* entries, uint32_t* claim, unsigned long long* occ,
+                             uint32_t num_entry, uint32_t num_bucket) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < num_entry) entries[i] = Entry{0, 0, 0, 0, -1};  // init_hash_table_kernel, voxel_hash.cu:14-17
   if (i < num_bucket) claim[i] = kInf;
+  if (i < (num_entry + 63) / 64) occ[i] = 0ull;
 }
 __global__ void k_init_heap(int32_t* heap, int32_t n) {   // heap_init_kernel, voxel_mem.cu:6-11
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,6 +41,7 @@ __global__ void k_init_heap(int32_t* heap, int32_t n) {   // heap_init_kernel, v
 }
 
 constexpr uint32_t kSlowCap = kSlowSortCap;
+constexpr int kDefaultVPL = 8;  // voxels per lane in k_integrate (RATSDF_VPL=2|4|8 overrides: tuning)
 constexpr uint32_t kSlowDelCap = 1u << 16;
 
 }  // namespace
@@ -51,6 +53,8 @@ struct ratsdf_engine {
   int block_bits = 0, bucket_bits = 0;
   int shard_rank = 0, shard_count = 1, shard_slab_bits = 2;
   int S = 3;
+  int vpl = kDefaultVPL;
+  unsigned integrate_grid = 2048;
 
   Table tab{};
   Pool pool{};
@@ -64,7 +68,7 @@ struct ratsdf_engine {
   Request* req = nullptr;
   uint32_t req_cap = 0;
   uint32_t* abitmap[2] = {nullptr, nullptr};
-  uint32_t* aprefix = nullptr;
+  uint32_t* chunk_prefix = nullptr;  // 1024 words
   uint32_t awords_cap = 0;
   int apass = 0;
 
@@ -73,14 +77,12 @@ struct ratsdf_engine {
   SlowRequest* distinct = nullptr;
 
   // directory-sized scratch
-  unsigned long long* masks = nullptr;
-  uint32_t* wg_count = nullptr;
-  uint32_t* wg_offset = nullptr;
+  unsigned long long* masks = nullptr;  // selection / visibility mask, one bit per directory entry
+  uint32_t* wg_count = nullptr;         // selected entries per kVisWG-word workgroup
   uint32_t nwg = 0;
   VisItem* vis = nullptr;
-  uint8_t* carve_flag = nullptr;
+  uint32_t* carve_flag = nullptr;  // per visible block: bit 31 carve candidate | voxels updated
   uint32_t* dbitmap[2] = {nullptr, nullptr};
-  uint32_t* dprefix = nullptr;
   uint32_t dwords = 0;
   int dpass = 0;
   int32_t* del_idx = nullptr;
@@ -101,7 +103,7 @@ struct ratsdf_engine {
   int free_all();
   int ensure_image(size_t npix, size_t nranks);
   int ensure_stage(size_t npix);
-  int alloc_tail(uint32_t nranks);
+  int alloc_tail(uint32_t nranks, bool is_frame);
   int carve_tail(bool is_frame);
   int select(int mode, const GridBounds& gb, uint32_t* count_slot);
   int frame(const void* d_rgb, const void* d_depth, const void* d_ht, const void* d_lt, int H, int W,
@@ -132,9 +134,9 @@ FrameParams ratsdf_engine::base_params() const {
 
 int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
-  void* ptrs[] = {tab.entries, tab.claim, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl, d_stats,
-                  texA, texB, req, abitmap[0], abitmap[1], aprefix, slow, xlocks, distinct, masks,
-                  wg_count, wg_offset, vis, carve_flag, dbitmap[0], dbitmap[1], dprefix, del_idx,
+  void* ptrs[] = {tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
+                  d_stats, texA, texB, req, abitmap[0], abitmap[1], chunk_prefix, slow, xlocks,
+                  distinct, masks, wg_count, vis, carve_flag, dbitmap[0], dbitmap[1], del_idx,
                   slowdel, d_stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -161,13 +163,11 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
     if (req) (void)hipFree(req);
     if (abitmap[0]) (void)hipFree(abitmap[0]);
     if (abitmap[1]) (void)hipFree(abitmap[1]);
-    if (aprefix) (void)hipFree(aprefix);
     req_cap = (uint32_t)nranks;
     awords_cap = (uint32_t)((nranks + 31) / 32);
     HIPCHK(hipMalloc(&req, (size_t)req_cap * sizeof(Request)));
     HIPCHK(hipMalloc(&abitmap[0], (size_t)awords_cap * 4));
     HIPCHK(hipMalloc(&abitmap[1], (size_t)awords_cap * 4));
-    HIPCHK(hipMalloc(&aprefix, (size_t)awords_cap * 4));
     rank_cap = nranks;
   }
   // Each pass's scan kernel cleans the other bitmap only over the current rank space, so both must
@@ -194,18 +194,16 @@ int ratsdf_engine::ensure_stage(size_t npix) {
   return RATSDF_OK;
 }
 
-// resolve -> mark -> scan -> commit on a rank space of `nranks`
-int ratsdf_engine::alloc_tail(uint32_t nranks) {
+// rank (resolve + mark + scan) -> commit on a rank space of `nranks`
+int ratsdf_engine::alloc_tail(uint32_t nranks, bool is_frame) {
   const uint32_t nwords = (nranks + 31) / 32;
   uint32_t* bm = abitmap[apass & 1];
   uint32_t* bm_next = abitmap[(apass + 1) & 1];
-  hipLaunchKernelGGL(k_alloc_resolve, dim3(1), dim3(1024), kSlowSortCap * sizeof(unsigned long long),
-                     stream, tab, req, req_cap, slow, kSlowCap, xlocks, distinct, ctl);
-  hipLaunchKernelGGL(k_alloc_mark, dim3(128), dim3(256), 0, stream, tab, req, req_cap, bm, ctl);
-  hipLaunchKernelGGL(k_alloc_scan, dim3(1), dim3(1024), 0, stream, bm, aprefix, nwords, bm_next,
-                     nwords, ctl);
-  hipLaunchKernelGGL(k_alloc_commit, dim3(512), dim3(256), 0, stream, tab, pool, req, req_cap, bm,
-                     aprefix, ctl);
+  hipLaunchKernelGGL(k_alloc_rank, dim3(1), dim3(1024), kSlowSortCap * sizeof(unsigned long long),
+                     stream, tab, req, req_cap, slow, kSlowCap, xlocks, distinct, bm, chunk_prefix,
+                     nwords, bm_next, nwords, ctl);
+  hipLaunchKernelGGL(k_alloc_commit, dim3(256), dim3(256), 0, stream, tab, pool, req, req_cap, bm,
+                     chunk_prefix, is_frame ? masks : (unsigned long long*)nullptr, wg_count, ctl);
   ++apass;
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
@@ -214,13 +212,9 @@ int ratsdf_engine::alloc_tail(uint32_t nranks) {
 int ratsdf_engine::carve_tail(bool is_frame) {
   uint32_t* bm = dbitmap[dpass & 1];
   uint32_t* bm_next = dbitmap[(dpass + 1) & 1];
-  hipLaunchKernelGGL(k_carve_mark, dim3(128), dim3(256), 0, stream, tab, vis, carve_flag, bm,
-                     del_idx, slowdel, kSlowDelCap, ctl);
-  hipLaunchKernelGGL(k_carve_scan, dim3(1), dim3(1024), 0, stream, tab, slowdel, kSlowDelCap, bm,
-                     dprefix, del_idx, bm_next, dwords, ctl,
+  hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, stream, tab, pool, vis, carve_flag, bm, bm_next,
+                     dwords, del_idx, slowdel, kSlowDelCap, ctl,
                      is_frame ? d_stats : (ratsdf_frame_stats*)nullptr);
-  hipLaunchKernelGGL(k_carve_commit, dim3(128), dim3(256), 0, stream, pool, bm, dprefix, del_idx,
-                     ctl);
   ++dpass;
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
@@ -230,15 +224,13 @@ int ratsdf_engine::carve_tail(bool is_frame) {
 int ratsdf_engine::select(int mode, const GridBounds& gb, uint32_t* count_slot) {
   FrameParams P = base_params();
   if (mode == kSelValid)
-    hipLaunchKernelGGL(k_select_flags<kSelValid>, dim3(nwg), dim3(kSelWG), 0, stream, tab, P, gb,
+    hipLaunchKernelGGL(k_select_flags<kSelValid>, dim3(nwg), dim3(kVisWG), 0, stream, tab, P, gb,
                        masks, wg_count);
   else
-    hipLaunchKernelGGL(k_select_flags<kSelBounds>, dim3(nwg), dim3(kSelWG), 0, stream, tab, P, gb,
+    hipLaunchKernelGGL(k_select_flags<kSelBounds>, dim3(nwg), dim3(kVisWG), 0, stream, tab, P, gb,
                        masks, wg_count);
-  hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, stream, wg_count, wg_offset, nwg,
-                     count_slot);
-  hipLaunchKernelGGL(k_select_scatter, dim3(nwg), dim3(kSelWG), 0, stream, tab, masks, wg_count,
-                     wg_offset, vis, (uint32_t)tab.num_block);
+  hipLaunchKernelGGL(k_select_scatter, dim3(nwg), dim3(kVisWG), 0, stream, tab, masks, wg_count, vis,
+                     (uint32_t)tab.num_block, count_slot);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
@@ -260,19 +252,16 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
   P.S = S;
   P.has_sem = (d_ht && d_lt) ? 1 : 0;
 
-  HIPCHK(hipMemsetAsync(ctl, 0, kCtlFrameBytes, stream));
-  hipLaunchKernelGGL(k_alloc_pixels, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, tab,
-                     P, (const float*)d_depth, (const uint8_t*)d_rgb, (const float*)d_ht,
-                     (const float*)d_lt, texA, texB, req, req_cap, slow, kSlowCap, ctl);
-  st = alloc_tail((uint32_t)(npix * (size_t)S));
+  // the control block was zeroed by the previous pass's last kernel (k_carve) or at creation
+  const unsigned n_pix_wg = (unsigned)((npix + 255) / 256);
+  hipLaunchKernelGGL(k_front, dim3(n_pix_wg + nwg), dim3(256), 0, stream, tab, P, n_pix_wg,
+                     (const float*)d_depth, (const uint8_t*)d_rgb, (const float*)d_ht,
+                     (const float*)d_lt, texA, texB, req, req_cap, slow, kSlowCap, masks, wg_count,
+                     ctl);
+  st = alloc_tail((uint32_t)(npix * (size_t)S), true);
   if (st != RATSDF_OK) return st;
-
-  hipLaunchKernelGGL(k_select_flags<kSelVisible>, dim3(nwg), dim3(kSelWG), 0, stream, tab, P,
-                     GridBounds{}, masks, wg_count);
-  hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, stream, wg_count, wg_offset, nwg,
-                     &ctl->n_vis);
-  hipLaunchKernelGGL(k_select_scatter, dim3(nwg), dim3(kSelWG), 0, stream, tab, masks, wg_count,
-                     wg_offset, vis, (uint32_t)tab.num_block);
+  hipLaunchKernelGGL(k_select_scatter, dim3(nwg), dim3(kVisWG), 0, stream, tab, masks, wg_count, vis,
+                     (uint32_t)tab.num_block, &ctl->n_vis);
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (profiling) {
@@ -287,8 +276,19 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
     ++prof_used;
     HIPCHK(hipEventRecord(ev0, stream));
   }
-  hipLaunchKernelGGL(k_integrate, dim3(2048), dim3(256), 0, stream, pool, P, vis, texA, texB,
-                     carve_flag, ctl);
+  switch (vpl) {
+    case 8:
+      hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, pool, P, vis,
+                         texA, texB, carve_flag, ctl);
+      break;
+    case 4:
+      hipLaunchKernelGGL(k_integrate<4>, dim3(integrate_grid), dim3(256), 0, stream, pool, P, vis,
+                         texA, texB, carve_flag, ctl);
+      break;
+    default:
+      hipLaunchKernelGGL(k_integrate<2>, dim3(integrate_grid), dim3(256), 0, stream, pool, P, vis,
+                         texA, texB, carve_flag, ctl);
+  }
   if (profiling) HIPCHK(hipEventRecord(ev1, stream));
 
   st = carve_tail(true);
@@ -343,13 +343,22 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   e->shard_count = cfg->shard_count > 1 ? cfg->shard_count : 1;
   e->shard_slab_bits = cfg->shard_slab_bits > 0 ? cfg->shard_slab_bits : 2;
   e->S = (int)ceilf(2.f * e->trunc / e->vs / RATSDF_BLOCK_LEN) + 2;
+  if (const char* v = getenv("RATSDF_VPL")) {
+    const int x = atoi(v);
+    if (x == 2 || x == 4 || x == 8) e->vpl = x;
+  }
+  if (const char* v = getenv("RATSDF_GRID")) {
+    const int x = atoi(v);
+    if (x >= 64 && x <= 65536) e->integrate_grid = (unsigned)x;
+  }
   Table& t = e->tab;
   t.num_block = 1 << bb;
   t.num_bucket = 1u << kb;
   t.num_entry = t.num_bucket << 1;
   t.bucket_mask = t.num_bucket - 1;
   t.entry_mask = t.num_entry - 1;
-  e->nwg = t.num_entry / kSelWG;
+  const uint32_t occ_words = (t.num_entry + 63) / 64;
+  e->nwg = (occ_words + kVisWG - 1) / kVisWG;
   e->dwords = ((uint32_t)t.num_block + 31) / 32;
   const size_t nvox = (size_t)t.num_block << 9;
 
@@ -366,6 +375,8 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CREATE_CHK(hipMalloc(&t.entries, (size_t)t.num_entry * sizeof(Entry)));
   CREATE_CHK(hipMalloc(&t.claim, (size_t)t.num_bucket * 4));
+  CREATE_CHK(hipMalloc(&t.occ, (size_t)occ_words * 8));
+  CREATE_CHK(hipMalloc(&e->chunk_prefix, 1024 * 4));
   CREATE_CHK(hipMalloc(&e->pool.rgbw, nvox * 4));
   CREATE_CHK(hipMalloc(&e->pool.tsdf, nvox * 4));
   CREATE_CHK(hipMalloc(&e->pool.segm, nvox * 4));
@@ -375,14 +386,12 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->slow, (size_t)kSlowCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->xlocks, (size_t)kXLockCap * sizeof(XLock)));
   CREATE_CHK(hipMalloc(&e->distinct, (size_t)kSlowDistinctCap * sizeof(SlowRequest)));
-  CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * (kSelWG / 64) * 8));
+  CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * kVisWG * 8));
   CREATE_CHK(hipMalloc(&e->wg_count, (size_t)e->nwg * 4));
-  CREATE_CHK(hipMalloc(&e->wg_offset, (size_t)e->nwg * 4));
   CREATE_CHK(hipMalloc(&e->vis, (size_t)t.num_block * sizeof(VisItem)));
-  CREATE_CHK(hipMalloc(&e->carve_flag, (size_t)t.num_block));
+  CREATE_CHK(hipMalloc(&e->carve_flag, (size_t)t.num_block * 4));
   CREATE_CHK(hipMalloc(&e->dbitmap[0], (size_t)e->dwords * 4));
   CREATE_CHK(hipMalloc(&e->dbitmap[1], (size_t)e->dwords * 4));
-  CREATE_CHK(hipMalloc(&e->dprefix, (size_t)e->dwords * 4));
   CREATE_CHK(hipMalloc(&e->del_idx, (size_t)t.num_block * 4));
   CREATE_CHK(hipMalloc(&e->slowdel, (size_t)kSlowDelCap * sizeof(SlowDelete)));
   // voxel memory starts zeroed (defined value for the reference's uninitialised rgb)
@@ -394,12 +403,12 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMemsetAsync(e->dbitmap[0], 0, (size_t)e->dwords * 4, e->stream));
   CREATE_CHK(hipMemsetAsync(e->dbitmap[1], 0, (size_t)e->dwords * 4, e->stream));
   hipLaunchKernelGGL(k_init_table, dim3((t.num_entry + 255) / 256), dim3(256), 0, e->stream,
-                     t.entries, t.claim, t.num_entry, t.num_bucket);
+                     t.entries, t.claim, t.occ, t.num_entry, t.num_bucket);
   hipLaunchKernelGGL(k_init_heap, dim3((t.num_block + 255) / 256), dim3(256), 0, e->stream,
                      e->pool.heap, t.num_block);
   const int32_t nf = t.num_block;
   CREATE_CHK(hipMemcpyAsync(&e->ctl->num_free, &nf, 4, hipMemcpyHostToDevice, e->stream));
-  CREATE_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_alloc_resolve),
+  CREATE_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_alloc_rank),
                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                  kSlowSortCap * (int)sizeof(unsigned long long)));
   CREATE_CHK(hipStreamSynchronize(e->stream));
@@ -634,7 +643,9 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
   hipLaunchKernelGGL(k_alloc_list, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->tab, P, d, n,
                      e->req, e->req_cap, e->slow, kSlowCap, e->ctl);
-  st = e->alloc_tail((uint32_t)n);
+  st = e->alloc_tail((uint32_t)n, false);
+  // frames expect a clean control block (normally left behind by k_carve)
+  HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
   const int st2 = e->sticky();
   (void)hipFree(d);
   return st != RATSDF_OK ? st : st2;
