@@ -1,0 +1,60 @@
+// tsdf_grid.hpp -- TSDFGrid with the reference's method names (utils/tsdf/voxel_tsdf.cuh:39-145),
+// forwarding to the C ABI of include/ratsdf.h.  The ABI library is bound at run time (dlopen), so
+// this host layer builds with g++ alone; the default binding is the in-tree HIP engine.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "types.hpp"
+
+namespace ratsdf {
+
+// Entry points of include/ratsdf.h resolved from one shared library.
+struct Api {
+  int (*create)(float, float, int, ratsdf_engine**) = nullptr;
+  int (*destroy)(ratsdf_engine*) = nullptr;
+  int (*integrate)(ratsdf_engine*, const uint8_t*, const float*, const float*, const float*, int,
+                   int, float, const ratsdf_intrinsics*, const ratsdf_pose*) = nullptr;
+  int (*query)(ratsdf_engine*, const ratsdf_bounds*, ratsdf_voxel_tsdf**, size_t*) = nullptr;
+  int (*gather_valid)(ratsdf_engine*, ratsdf_voxel_tsdf**, size_t*) = nullptr;
+  int (*gather_valid_semantic)(ratsdf_engine*, ratsdf_voxel_segm**, size_t*) = nullptr;
+  int (*download_all)(ratsdf_engine*, const char*) = nullptr;
+  int (*free_buffer)(void*) = nullptr;
+  int (*num_active_blocks)(ratsdf_engine*, int32_t*) = nullptr;
+  const char* (*status_string)(int) = nullptr;
+  const char* (*backend)() = nullptr;
+  void* handle = nullptr;
+
+  // path == nullptr: $RATSDF_LIB or libratsdf.so next to this layer; prefix: "ratsdf_"
+  static const Api& Load(const char* path = nullptr, const char* prefix = "ratsdf_");
+};
+
+class TSDFGrid {
+ public:
+  TSDFGrid(float voxel_size, float truncation, int device = 0, const Api* api = nullptr);
+  ~TSDFGrid();
+  TSDFGrid(const TSDFGrid&) = delete;
+  TSDFGrid& operator=(const TSDFGrid&) = delete;
+
+  // voxel_tsdf.cuh:65-67.  Like the reference (errors.cuh:13-20) failures do not throw; the last
+  // status is kept and printed to stderr.
+  void Integrate(const Image& img_rgb, const Image& img_depth, const Image& img_ht,
+                 const Image& img_lt, float max_depth, const CameraIntrinsics<float>& intrinsics,
+                 const SE3<float>& cam_T_world);
+  std::vector<VoxelSpatialTSDF> GatherValid();                                   // :86
+  std::vector<VoxelSpatialTSDFSEGM> GatherValidSemantic();                       // :93
+  std::vector<VoxelSpatialTSDF> GatherVoxels(const BoundingCube<float>& volumn);  // :102
+  void DownloadAll(const std::string& file_path);  // the write of tsdf_module.cc:57-64
+  int NumActiveBlock();                            // voxel_hash.cu:225
+  int last_status() const { return status_; }
+  ratsdf_engine* handle() { return engine_; }
+  const Api& api() const { return *api_; }
+
+ private:
+  void note(int st, const char* what);
+  const Api* api_;
+  ratsdf_engine* engine_ = nullptr;
+  int status_ = 0;
+};
+
+}  // namespace ratsdf

@@ -1,0 +1,77 @@
+// tsdf_system.hpp -- TSDFSystem: the threaded front of the TSDF map, same public surface and
+// locking as the reference (modules/tsdf_module.h:37-165, modules/tsdf_module.cc:7-131).
+//
+//   * the constructor starts the integration thread                         (tsdf_module.cc:7-12)
+//   * Integrate() may be called from any thread, blocks while paused, deep-copies its images into
+//     the queue (callers may reuse their buffers at once), substitutes all-ones ht/lt images when
+//     either is empty and composes cam_T_posecam * posecam_T_world          (tsdf_module.cc:22-37)
+//   * the worker integrates under mtx_read_; Query / DownloadAll take the same mutex, so they are
+//     serialised against integration and each other                         (tsdf_module.cc:39-64,88-115)
+//   * terminate() stops the worker at the top of its loop, DISCARDING queued frames, exactly like
+//     the reference (tsdf_module.cc:91-94,119-125).  Knowingly fixed: terminate() is idempotent
+//     (the reference's destructor joins a second time and would throw), and Flush() is added so a
+//     harness can wait for the queue to drain first.
+//   * Render / DownloadAllMesh (ray casting, marching cubes) are outside this build's scope.
+#pragma once
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "tsdf_grid.hpp"
+
+namespace ratsdf {
+
+struct TSDFSystemInput {  // tsdf_module.h:19-35, images owned by the queue element
+  SE3<float> cam_T_world;
+  int rows = 0, cols = 0;
+  std::vector<uint8_t> img_rgb;
+  std::vector<float> img_depth, img_ht, img_lt;
+};
+
+class TSDFSystem {
+ public:
+  TSDFSystem(float voxel_size, float truncation, float max_depth,
+             const CameraIntrinsics<float>& intrinsics,
+             const SE3<float>& extrinsics = SE3<float>::Identity(), int device = 0,
+             const Api* api = nullptr);
+  ~TSDFSystem();
+
+  void Integrate(const SE3<float>& posecam_T_world, const Image& img_rgb, const Image& img_depth,
+                 const Image& img_ht = {}, const Image& img_lt = {});
+  std::vector<VoxelSpatialTSDF> Query(const BoundingCube<float>& volumn);
+  void DownloadAll(const std::string& file_path);
+  bool is_terminated();
+  void terminate();
+  void SetPause(bool pause);
+
+  // additions (not in the reference)
+  void Flush();                 // block until every queued frame has been integrated
+  size_t QueueSize();
+  int NumActiveBlock();
+  size_t frames_integrated();
+
+ private:
+  void Run();
+  TSDFGrid tsdf_;
+  float max_depth_;
+  const CameraIntrinsics<float> intrinsics_;
+  const SE3<float> cam_T_posecam_;
+  std::mutex mtx_queue_;
+  std::queue<std::unique_ptr<TSDFSystemInput>> inputs_;
+  std::condition_variable cv_queue_;  // the reference busy-polls (tsdf_module.cc:101)
+  bool busy_ = false;
+  std::mutex mtx_read_;
+  std::mutex mtx_terminate_;
+  bool terminate_ = false;
+  std::mutex mtx_pause_;
+  std::condition_variable cv_pause_;
+  bool pause_ = false;
+  size_t frames_done_ = 0;
+  std::thread t_;  // declared last: everything above exists before Run() starts (tsdf_module.h:144-164)
+};
+
+}  // namespace ratsdf

@@ -1,0 +1,287 @@
+// tsdf_host.cc -- TSDFGrid / TSDFSystem host layer over the C ABI (see the headers for the mapping
+// to the reference's modules/tsdf_module.* and utils/tsdf/voxel_tsdf.cuh).
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "ratsdf/tsdf_system.hpp"
+
+namespace ratsdf {
+
+namespace {
+std::string default_library() {
+  if (const char* env = getenv("RATSDF_LIB")) return env;
+  Dl_info info;
+  if (dladdr((void*)&default_library, &info) && info.dli_fname) {
+    std::string here(info.dli_fname);
+    const size_t slash = here.rfind('/');
+    const std::string dir = slash == std::string::npos ? "." : here.substr(0, slash);
+    return dir + "/../../csrc/build/libratsdf.so";  // ra-slam_amd/host/build -> ra-slam_amd/csrc/build
+  }
+  return "libratsdf.so";
+}
+}  // namespace
+
+const Api& Api::Load(const char* path, const char* prefix) {
+  static std::mutex mtx;
+  static std::map<std::string, Api> loaded;
+  std::lock_guard<std::mutex> lock(mtx);
+  const std::string lib = path ? path : default_library();
+  const std::string key = lib + "|" + prefix;
+  auto it = loaded.find(key);
+  if (it != loaded.end()) return it->second;
+  Api api;
+  api.handle = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!api.handle) {
+    fprintf(stderr, "[ratsdf] cannot load %s: %s\n", lib.c_str(), dlerror());
+    abort();  // no fallback: the HIP engine is the only implementation of the product path
+  }
+  auto sym = [&](const char* name) {
+    const std::string full = std::string(prefix) + name;
+    void* p = dlsym(api.handle, full.c_str());
+    if (!p) {
+      fprintf(stderr, "[ratsdf] %s does not export %s\n", lib.c_str(), full.c_str());
+      abort();
+    }
+    return p;
+  };
+  api.create = reinterpret_cast<decltype(api.create)>(sym("create"));
+  api.destroy = reinterpret_cast<decltype(api.destroy)>(sym("destroy"));
+  api.integrate = reinterpret_cast<decltype(api.integrate)>(sym("integrate"));
+  api.query = reinterpret_cast<decltype(api.query)>(sym("query"));
+  api.gather_valid = reinterpret_cast<decltype(api.gather_valid)>(sym("gather_valid"));
+  api.gather_valid_semantic =
+      reinterpret_cast<decltype(api.gather_valid_semantic)>(sym("gather_valid_semantic"));
+  api.download_all = reinterpret_cast<decltype(api.download_all)>(sym("download_all"));
+  api.free_buffer = reinterpret_cast<decltype(api.free_buffer)>(sym("free_buffer"));
+  api.num_active_blocks = reinterpret_cast<decltype(api.num_active_blocks)>(sym("num_active_blocks"));
+  api.status_string = reinterpret_cast<decltype(api.status_string)>(sym("status_string"));
+  api.backend = reinterpret_cast<decltype(api.backend)>(sym("backend"));
+  return loaded.emplace(key, api).first->second;
+}
+
+// ---- TSDFGrid -------------------------------------------------------------------------------
+TSDFGrid::TSDFGrid(float voxel_size, float truncation, int device, const Api* api)
+    : api_(api ? api : &Api::Load()) {
+  note(api_->create(voxel_size, truncation, device, &engine_), "create");
+}
+
+TSDFGrid::~TSDFGrid() {
+  if (engine_) api_->destroy(engine_);
+}
+
+void TSDFGrid::note(int st, const char* what) {
+  status_ = st;
+  if (st != RATSDF_OK)
+    fprintf(stderr, "[ratsdf] %s failed: %s\n", what, api_->status_string(st));
+}
+
+void TSDFGrid::Integrate(const Image& rgb, const Image& depth, const Image& ht, const Image& lt,
+                         float max_depth, const CameraIntrinsics<float>& K,
+                         const SE3<float>& cam_T_world) {
+  if (!engine_) return;
+  // the reference's asserts, voxel_tsdf.cu:419-428
+  if (rgb.type != kU8C3 || depth.type != kF32C1 || rgb.rows != depth.rows ||
+      rgb.cols != depth.cols ||
+      (!ht.empty() && (ht.type != kF32C1 || ht.rows != depth.rows || ht.cols != depth.cols)) ||
+      (!lt.empty() && (lt.type != kF32C1 || lt.rows != depth.rows || lt.cols != depth.cols))) {
+    note(RATSDF_ERR_BAD_ARGUMENT, "Integrate");
+    return;
+  }
+  const ratsdf_intrinsics k{K.fx, K.fy, K.cx, K.cy};
+  const ratsdf_pose p = cam_T_world.abi();
+  note(api_->integrate(engine_, static_cast<const uint8_t*>(rgb.data),
+                       static_cast<const float*>(depth.data),
+                       ht.empty() ? nullptr : static_cast<const float*>(ht.data),
+                       lt.empty() ? nullptr : static_cast<const float*>(lt.data), depth.rows,
+                       depth.cols, max_depth, &k, &p),
+       "Integrate");
+}
+
+std::vector<VoxelSpatialTSDF> TSDFGrid::GatherValid() {
+  std::vector<VoxelSpatialTSDF> out;
+  if (!engine_) return out;
+  ratsdf_voxel_tsdf* buf = nullptr;
+  size_t n = 0;
+  note(api_->gather_valid(engine_, &buf, &n), "GatherValid");
+  if (status_ == RATSDF_OK) out.assign(buf, buf + n);
+  if (buf) api_->free_buffer(buf);
+  return out;
+}
+
+std::vector<VoxelSpatialTSDFSEGM> TSDFGrid::GatherValidSemantic() {
+  std::vector<VoxelSpatialTSDFSEGM> out;
+  if (!engine_) return out;
+  ratsdf_voxel_segm* buf = nullptr;
+  size_t n = 0;
+  note(api_->gather_valid_semantic(engine_, &buf, &n), "GatherValidSemantic");
+  if (status_ == RATSDF_OK) out.assign(buf, buf + n);
+  if (buf) api_->free_buffer(buf);
+  return out;
+}
+
+std::vector<VoxelSpatialTSDF> TSDFGrid::GatherVoxels(const BoundingCube<float>& v) {
+  std::vector<VoxelSpatialTSDF> out;
+  if (!engine_) return out;
+  const ratsdf_bounds b{v.xmin, v.xmax, v.ymin, v.ymax, v.zmin, v.zmax};
+  ratsdf_voxel_tsdf* buf = nullptr;
+  size_t n = 0;
+  note(api_->query(engine_, &b, &buf, &n), "GatherVoxels");
+  if (status_ == RATSDF_OK) out.assign(buf, buf + n);
+  if (buf) api_->free_buffer(buf);
+  return out;
+}
+
+void TSDFGrid::DownloadAll(const std::string& path) {
+  if (engine_) note(api_->download_all(engine_, path.c_str()), "DownloadAll");
+}
+
+int TSDFGrid::NumActiveBlock() {
+  int32_t n = 0;
+  if (engine_) note(api_->num_active_blocks(engine_, &n), "NumActiveBlock");
+  return n;
+}
+
+// ---- TSDFSystem -----------------------------------------------------------------------------
+TSDFSystem::TSDFSystem(float voxel_size, float truncation, float max_depth,
+                       const CameraIntrinsics<float>& intrinsics, const SE3<float>& extrinsics,
+                       int device, const Api* api)
+    : tsdf_(voxel_size, truncation, device, api),
+      max_depth_(max_depth),
+      intrinsics_(intrinsics),
+      cam_T_posecam_(extrinsics),
+      t_(&TSDFSystem::Run, this) {}
+
+TSDFSystem::~TSDFSystem() { this->terminate(); }
+
+void TSDFSystem::Integrate(const SE3<float>& posecam_T_world, const Image& rgb, const Image& depth,
+                           const Image& ht, const Image& lt) {
+  std::unique_lock<std::mutex> pause_lock(mtx_pause_);
+  while (pause_) cv_pause_.wait(pause_lock);
+  auto in = std::make_unique<TSDFSystemInput>();
+  in->cam_T_world = cam_T_posecam_ * posecam_T_world;  // tsdf_module.cc:28,33
+  in->rows = depth.rows;
+  in->cols = depth.cols;
+  const size_t npix = (size_t)depth.rows * depth.cols;
+  const uint8_t* c = static_cast<const uint8_t*>(rgb.data);
+  const float* d = static_cast<const float*>(depth.data);
+  in->img_rgb.assign(c, c + npix * 3);  // clone(), tsdf_module.cc:28-35
+  in->img_depth.assign(d, d + npix);
+  if (ht.empty() || lt.empty()) {
+    in->img_ht.assign(npix, 1.f);  // cv::Mat::ones, tsdf_module.cc:29-31
+    in->img_lt.assign(npix, 1.f);
+  } else {
+    const float* h = static_cast<const float*>(ht.data);
+    const float* l = static_cast<const float*>(lt.data);
+    in->img_ht.assign(h, h + npix);
+    in->img_lt.assign(l, l + npix);
+  }
+  {
+    std::lock_guard<std::mutex> lock(mtx_queue_);
+    inputs_.push(std::move(in));
+  }
+  cv_queue_.notify_all();
+}
+
+std::vector<VoxelSpatialTSDF> TSDFSystem::Query(const BoundingCube<float>& volumn) {
+  std::lock_guard<std::mutex> lock(mtx_read_);
+  return tsdf_.GatherVoxels(volumn);
+}
+
+void TSDFSystem::DownloadAll(const std::string& file_path) {
+  std::lock_guard<std::mutex> lock(mtx_read_);
+  tsdf_.DownloadAll(file_path);
+}
+
+void TSDFSystem::Run() {
+  while (true) {
+    std::unique_ptr<TSDFSystemInput> input;
+    {
+      std::unique_lock<std::mutex> lock(mtx_queue_);
+      // wake up for new input or for termination; the reference spins here (tsdf_module.cc:88-102)
+      while (inputs_.empty()) {
+        {
+          std::lock_guard<std::mutex> tl(mtx_terminate_);
+          if (terminate_) return;
+        }
+        cv_queue_.wait_for(lock, std::chrono::milliseconds(2));
+      }
+      {
+        std::lock_guard<std::mutex> tl(mtx_terminate_);
+        if (terminate_) return;  // queued frames are dropped, as in the reference
+      }
+      if (inputs_.size() > 10)
+        fprintf(stderr, "[TSDF System] Processing cannot catch up (input size: %zu)\n",
+                inputs_.size());
+      input = std::move(inputs_.front());
+      inputs_.pop();
+      busy_ = true;
+    }
+    {
+      std::lock_guard<std::mutex> lock(mtx_read_);
+      const Image rgb{input->img_rgb.data(), input->rows, input->cols, kU8C3};
+      const Image depth{input->img_depth.data(), input->rows, input->cols, kF32C1};
+      const Image ht{input->img_ht.data(), input->rows, input->cols, kF32C1};
+      const Image lt{input->img_lt.data(), input->rows, input->cols, kF32C1};
+      tsdf_.Integrate(rgb, depth, ht, lt, max_depth_, intrinsics_, input->cam_T_world);
+    }
+    {
+      std::lock_guard<std::mutex> lock(mtx_queue_);
+      busy_ = false;
+      ++frames_done_;
+    }
+    cv_queue_.notify_all();
+  }
+}
+
+bool TSDFSystem::is_terminated() {
+  std::lock_guard<std::mutex> lock(mtx_terminate_);
+  return terminate_;
+}
+
+void TSDFSystem::terminate() {
+  {
+    std::lock_guard<std::mutex> lock(mtx_terminate_);
+    terminate_ = true;
+  }
+  cv_queue_.notify_all();
+  if (t_.joinable()) t_.join();  // idempotent, unlike tsdf_module.cc:119-125
+}
+
+void TSDFSystem::SetPause(bool pause) {
+  std::unique_lock<std::mutex> pause_lock(mtx_pause_);
+  pause_ = pause;
+  cv_pause_.notify_all();
+}
+
+void TSDFSystem::Flush() {
+  std::unique_lock<std::mutex> lock(mtx_queue_);
+  while (!inputs_.empty() || busy_) {
+    {
+      std::lock_guard<std::mutex> tl(mtx_terminate_);
+      if (terminate_) return;
+    }
+    cv_queue_.wait_for(lock, std::chrono::milliseconds(2));
+  }
+}
+
+size_t TSDFSystem::QueueSize() {
+  std::lock_guard<std::mutex> lock(mtx_queue_);
+  return inputs_.size();
+}
+
+int TSDFSystem::NumActiveBlock() {
+  std::lock_guard<std::mutex> lock(mtx_read_);
+  return tsdf_.NumActiveBlock();
+}
+
+size_t TSDFSystem::frames_integrated() {
+  std::lock_guard<std::mutex> lock(mtx_queue_);
+  return frames_done_;
+}
+
+}  // namespace ratsdf

@@ -1,0 +1,171 @@
+// Exercises the TSDFSystem / TSDFGrid host layer against one ABI library.
+//   usage: test_tsdf_system <library.so> <symbol prefix>
+// Run by tests/test_host_layer.py with the CPU oracle (no GPU) and with the HIP engine (-m gpu).
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "ratsdf/tsdf_system.hpp"
+
+using namespace ratsdf;
+
+#define CHECK(cond)                                                       \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      fprintf(stderr, "CHECK failed at line %d: %s\n", __LINE__, #cond);  \
+      exit(1);                                                            \
+    }                                                                     \
+  } while (0)
+
+struct Frame {
+  std::vector<uint8_t> rgb;
+  std::vector<float> depth, ht, lt;
+  SE3<float> pose;
+};
+
+static const int W = 80, H = 60;
+
+static Frame make_frame(int i) {
+  Frame f;
+  f.rgb.resize((size_t)W * H * 3);
+  f.depth.resize((size_t)W * H);
+  f.ht.resize((size_t)W * H);
+  f.lt.resize((size_t)W * H);
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int k = y * W + x;
+      f.depth[k] = 1.5f + 0.002f * (float)x + 0.001f * (float)i;
+      f.rgb[3 * k] = (uint8_t)(x * 3 + i);
+      f.rgb[3 * k + 1] = (uint8_t)(y * 4);
+      f.rgb[3 * k + 2] = (uint8_t)(x + y);
+      f.ht[k] = 0.2f + 0.6f * (float)x / W;
+      f.lt[k] = 1.f - f.ht[k];
+    }
+  f.pose = SE3<float>(Quaternion<float>{0, 0, 0, 1}, Vector3<float>{0.01f * i, 0, 0});
+  return f;
+}
+
+static Image img(const std::vector<uint8_t>& v) { return Image{v.data(), H, W, kU8C3}; }
+static Image img(const std::vector<float>& v) { return Image{v.data(), H, W, kF32C1}; }
+
+static bool same(const std::vector<VoxelSpatialTSDF>& a, const std::vector<VoxelSpatialTSDF>& b) {
+  return a.size() == b.size() &&
+         (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(VoxelSpatialTSDF)) == 0);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  const Api& api = Api::Load(argv[1], argv[2]);
+  printf("backend: %s\n", api.backend());
+  const float vs = 0.02f, tr = 0.12f, md = 4.f;
+  const CameraIntrinsics<float> K(71.45f, 71.45f, 39.5f, 29.5f);
+  std::vector<Frame> frames;
+  for (int i = 0; i < 5; ++i) frames.push_back(make_frame(i));
+
+  // 1+2: queue order is preserved and the threaded path equals direct TSDFGrid calls
+  TSDFGrid grid(vs, tr, 0, &api);
+  CHECK(grid.last_status() == 0);
+  for (auto& f : frames) grid.Integrate(img(f.rgb), img(f.depth), img(f.ht), img(f.lt), md, K, f.pose);
+  {
+    TSDFSystem sys(vs, tr, md, K, SE3<float>::Identity(), 0, &api);
+    for (auto& f : frames) {
+      Frame copy = f;  // caller buffers may be reused / destroyed right after Integrate returns
+      sys.Integrate(copy.pose, img(copy.rgb), img(copy.depth), img(copy.ht), img(copy.lt));
+      memset(copy.depth.data(), 0, copy.depth.size() * 4);
+    }
+    sys.Flush();
+    CHECK(sys.frames_integrated() == frames.size());
+    CHECK(sys.QueueSize() == 0);
+    CHECK(sys.NumActiveBlock() == grid.NumActiveBlock());
+    CHECK(sys.NumActiveBlock() > 0);
+    const BoundingCube<float> all{-10, 10, -10, 10, -10, 10};
+    CHECK(same(sys.Query(all), grid.GatherVoxels(all)));
+    const BoundingCube<float> part{-0.3f, 0.3f, -0.3f, 0.3f, 1.0f, 2.0f};
+    const auto q = sys.Query(part);
+    CHECK(same(q, grid.GatherVoxels(part)));
+    CHECK(q.size() < grid.GatherValid().size());
+    CHECK(q.size() % 512 == 0);
+
+    // 3: pause blocks the producer
+    sys.SetPause(true);
+    std::atomic<bool> returned{false};
+    std::thread producer([&] {
+      sys.Integrate(frames[0].pose, img(frames[0].rgb), img(frames[0].depth));
+      returned = true;
+    });
+    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    CHECK(!returned.load());
+    CHECK(sys.frames_integrated() == frames.size());
+    sys.SetPause(false);
+    producer.join();
+    sys.Flush();
+    CHECK(returned.load());
+    CHECK(sys.frames_integrated() == frames.size() + 1);
+
+    // 6: terminate twice, frames queued after termination are never integrated
+    CHECK(!sys.is_terminated());
+    sys.terminate();
+    sys.terminate();
+    CHECK(sys.is_terminated());
+    sys.Integrate(frames[1].pose, img(frames[1].rgb), img(frames[1].depth));
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    CHECK(sys.frames_integrated() == frames.size() + 1);
+  }  // destructor after terminate(): must not throw / hang
+
+  // 4: missing ht/lt -> all-ones images -> probability stays exactly 0.5
+  {
+    TSDFSystem sys(vs, tr, md, K, SE3<float>::Identity(), 0, &api);
+    for (auto& f : frames) sys.Integrate(f.pose, img(f.rgb), img(f.depth), Image{}, img(f.lt));
+    sys.Flush();
+    const char* path = "/tmp/ratsdf_host_test_download.bin";
+    sys.DownloadAll(path);
+    FILE* fp = fopen(path, "rb");
+    CHECK(fp != nullptr);
+    fseek(fp, 0, SEEK_END);
+    const long bytes = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    CHECK(bytes > 0 && bytes % (long)sizeof(VoxelSpatialTSDFSEGM) == 0);
+    std::vector<VoxelSpatialTSDFSEGM> rec((size_t)bytes / sizeof(VoxelSpatialTSDFSEGM));
+    CHECK(fread(rec.data(), sizeof(VoxelSpatialTSDFSEGM), rec.size(), fp) == rec.size());
+    fclose(fp);
+    remove(path);
+    CHECK((long)rec.size() == (long)sys.NumActiveBlock() * 512);
+    for (auto& r : rec) CHECK(r.prob == 0.5f);
+  }
+
+  // 7: extrinsics are composed as cam_T_posecam * posecam_T_world
+  {
+    const float c = std::cos(0.1f), s = std::sin(0.1f);
+    const float m[16] = {c, 0, s, 0.05f, 0, 1, 0, -0.02f, -s, 0, c, 0.01f, 0, 0, 0, 1};
+    const SE3<float> E(m);
+    TSDFSystem sys(vs, tr, md, K, E, 0, &api);
+    TSDFGrid ref(vs, tr, 0, &api);
+    for (auto& f : frames) {
+      sys.Integrate(f.pose, img(f.rgb), img(f.depth), img(f.ht), img(f.lt));
+      ref.Integrate(img(f.rgb), img(f.depth), img(f.ht), img(f.lt), md, K, E * f.pose);
+    }
+    sys.Flush();
+    const BoundingCube<float> all{-10, 10, -10, 10, -10, 10};
+    CHECK(same(sys.Query(all), ref.GatherVoxels(all)));
+    // SE3 round trip
+    const SE3<float> I = E * E.Inverse();
+    CHECK(std::fabs(I.GetR().w) > 0.999999f && std::fabs(I.GetT().x) < 1e-6f);
+  }
+
+  // bad arguments are reported, not fatal (the reference only asserts)
+  {
+    TSDFGrid g(vs, tr, 0, &api);
+    std::vector<float> small((size_t)10 * 10, 1.f);
+    g.Integrate(img(frames[0].rgb), Image{small.data(), 10, 10, kF32C1}, Image{}, Image{}, md, K,
+                frames[0].pose);
+    CHECK(g.last_status() == RATSDF_ERR_BAD_ARGUMENT);
+    CHECK(g.NumActiveBlock() == 0);
+  }
+  printf("OK\n");
+  return 0;
+}

@@ -71,3 +71,40 @@ def test_query_and_gather_match(make_engine, make_oracle):
     assert len(sa) == len(sb)
     assert np.max(np.abs(sa["prob"] - sb["prob"]), initial=0) <= 1e-4
     assert np.max(np.abs(sa["tsdf"] - sb["tsdf"]), initial=0) <= 1e-4
+
+
+@pytest.mark.parametrize("world,slab", [(2, 1), (4, 2)])
+def test_sharded_engines_match_sharded_oracle(world, slab, make_engine, make_oracle):
+    """Block-ownership sharding (BASELINE config 4): every shard's map is bit-exact vs the oracle
+    with the same shard parameters, and the shards partition the blocks."""
+    from ratsdf import multi
+    vs = 0.02
+    frames = synthetic.stream("room", 4, scale=0.25)
+    per_rank = []
+    for r in range(world):
+        kw = dict(shard_rank=r, shard_count=world, shard_slab_bits=slab)
+        gpu, cpu = make_engine(vs, 6 * vs, **kw), make_oracle(vs, 6 * vs, **kw)
+        run_both(gpu, cpu, frames)
+        per_rank.append(gpu.dump_directory()[1])
+    assert multi.check_sharded_directories(per_rank, slab) == sum(len(b) for b in per_rank)
+    assert all(len(b) > 0 for b in per_rank)
+
+
+def test_export_directory_device(make_engine):
+    """ratsdf_export_directory_device writes the same compact directory the host dump returns."""
+    import torch
+    from ratsdf._abi import BLOCK_DTYPE
+    vs = 0.02
+    gpu = make_engine(vs, 6 * vs)
+    for f in synthetic.stream("room", 2, scale=0.25):
+        gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+    cap = 4096
+    buf = torch.zeros(cap * 3, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu.export_directory_device(buf.data_ptr(), cap, cnt.data_ptr())
+    gpu.synchronize()
+    _, blocks = gpu.dump_directory()
+    n = int(cnt.item())
+    assert n == len(blocks)
+    got = buf.cpu().numpy()[:n * 3].view(BLOCK_DTYPE)
+    assert np.array_equal(got, blocks)
