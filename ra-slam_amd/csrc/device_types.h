@@ -71,8 +71,22 @@ struct Ctl {
   uint32_t error;         // sticky ratsdf_status
   unsigned long long totals[5];  // frames, sum V, sum U, sum allocated, sum deleted
   uint32_t pad1[4];
+  unsigned long long stamps[32];  // diagnostic build only
 };
 constexpr int kCtlFrameBytes = 64;
+
+// Diagnostic build only (-DRATSDF_STAMPS): thread 0 of the single-workgroup kernels accumulates
+// shader-clock stamps per phase into Ctl-adjacent memory; never compiled into the product library.
+#ifdef RATSDF_STAMPS
+#define RATSDF_STAMP(buf, i)                                            \
+  do {                                                                  \
+    if (threadIdx.x == 0) (buf)[i] += (unsigned long long)clock64();    \
+  } while (0)
+#else
+#define RATSDF_STAMP(buf, i) \
+  do {                       \
+  } while (0)
+#endif
 
 struct Quat {
   float x, y, z, w;
@@ -99,6 +113,7 @@ struct FrameParams {
   int S;        // rank stride: max ray samples per pixel
   int has_sem;
   int shard_rank, shard_count, shard_slab_bits;
+  int debug;    // diagnostic switches (0 in production)
 };
 
 struct Table {

@@ -166,6 +166,7 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
   }
   V3 p = sg;
   uint32_t prev0 = kInf, prev1 = kInf;  // this lane's previous sample
+  if (P.debug == 1) return;
   for (int i = 0; i < P.S; ++i) {       // uniform trip count: the shuffles below need every lane
     const bool act = valid && i <= steps;
     const int gx = (int16_t)f2i(roundf(p.x)), gy = (int16_t)f2i(roundf(p.y)),
@@ -177,7 +178,7 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
     // on a lock that stays taken), so drop repeats of the previous sample / the previous pixel.
     const uint32_t n0 = __shfl_up(k0, 1), n1 = __shfl_up(k1, 1);
     const bool dup = (k0 == prev0 && k1 == prev1) || (lane > 0 && k0 == n0 && k1 == n1);
-    if (act && !dup && shard_owned(bx, P)) {
+    if (act && !dup && shard_owned(bx, P) && P.debug != 2) {
       // lookup first (cheap, usually a hit), the 8-corner frustum test only for absent blocks
       // (both are pure predicates; the reference tests visibility first, :165-166)
       EntryWords w;
@@ -345,45 +346,81 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
   }
 }
 
-// Exclusive scan of one value per thread across the workgroup (Hillis-Steele in LDS).
-// Returns the exclusive prefix; *total receives the workgroup sum.  lds: blockDim.x words.
+// Exclusive scan of one value per thread across the workgroup: wave-level scan with cross-lane
+// shuffles, then the (<= 16) wave totals through LDS.  Returns the exclusive prefix; *total receives
+// the workgroup sum.  lds: at least blockDim.x / 64 words.  Two barriers.
 __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  __syncthreads();  // lds may still be in use by a previous scan
-  lds[tid] = v;
-  __syncthreads();
-  for (uint32_t d = 1; d < nt; d <<= 1) {
-    const uint32_t t = tid >= d ? lds[tid - d] : 0;
-    __syncthreads();
-    lds[tid] += t;
-    __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(x, o);
+    if (lane >= (uint32_t)o) x += t;
   }
-  *total = lds[nt - 1];
-  return lds[tid] - v;
+  __syncthreads();  // lds may still be in use by a previous scan
+  if (lane == 63) lds[wave] = x;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t i = 0; i < nw; ++i) {
+    const uint32_t w = lds[i];
+    if (i < wave) base += w;
+    tot += w;
+  }
+  *total = tot;
+  return base + x - v;
 }
 
-// Words per thread-chunk of a bitmap scanned by `nt` threads (multiple of 4 for 16-byte loads).
+// Rank bitmaps are organised in groups of 32 words (1024 bits) with a summary bitmap (one bit per
+// group) so that scans and clean-ups only touch groups that contain set bits.
+constexpr uint32_t kGroupWords = 32;
+
+// Words per thread-chunk when `nt` threads scan a bitmap of `nwords` words (whole groups).
 __host__ __device__ inline uint32_t bitmap_chunk(uint32_t nwords, uint32_t nt) {
-  uint32_t c = (nwords + nt - 1) / nt;
-  c = (c + 3u) & ~3u;
-  return c ? c : 4u;
+  const uint32_t ngroups = (nwords + kGroupWords - 1) / kGroupWords;
+  uint32_t gpt = (ngroups + nt - 1) / nt;
+  if (gpt == 0) gpt = 1;
+  return gpt * kGroupWords;
 }
 
-// Popcount of this thread's chunk of a bitmap.  The bits were set with atomics earlier in the same
-// kernel by this workgroup; the words have not been read before in this kernel (and the vector L1
-// is invalidated at kernel start), so plain loads after the barrier fetch them from L2.
-__device__ inline uint32_t chunk_popcount(const uint32_t* bitmap, uint32_t nwords, uint32_t chunk) {
+__device__ inline void bitmap_set(uint32_t* bitmap, uint32_t* summary, uint32_t pos) {
+  const uint32_t w = pos >> 5;
+  atomicOr(&bitmap[w], 1u << (pos & 31));
+  const uint32_t g = w / kGroupWords;
+  atomicOr(&summary[g >> 5], 1u << (g & 31));
+}
+
+// Popcount of this thread's chunk, skipping groups whose summary bit is clear.  The bits were set
+// with atomics earlier in the same kernel by this workgroup; neither the summary nor the bitmap
+// words have been read before in this kernel (and the vector L1 is invalidated at kernel start), so
+// plain loads after the barrier fetch them from L2.  `bitmap` must be padded to whole groups.
+__device__ inline uint32_t chunk_popcount(const uint32_t* bitmap, const uint32_t* summary,
+                                          uint32_t nwords, uint32_t chunk) {
   const uint32_t lo = threadIdx.x * chunk;
   uint32_t sum = 0;
-  for (uint32_t w = lo; w < lo + chunk && w < nwords; w += 4) {
-    if (w + 4 <= nwords) {
-      const uint4 v = *reinterpret_cast<const uint4*>(bitmap + w);
-      sum += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-    } else {
-      for (uint32_t k = w; k < nwords; ++k) sum += __popc(bitmap[k]);
-    }
+  for (uint32_t w = lo; w < lo + chunk && w < nwords; w += kGroupWords) {
+    const uint32_t g = w / kGroupWords;
+    if (!((summary[g >> 5] >> (g & 31)) & 1u)) continue;
+    const uint4* p = reinterpret_cast<const uint4*>(bitmap + w);
+    uint4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += __popc(v[i].x) + __popc(v[i].y) + __popc(v[i].z) + __popc(v[i].w);
   }
   return sum;
+}
+
+// Zero every group of `bitmap` whose summary bit is set, then the summary itself (whole workgroup).
+__device__ inline void bitmap_clean(uint32_t* bitmap, uint32_t* summary, uint32_t nwords) {
+  const uint32_t ngroups = (nwords + kGroupWords - 1) / kGroupWords;
+  for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
+    if (!((summary[g >> 5] >> (g & 31)) & 1u)) continue;
+    uint4* p = reinterpret_cast<uint4*>(bitmap + g * kGroupWords);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < (ngroups + 31) / 32; i += blockDim.x) summary[i] = 0;
 }
 
 // rank of bit `pos` among the set bits of the bitmap, given the per-chunk exclusive prefix
@@ -398,22 +435,25 @@ __device__ inline uint32_t bitmap_rank(const uint32_t* bitmap, const uint32_t* c
 
 // ---------------------------------------------------------------------------------------------
 // k_alloc_rank: one workgroup.  resolve -> mark winners -> rank scan -> free-list bookkeeping.
-// Also cleans the other (next pass's) rank bitmap.
+// Also cleans the other (previous pass's) rank bitmap, group by group, for the next pass.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, uint32_t req_cap,
                                                      const SlowRequest* slow, uint32_t slow_cap,
                                                      XLock* xlocks, SlowRequest* distinct,
-                                                     uint32_t* bitmap, uint32_t* chunk_prefix,
-                                                     uint32_t nwords, uint32_t* next_bitmap,
-                                                     uint32_t next_words, Ctl* ctl) {
+                                                     uint32_t* bitmap, uint32_t* summary,
+                                                     uint32_t* chunk_prefix, uint32_t nwords,
+                                                     uint32_t* next_bitmap, uint32_t* next_summary,
+                                                     Ctl* ctl) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
   uint32_t* lds = reinterpret_cast<uint32_t*>(skeys);
+  RATSDF_STAMP(ctl->stamps, 8);
   if (ctl->n_slow != 0) {  // uniform
     resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, distinct, ctl, skeys);
     __syncthreads();
   }
   uint32_t n = ctl->n_req;
   if (n > req_cap) n = req_cap;
+  RATSDF_STAMP(ctl->stamps, 12);
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const Request r = req[i];
     bool win = (r.flags & kReqWinner) != 0;
@@ -422,15 +462,17 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, ui
       win = tab.claim[bucket] == r.rank;
       if (win) req[i].flags = kReqWinner;
     }
-    if (win) atomicOr(&bitmap[r.rank >> 5], 1u << (r.rank & 31));
+    if (win) bitmap_set(bitmap, summary, r.rank);
   }
   __syncthreads();
+  RATSDF_STAMP(ctl->stamps, 9);
   const uint32_t chunk = bitmap_chunk(nwords, blockDim.x);
-  const uint32_t sum = chunk_popcount(bitmap, nwords, chunk);
+  const uint32_t sum = chunk_popcount(bitmap, summary, nwords, chunk);
   uint32_t total = 0;
   const uint32_t excl = block_exclusive_scan(sum, lds, &total);
   chunk_prefix[threadIdx.x] = excl;
-  for (uint32_t w = threadIdx.x; w < next_words; w += blockDim.x) next_bitmap[w] = 0;
+  RATSDF_STAMP(ctl->stamps, 10);
+  bitmap_clean(next_bitmap, next_summary, nwords);
   if (threadIdx.x == 0) {
     const int32_t nf = ctl->num_free;
     uint32_t take = total;
@@ -443,6 +485,7 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, ui
     ctl->rank_chunk = chunk;
     ctl->num_free = nf - (int32_t)take;
   }
+  RATSDF_STAMP(ctl->stamps, 11);
 }
 
 // One wave per request.  Winner k (in rank order) takes heap[alloc_base - 1 - k]

@@ -221,13 +221,14 @@ __device__ inline uint32_t ld_agent(const uint32_t* p) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisItem* vis,
                                                 const uint32_t* blk_info, uint32_t* bitmap,
-                                                uint32_t* next_bitmap, uint32_t next_words,
-                                                int32_t* del_idx, SlowDelete* slow,
+                                                uint32_t* summary, int32_t* del_idx,
+                                                SlowDelete* slow,
                                                 uint32_t slow_cap, Ctl* ctl,
                                                 ratsdf_frame_stats* stats) {
-  __shared__ uint32_t lds[1024];
+  __shared__ uint32_t lds[32];
   __shared__ uint32_t cprefix[1024];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  RATSDF_STAMP(ctl->stamps, 0);
   const uint32_t nv = ctl->n_vis;
   uint32_t upd_part = 0;
   for (uint32_t i = tid; i < nv; i += nt) {
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
       pe[2] = (uint32_t)-1;
       occ_clear(tab, it.entry);
       del_idx[i] = it.idx;
-      atomicOr(&bitmap[i >> 5], 1u << (i & 31));
+      bitmap_set(bitmap, summary, i);
     } else {
       atomicMin(&tab.claim[bucket], i);
       const uint32_t slot = atomicAdd(&ctl->n_slow_del, 1u);
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
     }
   }
   __syncthreads();
+  RATSDF_STAMP(ctl->stamps, 1);
   uint32_t ns = ld_agent(&ctl->n_slow_del);
   if (ns > slow_cap) ns = slow_cap;
   if (ns) {  // uniform
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
         pn[1] = pn[1] & 0xFFFFu;
         pn[2] = (uint32_t)-1;
         occ_clear(tab, nxt);  // the head keeps its bit unless it was its own successor
-        atomicOr(&bitmap[s.vis >> 5], 1u << (s.vis & 31));
+        bitmap_set(bitmap, summary, s.vis);
       } else {                                                            // voxel_hash.cu:142-158
         for (uint32_t g = 0; g < tab.num_entry; ++g) {
           const EntryWords lw = load_entry(tab.entries, last);
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
             pcur[1] = pcur[1] & 0xFFFFu;
             pcur[2] = (uint32_t)-1;
             occ_clear(tab, cur);
-            atomicOr(&bitmap[s.vis >> 5], 1u << (s.vis & 31));
+            bitmap_set(bitmap, summary, s.vis);
             break;
           }
           last = cur;
@@ -314,14 +316,16 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
     }
     __syncthreads();
   }
+  RATSDF_STAMP(ctl->stamps, 2);
   uint32_t upd = 0;
   (void)block_exclusive_scan(upd_part, lds, &upd);
   const uint32_t nwords = (nv + 31) >> 5;
   const uint32_t chunk = bitmap_chunk(nwords, nt);
-  const uint32_t sum = chunk_popcount(bitmap, nwords, chunk);
+  const uint32_t sum = chunk_popcount(bitmap, summary, nwords, chunk);
   uint32_t total = 0;
   cprefix[tid] = block_exclusive_scan(sum, lds, &total);
   __syncthreads();
+  RATSDF_STAMP(ctl->stamps, 3);
   const int32_t nf = ctl->num_free;
   if (total) {  // uniform
     for (uint32_t i = tid; i < nv; i += nt) {
@@ -330,8 +334,10 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
       pool.heap[(uint32_t)nf + k] = del_idx[i];                           // voxel_mem.cu:56-60
     }
   }
-  for (uint32_t w = tid; w < next_words; w += nt) next_bitmap[w] = 0;
-  __syncthreads();
+  __syncthreads();  // every reader of the delete bitmap is done: leave it clean for the next pass
+  RATSDF_STAMP(ctl->stamps, 4);
+  bitmap_clean(bitmap, summary, nwords);
+  RATSDF_STAMP(ctl->stamps, 5);
   if (tid == 0) {
     ctl->num_free = nf + (int32_t)total;
     if (stats) {
@@ -351,6 +357,7 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
     uint32_t* z = reinterpret_cast<uint32_t*>(ctl);
     for (int i = 0; i < kCtlFrameBytes / 4; ++i) z[i] = 0;
   }
+  RATSDF_STAMP(ctl->stamps, 6);
 }
 
 }  // namespace ratsdf

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_front(Table tab, FrameParams P, uint32_
   if (blockIdx.x < n_pix_wg) {
     alloc_pixels_role(tab, P, blockIdx.x, depth, rgb, ht, lt, texA, texB, req, req_cap, slow,
                       slow_cap, ctl);
-  } else {
+  } else if (P.debug != 3) {
     select_flags_role<kSelVisible>(tab, P, GridBounds{}, blockIdx.x - n_pix_wg, vismask,
                                    vis_wg_count);
   }
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kVisWG) void k_select_scatter(Table tab,
                                                            const unsigned long long* masks,
                                                            const uint32_t* wg_count, VisItem* out,
                                                            uint32_t out_cap, uint32_t* total_out) {
-  __shared__ uint32_t lds[kVisWG];
+  __shared__ uint32_t lds[32];
   const uint32_t wg = blockIdx.x, tid = threadIdx.x;
   uint32_t before = 0;
   for (uint32_t j = tid; j < wg; j += kVisWG) before += wg_count[j];

@@ -54,6 +54,7 @@ struct ratsdf_engine {
   int shard_rank = 0, shard_count = 1, shard_slab_bits = 2;
   int S = 3;
   int vpl = kDefaultVPL;
+  int debug = 0;
   unsigned integrate_grid = 2048;
 
   Table tab{};
@@ -67,9 +68,10 @@ struct ratsdf_engine {
   uint2* texB = nullptr;
   Request* req = nullptr;
   uint32_t req_cap = 0;
-  uint32_t* abitmap[2] = {nullptr, nullptr};
+  uint32_t* abitmap[2] = {nullptr, nullptr};   // rank bitmaps (padded to whole 32-word groups)
+  uint32_t* asummary[2] = {nullptr, nullptr};  // one bit per group
   uint32_t* chunk_prefix = nullptr;  // 1024 words
-  uint32_t awords_cap = 0;
+  uint32_t awords_cap = 0, asum_words = 0;
   int apass = 0;
 
   SlowRequest* slow = nullptr;
@@ -82,9 +84,9 @@ struct ratsdf_engine {
   uint32_t nwg = 0;
   VisItem* vis = nullptr;
   uint32_t* carve_flag = nullptr;  // per visible block: bit 31 carve candidate | voxels updated
-  uint32_t* dbitmap[2] = {nullptr, nullptr};
+  uint32_t* dbitmap = nullptr;   // delete bitmap over the visible list (self-cleaning)
+  uint32_t* dsummary = nullptr;
   uint32_t dwords = 0;
-  int dpass = 0;
   int32_t* del_idx = nullptr;
   SlowDelete* slowdel = nullptr;
 
@@ -129,14 +131,16 @@ FrameParams ratsdf_engine::base_params() const {
   P.shard_rank = shard_rank;
   P.shard_count = shard_count;
   P.shard_slab_bits = shard_slab_bits;
+  P.debug = debug;
   return P;
 }
 
 int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
   void* ptrs[] = {tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
-                  d_stats, texA, texB, req, abitmap[0], abitmap[1], chunk_prefix, slow, xlocks,
-                  distinct, masks, wg_count, vis, carve_flag, dbitmap[0], dbitmap[1], del_idx,
+                  d_stats, texA, texB, req, abitmap[0], abitmap[1], asummary[0], asummary[1], chunk_prefix,
+                  slow, xlocks,
+                  distinct, masks, wg_count, vis, carve_flag, dbitmap, dsummary, del_idx,
                   slowdel, d_stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -163,11 +167,17 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
     if (req) (void)hipFree(req);
     if (abitmap[0]) (void)hipFree(abitmap[0]);
     if (abitmap[1]) (void)hipFree(abitmap[1]);
+    if (asummary[0]) (void)hipFree(asummary[0]);
+    if (asummary[1]) (void)hipFree(asummary[1]);
     req_cap = (uint32_t)nranks;
     awords_cap = (uint32_t)((nranks + 31) / 32);
+    awords_cap = (awords_cap + kGroupWords - 1) / kGroupWords * kGroupWords;
+    asum_words = (awords_cap / kGroupWords + 31) / 32;
     HIPCHK(hipMalloc(&req, (size_t)req_cap * sizeof(Request)));
     HIPCHK(hipMalloc(&abitmap[0], (size_t)awords_cap * 4));
     HIPCHK(hipMalloc(&abitmap[1], (size_t)awords_cap * 4));
+    HIPCHK(hipMalloc(&asummary[0], (size_t)asum_words * 4));
+    HIPCHK(hipMalloc(&asummary[1], (size_t)asum_words * 4));
     rank_cap = nranks;
   }
   // Each pass's scan kernel cleans the other bitmap only over the current rank space, so both must
@@ -175,6 +185,8 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
   if (nranks != cur_nranks) {
     HIPCHK(hipMemsetAsync(abitmap[0], 0, (size_t)awords_cap * 4, stream));
     HIPCHK(hipMemsetAsync(abitmap[1], 0, (size_t)awords_cap * 4, stream));
+    HIPCHK(hipMemsetAsync(asummary[0], 0, (size_t)asum_words * 4, stream));
+    HIPCHK(hipMemsetAsync(asummary[1], 0, (size_t)asum_words * 4, stream));
     cur_nranks = nranks;
   }
   return RATSDF_OK;
@@ -200,8 +212,9 @@ int ratsdf_engine::alloc_tail(uint32_t nranks, bool is_frame) {
   uint32_t* bm = abitmap[apass & 1];
   uint32_t* bm_next = abitmap[(apass + 1) & 1];
   hipLaunchKernelGGL(k_alloc_rank, dim3(1), dim3(1024), kSlowSortCap * sizeof(unsigned long long),
-                     stream, tab, req, req_cap, slow, kSlowCap, xlocks, distinct, bm, chunk_prefix,
-                     nwords, bm_next, nwords, ctl);
+                     stream, tab, req, req_cap, slow, kSlowCap, xlocks, distinct, bm,
+                     asummary[apass & 1], chunk_prefix, nwords, bm_next, asummary[(apass + 1) & 1],
+                     ctl);
   hipLaunchKernelGGL(k_alloc_commit, dim3(256), dim3(256), 0, stream, tab, pool, req, req_cap, bm,
                      chunk_prefix, is_frame ? masks : (unsigned long long*)nullptr, wg_count, ctl);
   ++apass;
@@ -210,12 +223,9 @@ int ratsdf_engine::alloc_tail(uint32_t nranks, bool is_frame) {
 }
 
 int ratsdf_engine::carve_tail(bool is_frame) {
-  uint32_t* bm = dbitmap[dpass & 1];
-  uint32_t* bm_next = dbitmap[(dpass + 1) & 1];
-  hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, stream, tab, pool, vis, carve_flag, bm, bm_next,
-                     dwords, del_idx, slowdel, kSlowDelCap, ctl,
+  hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, stream, tab, pool, vis, carve_flag, dbitmap,
+                     dsummary, del_idx, slowdel, kSlowDelCap, ctl,
                      is_frame ? d_stats : (ratsdf_frame_stats*)nullptr);
-  ++dpass;
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
@@ -347,6 +357,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     const int x = atoi(v);
     if (x == 2 || x == 4 || x == 8) e->vpl = x;
   }
+  if (const char* v = getenv("RATSDF_DEBUG")) e->debug = atoi(v);
   if (const char* v = getenv("RATSDF_GRID")) {
     const int x = atoi(v);
     if (x >= 64 && x <= 65536) e->integrate_grid = (unsigned)x;
@@ -390,8 +401,10 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->wg_count, (size_t)e->nwg * 4));
   CREATE_CHK(hipMalloc(&e->vis, (size_t)t.num_block * sizeof(VisItem)));
   CREATE_CHK(hipMalloc(&e->carve_flag, (size_t)t.num_block * 4));
-  CREATE_CHK(hipMalloc(&e->dbitmap[0], (size_t)e->dwords * 4));
-  CREATE_CHK(hipMalloc(&e->dbitmap[1], (size_t)e->dwords * 4));
+  e->dwords = (e->dwords + kGroupWords - 1) / kGroupWords * kGroupWords;
+  const uint32_t dsum_words = (e->dwords / kGroupWords + 31) / 32;
+  CREATE_CHK(hipMalloc(&e->dbitmap, (size_t)e->dwords * 4));
+  CREATE_CHK(hipMalloc(&e->dsummary, (size_t)dsum_words * 4));
   CREATE_CHK(hipMalloc(&e->del_idx, (size_t)t.num_block * 4));
   CREATE_CHK(hipMalloc(&e->slowdel, (size_t)kSlowDelCap * sizeof(SlowDelete)));
   // voxel memory starts zeroed (defined value for the reference's uninitialised rgb)
@@ -400,8 +413,8 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMemsetAsync(e->pool.segm, 0, nvox * 4, e->stream));
   CREATE_CHK(hipMemsetAsync(e->ctl, 0, sizeof(Ctl), e->stream));
   CREATE_CHK(hipMemsetAsync(e->d_stats, 0, sizeof(ratsdf_frame_stats), e->stream));
-  CREATE_CHK(hipMemsetAsync(e->dbitmap[0], 0, (size_t)e->dwords * 4, e->stream));
-  CREATE_CHK(hipMemsetAsync(e->dbitmap[1], 0, (size_t)e->dwords * 4, e->stream));
+  CREATE_CHK(hipMemsetAsync(e->dbitmap, 0, (size_t)e->dwords * 4, e->stream));
+  CREATE_CHK(hipMemsetAsync(e->dsummary, 0, (size_t)dsum_words * 4, e->stream));
   hipLaunchKernelGGL(k_init_table, dim3((t.num_entry + 255) / 256), dim3(256), 0, e->stream,
                      t.entries, t.claim, t.occ, t.num_entry, t.num_bucket);
   hipLaunchKernelGGL(k_init_heap, dim3((t.num_block + 255) / 256), dim3(256), 0, e->stream,
@@ -510,6 +523,22 @@ int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   HIPCHK(hipMemcpyAsync(out, e->d_stats, sizeof(*out), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  return RATSDF_OK;
+}
+
+// diagnostic: prints the accumulated phase stamps of the single-workgroup kernels (stamps build only)
+extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
+  unsigned long long t[32];
+  unsigned long long tot[5];
+  HIPCHK(hipMemcpyAsync(t, e->ctl->stamps, sizeof(t), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(tot, e->ctl->totals, sizeof(tot), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const double n = tot[0] ? (double)tot[0] : 1.0;
+  fprintf(stderr, "[stamps] frames=%llu  carve phases (cycles/frame):", tot[0]);
+  for (int i = 1; i <= 6; ++i) fprintf(stderr, " %d:%.0f", i, (double)(t[i] - t[i - 1]) / n);
+  fprintf(stderr, "\n[stamps] rank phases: read_n:%.0f mark:%.0f scan:%.0f tail:%.0f\n",
+          (double)(t[12] - t[8]) / n, (double)(t[9] - t[12]) / n, (double)(t[10] - t[9]) / n,
+          (double)(t[11] - t[10]) / n);
   return RATSDF_OK;
 }
 
