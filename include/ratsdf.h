@@ -189,8 +189,10 @@ int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t cap
  * raster rank i, followed by ResetLocks: the Allocate<<<>>> kernel + ResetLocks of
  * utils/tests/voxel_hash_test.cu:36-39,98-99,140-141. */
 int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* block_pos, int32_t n);
-/* One carve pass that requests deletion of the listed blocks, processed in list order, then
- * ResetLocks: VoxelHashTable::Delete, voxel_hash.cu:110-159. */
+/* One carve pass that requests deletion of the listed blocks: like space carving, the blocks are
+ * looked up first and then deleted in ascending hash-entry order (the order of the reference's
+ * visible list, voxel_tsdf.cu:847-867), followed by ResetLocks: VoxelHashTable::Delete,
+ * voxel_hash.cu:110-159. */
 int ratsdf_test_delete(ratsdf_engine* e, const int16_t* block_pos, int32_t n);
 /* VoxelHashTable::Retrieve<Voxel>(point, cache) with a fresh cache per point,
  * voxel_hash.cuh:104-143; voxel_hash_test.cu:41-45.  points = 3 x int16 voxel coordinates.

@@ -36,6 +36,7 @@
 //
 // Build: see oracle/Makefile (g++ -O2 -ffp-contract=off, no fast-math).
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -754,7 +755,30 @@ int ratsdf_oracle_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) 
 
 int ratsdf_oracle_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   if (!e || (!bp && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
-  for (int i = 0; i < n; ++i) e->erase(S3{bp[3 * i], bp[3 * i + 1], bp[3 * i + 2]});
+  // A carve pass works on a list built BEFORE any deletion and ordered by hash entry
+  // (GatherBlock, voxel_tsdf.cu:847-867): look every block up first, then delete in that order.
+  std::vector<std::pair<uint32_t, S3>> order;
+  for (int i = 0; i < n; ++i) {
+    const S3 p{bp[3 * i], bp[3 * i + 1], bp[3 * i + 2]};
+    const uint32_t e0 = e->hash(p) << 1;
+    uint32_t found = 0xFFFFFFFFu;
+    for (int k = 0; k < 2 && found == 0xFFFFFFFFu; ++k)
+      if (e->table[e0 + k].pos == p && e->table[e0 + k].idx >= 0) found = e0 + k;
+    uint32_t last = e0 + 1;
+    while (found == 0xFFFFFFFFu && e->table[last].offset) {
+      last = (last + e->table[last].offset) & e->entry_mask;
+      if (e->table[last].pos == p && e->table[last].idx >= 0) found = last;
+    }
+    if (found == 0xFFFFFFFFu) continue;
+    bool dup = false;
+    for (auto& o : order) dup = dup || o.first == found;
+    if (!dup) order.emplace_back(found, p);
+  }
+  std::sort(order.begin(), order.end(),
+            [](const std::pair<uint32_t, S3>& a, const std::pair<uint32_t, S3>& b) {
+              return a.first < b.first;
+            });
+  for (auto& o : order) e->erase(o.second);
   e->reset_locks();
   return e->sticky;
 }

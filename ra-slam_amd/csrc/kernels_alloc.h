@@ -16,8 +16,8 @@
 //                      defeat later claims exactly as the sequential code would; (b) winners
 //                      (claim == own rank) set their bit in a rank-indexed bitmap; (c) popcount
 //                      prefix of the bitmap = order of the AquireBlock calls
-//   k_alloc_commit     one wave per winner: pool index heap[free-1-k], directory entry, occupancy /
-//                      visibility bits, block init
+//   commit_request     (inside k_integrate, or k_commit_only for the test hook) one wave per winner:
+//                      pool index heap[free-1-k], directory entry, occupancy bit
 #pragma once
 #include "device_math.h"
 
@@ -110,6 +110,49 @@ __device__ inline void alloc_request(const Table& t, int x, int y, int z, uint32
   }
 }
 
+// Presence test with the two home entries already loaded (chain walk only when the head links on).
+__device__ inline bool block_present_pre(const Table& t, uint32_t k0, uint32_t k1, uint32_t e0,
+                                         const EntryWords& a, const EntryWords& b) {
+  if (entry_matches(a, k0, k1) || entry_matches(b, k0, k1)) return true;
+  uint32_t last = e0 + 1;
+  int off = entry_offset(b);
+  uint32_t guard = 0;
+  while (off && guard++ < t.num_entry) {
+    last = (last + (uint32_t)off) & t.entry_mask;
+    const EntryWords w = load_entry(t.entries, last);
+    if (entry_matches(w, k0, k1)) return true;
+    off = entry_offset(w);
+  }
+  return false;
+}
+
+// alloc_request for a block already known to be absent, home entries already loaded.
+__device__ inline void alloc_request_absent(const Table& t, int x, int y, int z, uint32_t rank,
+                                            const EntryWords& a, const EntryWords& b, Request* req,
+                                            uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap,
+                                            Ctl* ctl) {
+  const uint32_t bucket = block_hash(x, y, z, t.bucket_mask);
+  const bool special = (a.idx >= 0 && b.idx >= 0) || entry_offset(b) != 0;
+  if (!special) {
+    const uint32_t old = atomicMin(&t.claim[bucket], rank);
+    if (rank < old) {
+      const uint32_t slot = atomicAdd(&ctl->n_req, 1u);
+      if (slot < req_cap) {
+        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, 0};
+      } else {
+        set_error(ctl, RATSDF_ERR_CAPACITY);
+      }
+    }
+  } else {
+    const uint32_t slot = atomicAdd(&ctl->n_slow, 1u);
+    if (slot < slow_cap) {
+      slow[slot] = SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank};
+    } else {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // alloc_pixels_role: block_allocate_kernel, voxel_tsdf.cu:120-168.  One lane per pixel, 64 consecutive
 // pixels of a row per wave (coalesced depth / ht / lt reads).  Also writes the packed per-pixel
@@ -167,6 +210,62 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
   V3 p = sg;
   uint32_t prev0 = kInf, prev1 = kInf;  // this lane's previous sample
   if (P.debug == 1) return;
+  if (P.S <= 4) {
+    // Batched form (S = 3 for truncation = 6 voxels): derive all candidate blocks first, then put
+    // every directory lookup of the lane in flight at once, then evaluate.  Same requests, same
+    // ranks as the sequential form below; only the memory latency overlaps.
+    int bxs[4], bys[4], bzs[4];
+    bool need[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      need[i] = false;
+      bxs[i] = bys[i] = bzs[i] = 0;
+      if (i < P.S) {  // uniform
+        const bool act = valid && i <= steps;
+        const int gx = (int16_t)f2i(roundf(p.x)), gy = (int16_t)f2i(roundf(p.y)),
+                  gz = (int16_t)f2i(roundf(p.z));                         // :163-164
+        const int bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
+        const uint32_t k0 = act ? key0(bx, by) : kInf;
+        const uint32_t k1 = act ? key1(bz) : kInf;
+        const uint32_t n0 = __shfl_up(k0, 1), n1 = __shfl_up(k1, 1);
+        const bool dup = (k0 == prev0 && k1 == prev1) || (lane > 0 && k0 == n0 && k1 == n1);
+        need[i] = act && !dup && shard_owned(bx, P) && P.debug != 2;
+        bxs[i] = bx;
+        bys[i] = by;
+        bzs[i] = bz;
+        if (act) {
+          prev0 = k0;
+          prev1 = k1;
+        }
+        p.x += st.x;
+        p.y += st.y;
+        p.z += st.z;
+      }
+    }
+    EntryWords ea[4], eb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ea[i] = EntryWords{0, 0, -1};
+      eb[i] = EntryWords{0, 0, -1};
+      if (need[i]) {
+        const uint32_t e0 = block_hash(bxs[i], bys[i], bzs[i], tab.bucket_mask) << 1;
+        ea[i] = load_entry(tab.entries, e0);
+        eb[i] = load_entry(tab.entries, e0 + 1);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!need[i]) continue;
+      const uint32_t e0 = block_hash(bxs[i], bys[i], bzs[i], tab.bucket_mask) << 1;
+      // lookup first (cheap, usually a hit), the 8-corner frustum test only for absent blocks
+      // (both are pure predicates; the reference tests visibility first, :165-166)
+      if (block_present_pre(tab, key0(bxs[i], bys[i]), key1(bzs[i]), e0, ea[i], eb[i])) continue;
+      if (!block_visible<true>(bxs[i], bys[i], bzs[i], P)) continue;
+      alloc_request_absent(tab, bxs[i], bys[i], bzs[i], (uint32_t)pix * (uint32_t)P.S + (uint32_t)i,
+                           ea[i], eb[i], req, req_cap, slow, slow_cap, ctl);
+    }
+    return;
+  }
   for (int i = 0; i < P.S; ++i) {       // uniform trip count: the shuffles below need every lane
     const bool act = valid && i <= steps;
     const int gx = (int16_t)f2i(roundf(p.x)), gy = (int16_t)f2i(roundf(p.y)),
@@ -179,8 +278,6 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
     const uint32_t n0 = __shfl_up(k0, 1), n1 = __shfl_up(k1, 1);
     const bool dup = (k0 == prev0 && k1 == prev1) || (lane > 0 && k0 == n0 && k1 == n1);
     if (act && !dup && shard_owned(bx, P) && P.debug != 2) {
-      // lookup first (cheap, usually a hit), the 8-corner frustum test only for absent blocks
-      // (both are pure predicates; the reference tests visibility first, :165-166)
       EntryWords w;
       if (find_block(tab, bx, by, bz, &w) == kInf && block_visible<true>(bx, by, bz, P)) {
         alloc_request(tab, bx, by, bz, (uint32_t)pix * (uint32_t)P.S + (uint32_t)i, req, req_cap,
@@ -423,14 +520,36 @@ __device__ inline void bitmap_clean(uint32_t* bitmap, uint32_t* summary, uint32_
   for (uint32_t i = threadIdx.x; i < (ngroups + 31) / 32; i += blockDim.x) summary[i] = 0;
 }
 
-// rank of bit `pos` among the set bits of the bitmap, given the per-chunk exclusive prefix
-__device__ inline uint32_t bitmap_rank(const uint32_t* bitmap, const uint32_t* chunk_prefix,
-                                       uint32_t chunk, uint32_t pos) {
+// Per-word exclusive prefix, written only for groups that contain set bits (the only ones anyone
+// looks up): `excl` = number of set bits before this thread's chunk, `sum` = set bits inside it.
+__device__ inline void bitmap_write_prefix(const uint32_t* bitmap, const uint32_t* summary,
+                                           uint32_t* prefix, uint32_t nwords, uint32_t chunk,
+                                           uint32_t sum, uint32_t excl) {
+  if (!sum) return;
+  const uint32_t lo = threadIdx.x * chunk;
+  uint32_t run = excl;
+  for (uint32_t w = lo; w < lo + chunk && w < nwords; w += kGroupWords) {
+    const uint32_t g = w / kGroupWords;
+    if (!((summary[g >> 5] >> (g & 31)) & 1u)) continue;
+    const uint4* p = reinterpret_cast<const uint4*>(bitmap + w);
+    uint4* q = reinterpret_cast<uint4*>(prefix + w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint4 v = p[i];
+      uint4 o;
+      o.x = run; run += __popc(v.x);
+      o.y = run; run += __popc(v.y);
+      o.z = run; run += __popc(v.z);
+      o.w = run; run += __popc(v.w);
+      q[i] = o;
+    }
+  }
+}
+
+// rank of set bit `pos` among the set bits (prefix written by bitmap_write_prefix)
+__device__ inline uint32_t bitmap_rank(const uint32_t* bitmap, const uint32_t* prefix, uint32_t pos) {
   const uint32_t w = pos >> 5;
-  const uint32_t c = w / chunk;
-  uint32_t k = chunk_prefix[c];
-  for (uint32_t i = c * chunk; i < w; ++i) k += __popc(bitmap[i]);
-  return k + __popc(bitmap[w] & ((1u << (pos & 31)) - 1u));
+  return prefix[w] + __popc(bitmap[w] & ((1u << (pos & 31)) - 1u));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,7 +560,7 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, ui
                                                      const SlowRequest* slow, uint32_t slow_cap,
                                                      XLock* xlocks, SlowRequest* distinct,
                                                      uint32_t* bitmap, uint32_t* summary,
-                                                     uint32_t* chunk_prefix, uint32_t nwords,
+                                                     uint32_t* prefix, uint32_t nwords,
                                                      uint32_t* next_bitmap, uint32_t* next_summary,
                                                      Ctl* ctl) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
@@ -470,7 +589,7 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, ui
   const uint32_t sum = chunk_popcount(bitmap, summary, nwords, chunk);
   uint32_t total = 0;
   const uint32_t excl = block_exclusive_scan(sum, lds, &total);
-  chunk_prefix[threadIdx.x] = excl;
+  bitmap_write_prefix(bitmap, summary, prefix, nwords, chunk, sum, excl);
   RATSDF_STAMP(ctl->stamps, 10);
   bitmap_clean(next_bitmap, next_summary, nwords);
   if (threadIdx.x == 0) {
@@ -482,74 +601,72 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, ui
     }
     ctl->alloc_base = (uint32_t)nf;
     ctl->n_win = take;
-    ctl->rank_chunk = chunk;
     ctl->num_free = nf - (int32_t)take;
   }
   RATSDF_STAMP(ctl->stamps, 11);
 }
 
-// One wave per request.  Winner k (in rank order) takes heap[alloc_base - 1 - k]
-// (AquireBlock, voxel_mem.cu:37-41), gets its directory entry written (voxel_hash.cu:72-74,101-103)
-// and its 512 voxels initialised to weight 1 / tsdf -1 / probability .5 with rgb left untouched
-// (voxel_mem.cu:43-51).  A new block is visible by construction (allocation needs all 8 corners in
-// view, voxel_tsdf.cu:165), so it is also entered into this frame's visibility mask.
-// Every request releases its bucket's claim (ResetLocks).
-__global__ __launch_bounds__(256) void k_alloc_commit(Table tab, Pool pool, const Request* req,
-                                                      uint32_t req_cap, const uint32_t* bitmap,
-                                                      const uint32_t* chunk_prefix,
-                                                      unsigned long long* vismask,
-                                                      uint32_t* vis_wg_count, Ctl* ctl) {
+// Commit of one allocation request by one wave (all lanes call it; only lane 0 of a wave with
+// `writer` set touches the directory).  A winner with rank k among the winners takes
+// heap[alloc_base - 1 - k] (AquireBlock, voxel_mem.cu:37-41) and gets its directory entry written
+// (voxel_hash.cu:72-74,101-103); every request releases its bucket's claim (ResetLocks).
+// Returns true for a winner that received a block; *out_k / *out_idx / *out_entry describe it.
+__device__ inline bool commit_request(const Table& tab, const Pool& pool, const Request& r,
+                                      const uint32_t* bitmap, const uint32_t* prefix,
+                                      uint32_t alloc_base, uint32_t n_win, bool writer,
+                                      uint32_t* out_k, int32_t* out_idx, uint32_t* out_entry) {
+  const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
+  const bool placed = (r.flags & kReqPlaced) != 0;
+  if (!(r.flags & kReqWinner)) {
+    if (writer && !placed) tab.claim[bucket] = kInf;
+    return false;
+  }
+  const uint32_t k = bitmap_rank(bitmap, prefix, r.rank);
+  uint32_t e = r.entry;
+  if (writer && !placed) {
+    const uint32_t e0 = bucket << 1;
+    e = (load_entry(tab.entries, e0).idx < 0) ? e0 : e0 + 1;
+  }
+  uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + e);
+  if (k >= n_win) {  // pool exhausted (voxel_mem.cu:39): this insertion does not happen
+    if (writer) {
+      if (placed) pe[2] = (uint32_t)-1;
+      else tab.claim[bucket] = kInf;
+    }
+    return false;
+  }
+  const int32_t idx = pool.heap[alloc_base - 1 - k];
+  if (writer) {
+    if (!placed) {
+      pe[0] = key0(r.x, r.y);
+      pe[1] = key1(r.z);
+      tab.claim[bucket] = kInf;
+    }
+    pe[2] = (uint32_t)idx;
+    atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
+  }
+  *out_k = k;
+  *out_idx = idx;
+  *out_entry = e;
+  return true;
+}
+
+// Stand-alone commit (test hook: allocation passes without a frame): one wave per request, block
+// initialised to weight 1 / tsdf -1 / probability .5 with rgb left untouched (voxel_mem.cu:43-51).
+__global__ __launch_bounds__(256) void k_commit_only(Table tab, Pool pool, const Request* req,
+                                                     uint32_t req_cap, const uint32_t* bitmap,
+                                                     const uint32_t* prefix, Ctl* ctl) {
   uint32_t n = ctl->n_req;
   if (n > req_cap) n = req_cap;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t base = ctl->alloc_base;
-  const uint32_t chunk = ctl->rank_chunk;
+  const uint32_t base = ctl->alloc_base, n_win = ctl->n_win;
   for (uint32_t i = wave; i < n; i += nwaves) {
     const Request r = req[i];
-    const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
-    const bool placed = (r.flags & kReqPlaced) != 0;
-    if (!(r.flags & kReqWinner)) {
-      if (lane == 0 && !placed) tab.claim[bucket] = kInf;
-      continue;
-    }
-    // rank among winners: chunk prefix + popcounts of the earlier words of the chunk (lanes in
-    // parallel) + bits below in the own word
-    const uint32_t w = r.rank >> 5;
-    const uint32_t c = w / chunk;
-    uint32_t part = 0;
-    for (uint32_t j = c * chunk + lane; j < w; j += 64) part += __popc(bitmap[j]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    const uint32_t k = chunk_prefix[c] + part + __popc(bitmap[w] & ((1u << (r.rank & 31)) - 1u));
-    uint32_t e = r.entry;
-    if (!placed) {
-      const uint32_t e0 = bucket << 1;
-      e = (load_entry(tab.entries, e0).idx < 0) ? e0 : e0 + 1;
-    }
-    uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + e);
-    if (k >= base) {  // pool exhausted: this insertion does not happen
-      if (lane == 0) {
-        if (placed) pe[2] = (uint32_t)-1;
-        else tab.claim[bucket] = kInf;
-      }
-      continue;
-    }
-    const int32_t idx = pool.heap[base - 1 - k];
-    if (lane == 0) {
-      if (!placed) {
-        pe[0] = key0(r.x, r.y);
-        pe[1] = key1(r.z);
-        tab.claim[bucket] = kInf;
-      }
-      pe[2] = (uint32_t)idx;
-      atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
-      if (vismask) {
-        atomicOr(&vismask[e >> 6], 1ull << (e & 63));
-        atomicAdd(&vis_wg_count[e >> 14], 1u);  // 256 words of 64 entries per visibility workgroup
-      }
-    }
+    uint32_t k, e;
+    int32_t idx;
+    if (!commit_request(tab, pool, r, bitmap, prefix, base, n_win, lane == 0, &k, &idx, &e)) continue;
     const size_t v = ((size_t)idx << 9) + lane * 8;
     float4* pt = reinterpret_cast<float4*>(pool.tsdf + v);
     float4* ps = reinterpret_cast<float4*>(pool.segm + v);

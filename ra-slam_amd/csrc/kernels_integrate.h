@@ -10,12 +10,19 @@
 // min |tsdf| (space carving) is reduced from registers with cross-lane shuffles (+ LDS across the
 // waves of a block), so the reference's second pass over the block is gone.
 //
+// k_integrate also performs the COMMIT of this frame's allocation winners: the wave that commits a
+// new block (pool index, directory entry, occupancy bit) integrates it straight away from the
+// initial values held in registers (weight 1 / tsdf -1 / probability .5, rgb read from the pool as
+// the reference leaves it untouched, voxel_mem.cu:43-51), so a new block costs no separate
+// initialisation pass.
+//
 // The carve pass (VoxelHashTable::Delete, voxel_hash.cu:110-159 + ReleaseBlock, voxel_mem.cu:56-61)
-// is made deterministic the same way as allocation: deletions happen in visible-list (= ascending
-// hash entry) order; deletes of a block sitting in slot 0 of its home bucket are lock-free and
-// independent; head / chain deletes are serialised per home bucket by the bucket lock, i.e. the
-// first one in list order wins (atomicMin claim), and the released pool indices are pushed on the
-// free list in list order via a popcount prefix over a bitmap.  One workgroup does the whole pass.
+// is made deterministic the same way as allocation: deletions happen in ascending hash-entry order
+// (the order of the reference's visible list); deletes of a block sitting in slot 0 of its home
+// bucket are lock-free and independent; head / chain deletes are serialised per home bucket by the
+// bucket lock, i.e. the first one in entry order wins (atomicMin claim), and the released pool
+// indices are pushed on the free list in entry order via a popcount prefix over an entry-indexed
+// bitmap.  One workgroup does the whole pass.
 #pragma once
 #include "kernels_visible.h"
 
@@ -67,9 +74,12 @@ struct VecIO<2> {
 };
 
 template <int VPL>
-__global__ __launch_bounds__(256) void k_integrate(Pool pool, FrameParams P, const VisItem* vis,
-                                                   const float4* texA, const uint2* texB,
-                                                   uint32_t* blk_info, Ctl* ctl) {
+__global__ __launch_bounds__(256) void k_integrate(Table tab, Pool pool, FrameParams P, VisItem* vis,
+                                                   uint32_t vis_cap, const Request* req,
+                                                   uint32_t req_cap, const uint32_t* abitmap,
+                                                   const uint32_t* aprefix, const float4* texA,
+                                                   const uint2* texB, uint32_t* blk_info,
+                                                   Ctl* ctl) {
   constexpr int WPB = 8 / VPL;  // waves per voxel block
   constexpr int BPW = 4 / WPB;  // voxel blocks per 256-thread workgroup
   __shared__ float smin[4];
@@ -77,21 +87,53 @@ __global__ __launch_bounds__(256) void k_integrate(Pool pool, FrameParams P, con
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wv = threadIdx.x >> 6;
   const uint32_t blk_in_wg = wv / WPB, part = wv % WPB;
-  const uint32_t nv = ctl->n_vis;
+  uint32_t n_exist = ctl->n_vis;  // blocks that existed before this frame and are in view
+  if (n_exist > vis_cap) n_exist = vis_cap;
+  uint32_t n_req = ctl->n_req;
+  if (n_req > req_cap) n_req = req_cap;
+  const uint32_t n_win = ctl->n_win, alloc_base = ctl->alloc_base;
+  const uint32_t n_items = n_exist + n_req;
   const uint32_t vi0 = (part * 64 + lane) * VPL;  // first voxel of this lane, x + 8y + 64z
   const int tx0 = vi0 & 7, ty = (vi0 >> 3) & 7, tz = vi0 >> 6;
-  for (uint32_t it = blockIdx.x; it * BPW < nv; it += gridDim.x) {
-    const uint32_t b = it * BPW + blk_in_wg;
-    const bool active = b < nv;
+  for (uint32_t it = blockIdx.x; it * BPW < n_items; it += gridDim.x) {
+    const uint32_t t = it * BPW + blk_in_wg;
+    bool active = t < n_items;
+    bool fresh = false;
+    uint32_t b = t;  // slot in the frame's block list
+    VisItem item{};
+    if (active) {
+      if (t < n_exist) {
+        item = vis[t];
+      } else {
+        const Request r = req[t - n_exist];
+        uint32_t k = 0, e = 0;
+        int32_t idx = -1;
+        const bool writer = part == 0 && lane == 0;
+        active = commit_request(tab, pool, r, abitmap, aprefix, alloc_base, n_win, writer, &k, &idx, &e);
+        fresh = active;
+        b = n_exist + k;  // winners occupy slots n_exist .. n_exist + n_win - 1
+        if (b >= vis_cap) active = false;
+        item = VisItem{r.x, r.y, r.z, 0, idx, e};
+        if (active && writer) vis[b] = item;  // the carve pass needs the block's directory entry
+      }
+    }
     float m = 3.0e38f;
     uint32_t nupd_blk = 0;
     if (active) {
-      const VisItem item = vis[b];
       const size_t v = ((size_t)item.idx << 9) + vi0;
       uint32_t tv[VPL], sv[VPL], cv[VPL];
-      VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.tsdf + v), tv);
-      VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.segm + v), sv);
       VecIO<VPL>::load(pool.rgbw + v, cv);
+      if (!fresh) {
+        VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.tsdf + v), tv);
+        VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.segm + v), sv);
+      } else {  // AquireBlock initial values, voxel_mem.cu:43-51 (rgb stays as found)
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          tv[j] = __float_as_uint(-1.f);
+          sv[j] = __float_as_uint(.5f);
+          cv[j] = (cv[j] & 0x00FFFFFFu) | 0x01000000u;
+        }
+      }
 
       const int gy = (int16_t)((int16_t)(item.y << 3) + ty);
       const int gz = (int16_t)((int16_t)(item.z << 3) + tz);
@@ -149,7 +191,7 @@ __global__ __launch_bounds__(256) void k_integrate(Pool pool, FrameParams P, con
           ++nupd;
         }
       }
-      if (nupd) {
+      if (nupd || fresh) {
         VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.tsdf + v), tv);
         VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), sv);
         VecIO<VPL>::store(pool.rgbw + v, cv);
@@ -187,7 +229,7 @@ __global__ __launch_bounds__(256) void k_integrate(Pool pool, FrameParams P, con
   }
 }
 
-// explicit delete list (test hook): builds a pseudo visible list in list order
+// explicit delete list (test hook): builds a pseudo visible list
 __global__ void k_lookup_list(Table tab, const int16_t* pos, int n, VisItem* vis,
                               uint32_t* blk_info, Ctl* ctl) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,47 +250,54 @@ __device__ inline uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+struct Released {  // a successful delete: where the block sat when the list was built, its pool index
+  uint32_t entry;
+  int32_t idx;
+};
+
 // ---------------------------------------------------------------------------------------------
 // k_carve: the whole carve pass in ONE workgroup.
 //   (1) every flagged block: slot-0-of-home deletes happen directly (no lock, voxel_hash.cu:114-123),
-//       the others claim their home bucket with atomicMin(list index) and go to a small list
-//   (2) head / chain deletes: one winner per home bucket = the first in list order
+//       the others claim their home bucket with atomicMin(entry index) and go to a small list
+//   (2) head / chain deletes: one winner per home bucket = the first in entry order
 //       (voxel_hash.cu:125-158); claims are released (ResetLocks)
-//   (3) popcount prefix over the delete bitmap = order of the ReleaseBlock calls; heap pushes
-//   (4) free-list bookkeeping, frame statistics, and the control block is zeroed for the next frame
-// Data produced with atomics inside this kernel (bitmap words, claims, n_slow_del) is read either
-// with agent-scope atomic loads or from lines this kernel has not touched before (L1 is cold).
+//   (3) popcount prefix over the entry-indexed delete bitmap = order of the ReleaseBlock calls
+//   (4) heap pushes, free-list bookkeeping, frame statistics; the control block and the delete
+//       bitmap are left clean for the next pass
+// Data produced with atomics inside this kernel (bitmap words, claims, counters) is read either with
+// agent-scope atomic loads or from lines this kernel has not touched before (L1 is cold).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisItem* vis,
-                                                const uint32_t* blk_info, uint32_t* bitmap,
-                                                uint32_t* summary, int32_t* del_idx,
-                                                SlowDelete* slow,
-                                                uint32_t slow_cap, Ctl* ctl,
+                                                uint32_t vis_cap, const uint32_t* blk_info,
+                                                uint32_t* bitmap, uint32_t* summary,
+                                                uint32_t* prefix, Released* rel, uint32_t rel_cap,
+                                                SlowDelete* slow, uint32_t slow_cap, Ctl* ctl,
                                                 ratsdf_frame_stats* stats) {
   __shared__ uint32_t lds[32];
-  __shared__ uint32_t cprefix[1024];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   RATSDF_STAMP(ctl->stamps, 0);
-  const uint32_t nv = ctl->n_vis;
+  uint32_t nv = ctl->n_vis + ctl->n_win;  // existing visible blocks + blocks inserted this frame
+  if (nv > vis_cap) nv = vis_cap;
   uint32_t upd_part = 0;
   for (uint32_t i = tid; i < nv; i += nt) {
     const uint32_t info = blk_info[i];
+    const VisItem it = vis[i];
     upd_part += info & 0x7FFFFFFFu;
     if (!(info >> 31)) continue;
-    const VisItem it = vis[i];
     const uint32_t bucket = block_hash(it.x, it.y, it.z, tab.bucket_mask);
     if (it.entry == (bucket << 1)) {
       uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + it.entry);
-      pe[1] = pe[1] & 0xFFFFu;  // offset = 0
+      pe[1] = key1(it.z);  // offset = 0
       pe[2] = (uint32_t)-1;
       occ_clear(tab, it.entry);
-      del_idx[i] = it.idx;
-      bitmap_set(bitmap, summary, i);
+      bitmap_set(bitmap, summary, it.entry);
+      const uint32_t slot = atomicAdd(&ctl->n_del, 1u);
+      if (slot < rel_cap) rel[slot] = Released{it.entry, it.idx};
     } else {
-      atomicMin(&tab.claim[bucket], i);
+      atomicMin(&tab.claim[bucket], it.entry);
       const uint32_t slot = atomicAdd(&ctl->n_slow_del, 1u);
       if (slot < slow_cap) {
-        slow[slot] = SlowDelete{it.x, it.y, it.z, 0, i};
+        slow[slot] = SlowDelete{it.x, it.y, it.z, 0, it.entry};
       } else {
         set_error(ctl, RATSDF_ERR_CAPACITY);
       }
@@ -276,11 +325,12 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
       uint32_t last = (bucket << 1) + 1;
       uint32_t* ph = reinterpret_cast<uint32_t*>(tab.entries + last);
       const EntryWords h = load_entry(tab.entries, last);
+      int32_t freed = -1;
       if (entry_matches(h, k0, k1)) {                                     // voxel_hash.cu:125-140
         const uint32_t nxt = (last + (uint32_t)entry_offset(h)) & tab.entry_mask;
         uint32_t* pn = reinterpret_cast<uint32_t*>(tab.entries + nxt);
         const EntryWords nw = load_entry(tab.entries, nxt);
-        del_idx[s.vis] = h.idx;
+        freed = h.idx;
         const int noff = entry_offset(nw);
         const int16_t hoff = noff ? (int16_t)(entry_offset(h) + noff) : (int16_t)0;
         ph[0] = nw.w0;
@@ -289,7 +339,6 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
         pn[1] = pn[1] & 0xFFFFu;
         pn[2] = (uint32_t)-1;
         occ_clear(tab, nxt);  // the head keeps its bit unless it was its own successor
-        bitmap_set(bitmap, summary, s.vis);
       } else {                                                            // voxel_hash.cu:142-158
         for (uint32_t g = 0; g < tab.num_entry; ++g) {
           const EntryWords lw = load_entry(tab.entries, last);
@@ -303,15 +352,19 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
             uint32_t* pl = reinterpret_cast<uint32_t*>(tab.entries + last);
             uint32_t* pcur = reinterpret_cast<uint32_t*>(tab.entries + cur);
             pl[1] = (pl[1] & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16);
-            del_idx[s.vis] = cw.idx;
+            freed = cw.idx;
             pcur[1] = pcur[1] & 0xFFFFu;
             pcur[2] = (uint32_t)-1;
             occ_clear(tab, cur);
-            bitmap_set(bitmap, summary, s.vis);
             break;
           }
           last = cur;
         }
+      }
+      if (freed >= 0) {
+        bitmap_set(bitmap, summary, s.vis);
+        const uint32_t slot = atomicAdd(&ctl->n_del, 1u);
+        if (slot < rel_cap) rel[slot] = Released{s.vis, freed};
       }
     }
     __syncthreads();
@@ -319,39 +372,41 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
   RATSDF_STAMP(ctl->stamps, 2);
   uint32_t upd = 0;
   (void)block_exclusive_scan(upd_part, lds, &upd);
-  const uint32_t nwords = (nv + 31) >> 5;
-  const uint32_t chunk = bitmap_chunk(nwords, nt);
-  const uint32_t sum = chunk_popcount(bitmap, summary, nwords, chunk);
-  uint32_t total = 0;
-  cprefix[tid] = block_exclusive_scan(sum, lds, &total);
-  __syncthreads();
-  RATSDF_STAMP(ctl->stamps, 3);
+  uint32_t n_rel = ld_agent(&ctl->n_del);
+  if (n_rel > rel_cap) n_rel = rel_cap;
   const int32_t nf = ctl->num_free;
-  if (total) {  // uniform
-    for (uint32_t i = tid; i < nv; i += nt) {
-      if (!((bitmap[i >> 5] >> (i & 31)) & 1u)) continue;
-      const uint32_t k = bitmap_rank(bitmap, cprefix, chunk, i);
-      pool.heap[(uint32_t)nf + k] = del_idx[i];                           // voxel_mem.cu:56-60
+  if (n_rel) {  // uniform
+    const uint32_t nwords = tab.num_entry >> 5;
+    const uint32_t chunk = bitmap_chunk(nwords, nt);
+    const uint32_t sum = chunk_popcount(bitmap, summary, nwords, chunk);
+    uint32_t total = 0;
+    const uint32_t excl = block_exclusive_scan(sum, lds, &total);
+    bitmap_write_prefix(bitmap, summary, prefix, nwords, chunk, sum, excl);
+    __syncthreads();
+    RATSDF_STAMP(ctl->stamps, 3);
+    for (uint32_t j = tid; j < n_rel; j += nt) {
+      const Released r = rel[j];
+      pool.heap[(uint32_t)nf + bitmap_rank(bitmap, prefix, r.entry)] = r.idx;  // voxel_mem.cu:56-60
     }
+    __syncthreads();  // every reader of the delete bitmap is done: leave it clean for the next pass
+    RATSDF_STAMP(ctl->stamps, 4);
+    bitmap_clean(bitmap, summary, nwords);
   }
-  __syncthreads();  // every reader of the delete bitmap is done: leave it clean for the next pass
-  RATSDF_STAMP(ctl->stamps, 4);
-  bitmap_clean(bitmap, summary, nwords);
   RATSDF_STAMP(ctl->stamps, 5);
   if (tid == 0) {
-    ctl->num_free = nf + (int32_t)total;
+    ctl->num_free = nf + (int32_t)n_rel;
     if (stats) {
       stats->visible_blocks = (int32_t)nv;
       stats->updated_voxels = (int32_t)upd;
       stats->allocated_blocks = (int32_t)ctl->n_win;
-      stats->deleted_blocks = (int32_t)total;
-      stats->active_blocks = tab.num_block - (nf + (int32_t)total);
+      stats->deleted_blocks = (int32_t)n_rel;
+      stats->active_blocks = tab.num_block - (nf + (int32_t)n_rel);
       stats->slow_requests = (int32_t)ctl->n_slow;
       ctl->totals[0] += 1;
       ctl->totals[1] += nv;
       ctl->totals[2] += upd;
       ctl->totals[3] += ctl->n_win;
-      ctl->totals[4] += total;
+      ctl->totals[4] += n_rel;
     }
     // control block ready for the next pass (saves a memset node per frame)
     uint32_t* z = reinterpret_cast<uint32_t*>(ctl);

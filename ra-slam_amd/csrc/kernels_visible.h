@@ -5,11 +5,12 @@
 // (utils/tsdf/voxel_tsdf.cu:15-33,98-118,465-474,847-867; utils/cuda/arithmetic.cuh:52-172).
 // The reference scans all 2^22 directory entries (48 MiB) three times per frame.  Here the engine
 // keeps a 512 KiB occupancy bitmap of the directory (one bit per entry, maintained by the commit and
-// carve kernels); a frame reads the bitmap and only the entries whose bit is set.  The output list
-// is ordered by ascending hash-entry index exactly like the reference's scan + gather: one lane per
-// 64-entry word produces a selection mask, and the scatter kernel turns per-workgroup counts into
-// offsets on the fly.  The count stays on the device (Ctl::n_vis / n_sel); consumers are
-// persistent grids that read it there.
+// carve code); a pass reads the bitmap and only the entries whose bit is set.
+//   * per frame: visible_append_role builds the (unordered) visible work list;
+//   * queries / exports: k_select_flags + k_select_scatter build a list ordered by ascending
+//     hash-entry index exactly like the reference's scan + gather (one lane per 64-entry word
+//     produces a selection mask, the scatter kernel turns per-workgroup counts into offsets).
+// Counts stay on the device (Ctl::n_vis / n_sel); consumers are persistent grids that read them.
 #pragma once
 #include "kernels_alloc.h"
 
@@ -69,23 +70,66 @@ __device__ inline void select_flags_role(const Table& tab, const FrameParams& P,
   }
 }
 
+// Visibility of the blocks that exist before this frame (check_visibility_kernel +
+// gather_visible_blocks_kernel, voxel_tsdf.cu:98-118): one lane per 64-entry occupancy word tests
+// the allocated entries of its word (any of the 8 corners in view) and the workgroup appends its
+// visible blocks to the frame's work list with ONE atomicAdd.  The list is unordered; nothing in
+// a frame depends on its order (blocks are independent; the carve pass orders its pool releases by
+// hash entry through an entry-indexed bitmap).
+__device__ inline void visible_append_role(const Table& tab, const FrameParams& P, uint32_t wg,
+                                           VisItem* vis, uint32_t vis_cap, Ctl* ctl) {
+  __shared__ uint32_t lds[32];
+  __shared__ uint32_t base_slot;
+  const uint32_t nwords = tab.num_entry >> 6;
+  const uint32_t w = wg * kVisWG + threadIdx.x;
+  unsigned long long occ = w < nwords ? tab.occ[w] : 0ull;
+  unsigned long long sel = 0;
+  while (occ) {
+    const int b = __ffsll((long long)occ) - 1;
+    occ &= occ - 1;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(tab.entries + ((size_t)w * 64 + b));
+    const uint32_t w0 = p[0], w1 = p[1];
+    const int bx = (int16_t)(w0 & 0xFFFFu), by = (int16_t)(w0 >> 16), bz = (int16_t)(w1 & 0xFFFFu);
+    if (block_visible<false>(bx, by, bz, P)) sel |= 1ull << b;           // voxel_tsdf.cu:98-109
+  }
+  uint32_t total = 0;
+  const uint32_t excl = block_exclusive_scan((uint32_t)__popcll(sel), lds, &total);
+  if (total == 0) return;  // uniform
+  if (threadIdx.x == 0) base_slot = atomicAdd(&ctl->n_vis, total);
+  __syncthreads();
+  uint32_t pos = base_slot + excl;
+  while (sel) {
+    const int b = __ffsll((long long)sel) - 1;
+    sel &= sel - 1;
+    const uint32_t e = w * 64 + b;
+    if (pos < vis_cap) {
+      const EntryWords ew = load_entry(tab.entries, e);
+      uint4 v;
+      v.x = ew.w0;
+      v.y = ew.w1;
+      v.z = (uint32_t)ew.idx;
+      v.w = e;
+      reinterpret_cast<uint4*>(vis)[pos] = v;
+    }
+    ++pos;
+  }
+}
+
 // k_front: the two directory-read-only jobs of a frame in one launch.
 //   workgroups [0, n_pix_wg)          allocation candidates + packed texels (alloc_pixels_role)
-//   workgroups [n_pix_wg, gridDim.x)  visibility of the blocks that exist before this frame
-// Blocks inserted by this frame are added to the visibility mask by k_alloc_commit.
+//   workgroups [n_pix_wg, gridDim.x)  visible list of the blocks that exist before this frame
+// Blocks inserted by this frame join the list in k_integrate (they are visible by construction).
 __global__ __launch_bounds__(256) void k_front(Table tab, FrameParams P, uint32_t n_pix_wg,
                                                const float* depth, const uint8_t* rgb,
                                                const float* ht, const float* lt, float4* texA,
                                                uint2* texB, Request* req, uint32_t req_cap,
-                                               SlowRequest* slow, uint32_t slow_cap,
-                                               unsigned long long* vismask, uint32_t* vis_wg_count,
-                                               Ctl* ctl) {
+                                               SlowRequest* slow, uint32_t slow_cap, VisItem* vis,
+                                               uint32_t vis_cap, Ctl* ctl) {
   if (blockIdx.x < n_pix_wg) {
     alloc_pixels_role(tab, P, blockIdx.x, depth, rgb, ht, lt, texA, texB, req, req_cap, slow,
                       slow_cap, ctl);
   } else if (P.debug != 3) {
-    select_flags_role<kSelVisible>(tab, P, GridBounds{}, blockIdx.x - n_pix_wg, vismask,
-                                   vis_wg_count);
+    visible_append_role(tab, P, blockIdx.x - n_pix_wg, vis, vis_cap, ctl);
   }
 }
 

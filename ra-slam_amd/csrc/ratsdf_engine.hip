@@ -70,7 +70,7 @@ struct ratsdf_engine {
   uint32_t req_cap = 0;
   uint32_t* abitmap[2] = {nullptr, nullptr};   // rank bitmaps (padded to whole 32-word groups)
   uint32_t* asummary[2] = {nullptr, nullptr};  // one bit per group
-  uint32_t* chunk_prefix = nullptr;  // 1024 words
+  uint32_t* aprefix = nullptr;       // per-word prefix of the rank bitmap (set groups only)
   uint32_t awords_cap = 0, asum_words = 0;
   int apass = 0;
 
@@ -84,10 +84,12 @@ struct ratsdf_engine {
   uint32_t nwg = 0;
   VisItem* vis = nullptr;
   uint32_t* carve_flag = nullptr;  // per visible block: bit 31 carve candidate | voxels updated
-  uint32_t* dbitmap = nullptr;   // delete bitmap over the visible list (self-cleaning)
+  uint32_t* dbitmap = nullptr;   // delete bitmap indexed by hash entry (self-cleaning)
   uint32_t* dsummary = nullptr;
+  uint32_t* dprefix = nullptr;
+  Released* rel = nullptr;       // (entry, pool idx) of this pass's successful deletes
+  uint32_t vis_cap = 0;
   uint32_t dwords = 0;
-  int32_t* del_idx = nullptr;
   SlowDelete* slowdel = nullptr;
 
   // staging for the host-image entry point
@@ -105,7 +107,7 @@ struct ratsdf_engine {
   int free_all();
   int ensure_image(size_t npix, size_t nranks);
   int ensure_stage(size_t npix);
-  int alloc_tail(uint32_t nranks, bool is_frame);
+  int alloc_rank(uint32_t nranks);
   int carve_tail(bool is_frame);
   int select(int mode, const GridBounds& gb, uint32_t* count_slot);
   int frame(const void* d_rgb, const void* d_depth, const void* d_ht, const void* d_lt, int H, int W,
@@ -138,9 +140,9 @@ FrameParams ratsdf_engine::base_params() const {
 int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
   void* ptrs[] = {tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
-                  d_stats, texA, texB, req, abitmap[0], abitmap[1], asummary[0], asummary[1], chunk_prefix,
+                  d_stats, texA, texB, req, abitmap[0], abitmap[1], asummary[0], asummary[1], aprefix,
                   slow, xlocks,
-                  distinct, masks, wg_count, vis, carve_flag, dbitmap, dsummary, del_idx,
+                  distinct, masks, wg_count, vis, carve_flag, dbitmap, dsummary, dprefix, rel,
                   slowdel, d_stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -169,6 +171,7 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
     if (abitmap[1]) (void)hipFree(abitmap[1]);
     if (asummary[0]) (void)hipFree(asummary[0]);
     if (asummary[1]) (void)hipFree(asummary[1]);
+    if (aprefix) (void)hipFree(aprefix);
     req_cap = (uint32_t)nranks;
     awords_cap = (uint32_t)((nranks + 31) / 32);
     awords_cap = (awords_cap + kGroupWords - 1) / kGroupWords * kGroupWords;
@@ -178,6 +181,7 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
     HIPCHK(hipMalloc(&abitmap[1], (size_t)awords_cap * 4));
     HIPCHK(hipMalloc(&asummary[0], (size_t)asum_words * 4));
     HIPCHK(hipMalloc(&asummary[1], (size_t)asum_words * 4));
+    HIPCHK(hipMalloc(&aprefix, (size_t)awords_cap * 4));
     rank_cap = nranks;
   }
   // Each pass's scan kernel cleans the other bitmap only over the current rank space, so both must
@@ -206,26 +210,22 @@ int ratsdf_engine::ensure_stage(size_t npix) {
   return RATSDF_OK;
 }
 
-// rank (resolve + mark + scan) -> commit on a rank space of `nranks`
-int ratsdf_engine::alloc_tail(uint32_t nranks, bool is_frame) {
+// rank kernel (resolve + mark + scan) on a rank space of `nranks`; the commit itself happens inside
+// k_integrate for frames and in k_commit_only for the stand-alone test hook
+int ratsdf_engine::alloc_rank(uint32_t nranks) {
   const uint32_t nwords = (nranks + 31) / 32;
-  uint32_t* bm = abitmap[apass & 1];
-  uint32_t* bm_next = abitmap[(apass + 1) & 1];
   hipLaunchKernelGGL(k_alloc_rank, dim3(1), dim3(1024), kSlowSortCap * sizeof(unsigned long long),
-                     stream, tab, req, req_cap, slow, kSlowCap, xlocks, distinct, bm,
-                     asummary[apass & 1], chunk_prefix, nwords, bm_next, asummary[(apass + 1) & 1],
-                     ctl);
-  hipLaunchKernelGGL(k_alloc_commit, dim3(256), dim3(256), 0, stream, tab, pool, req, req_cap, bm,
-                     chunk_prefix, is_frame ? masks : (unsigned long long*)nullptr, wg_count, ctl);
-  ++apass;
+                     stream, tab, req, req_cap, slow, kSlowCap, xlocks, distinct, abitmap[apass & 1],
+                     asummary[apass & 1], aprefix, nwords, abitmap[(apass + 1) & 1],
+                     asummary[(apass + 1) & 1], ctl);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
 
 int ratsdf_engine::carve_tail(bool is_frame) {
-  hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, stream, tab, pool, vis, carve_flag, dbitmap,
-                     dsummary, del_idx, slowdel, kSlowDelCap, ctl,
-                     is_frame ? d_stats : (ratsdf_frame_stats*)nullptr);
+  hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, stream, tab, pool, vis, vis_cap, carve_flag,
+                     dbitmap, dsummary, dprefix, rel, (uint32_t)tab.num_block, slowdel, kSlowDelCap,
+                     ctl, is_frame ? d_stats : (ratsdf_frame_stats*)nullptr);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
@@ -240,7 +240,7 @@ int ratsdf_engine::select(int mode, const GridBounds& gb, uint32_t* count_slot) 
     hipLaunchKernelGGL(k_select_flags<kSelBounds>, dim3(nwg), dim3(kVisWG), 0, stream, tab, P, gb,
                        masks, wg_count);
   hipLaunchKernelGGL(k_select_scatter, dim3(nwg), dim3(kVisWG), 0, stream, tab, masks, wg_count, vis,
-                     (uint32_t)tab.num_block, count_slot);
+                     vis_cap, count_slot);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
@@ -266,12 +266,11 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
   const unsigned n_pix_wg = (unsigned)((npix + 255) / 256);
   hipLaunchKernelGGL(k_front, dim3(n_pix_wg + nwg), dim3(256), 0, stream, tab, P, n_pix_wg,
                      (const float*)d_depth, (const uint8_t*)d_rgb, (const float*)d_ht,
-                     (const float*)d_lt, texA, texB, req, req_cap, slow, kSlowCap, masks, wg_count,
-                     ctl);
-  st = alloc_tail((uint32_t)(npix * (size_t)S), true);
+                     (const float*)d_lt, texA, texB, req, req_cap, slow, kSlowCap, vis, vis_cap, ctl);
+  st = alloc_rank((uint32_t)(npix * (size_t)S));
   if (st != RATSDF_OK) return st;
-  hipLaunchKernelGGL(k_select_scatter, dim3(nwg), dim3(kVisWG), 0, stream, tab, masks, wg_count, vis,
-                     (uint32_t)tab.num_block, &ctl->n_vis);
+  const uint32_t* bm = abitmap[apass & 1];
+  ++apass;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (profiling) {
@@ -288,16 +287,16 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
   }
   switch (vpl) {
     case 8:
-      hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, pool, P, vis,
-                         texA, texB, carve_flag, ctl);
+      hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
+                         vis, vis_cap, req, req_cap, bm, aprefix, texA, texB, carve_flag, ctl);
       break;
     case 4:
-      hipLaunchKernelGGL(k_integrate<4>, dim3(integrate_grid), dim3(256), 0, stream, pool, P, vis,
-                         texA, texB, carve_flag, ctl);
+      hipLaunchKernelGGL(k_integrate<4>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
+                         vis, vis_cap, req, req_cap, bm, aprefix, texA, texB, carve_flag, ctl);
       break;
     default:
-      hipLaunchKernelGGL(k_integrate<2>, dim3(integrate_grid), dim3(256), 0, stream, pool, P, vis,
-                         texA, texB, carve_flag, ctl);
+      hipLaunchKernelGGL(k_integrate<2>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
+                         vis, vis_cap, req, req_cap, bm, aprefix, texA, texB, carve_flag, ctl);
   }
   if (profiling) HIPCHK(hipEventRecord(ev1, stream));
 
@@ -370,7 +369,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   t.entry_mask = t.num_entry - 1;
   const uint32_t occ_words = (t.num_entry + 63) / 64;
   e->nwg = (occ_words + kVisWG - 1) / kVisWG;
-  e->dwords = ((uint32_t)t.num_block + 31) / 32;
+  e->dwords = (t.num_entry + 31) / 32;  // delete bitmap is indexed by hash entry
   const size_t nvox = (size_t)t.num_block << 9;
 
 #define CREATE_CHK(expr)                 \
@@ -387,7 +386,6 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&t.entries, (size_t)t.num_entry * sizeof(Entry)));
   CREATE_CHK(hipMalloc(&t.claim, (size_t)t.num_bucket * 4));
   CREATE_CHK(hipMalloc(&t.occ, (size_t)occ_words * 8));
-  CREATE_CHK(hipMalloc(&e->chunk_prefix, 1024 * 4));
   CREATE_CHK(hipMalloc(&e->pool.rgbw, nvox * 4));
   CREATE_CHK(hipMalloc(&e->pool.tsdf, nvox * 4));
   CREATE_CHK(hipMalloc(&e->pool.segm, nvox * 4));
@@ -399,13 +397,15 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->distinct, (size_t)kSlowDistinctCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * kVisWG * 8));
   CREATE_CHK(hipMalloc(&e->wg_count, (size_t)e->nwg * 4));
-  CREATE_CHK(hipMalloc(&e->vis, (size_t)t.num_block * sizeof(VisItem)));
-  CREATE_CHK(hipMalloc(&e->carve_flag, (size_t)t.num_block * 4));
+  e->vis_cap = 2u * (uint32_t)t.num_block;  // visible existing blocks + blocks inserted this frame
+  CREATE_CHK(hipMalloc(&e->vis, (size_t)e->vis_cap * sizeof(VisItem)));
+  CREATE_CHK(hipMalloc(&e->carve_flag, (size_t)e->vis_cap * 4));
   e->dwords = (e->dwords + kGroupWords - 1) / kGroupWords * kGroupWords;
   const uint32_t dsum_words = (e->dwords / kGroupWords + 31) / 32;
   CREATE_CHK(hipMalloc(&e->dbitmap, (size_t)e->dwords * 4));
   CREATE_CHK(hipMalloc(&e->dsummary, (size_t)dsum_words * 4));
-  CREATE_CHK(hipMalloc(&e->del_idx, (size_t)t.num_block * 4));
+  CREATE_CHK(hipMalloc(&e->dprefix, (size_t)e->dwords * 4));
+  CREATE_CHK(hipMalloc(&e->rel, (size_t)t.num_block * sizeof(Released)));
   CREATE_CHK(hipMalloc(&e->slowdel, (size_t)kSlowDelCap * sizeof(SlowDelete)));
   // voxel memory starts zeroed (defined value for the reference's uninitialised rgb)
   CREATE_CHK(hipMemsetAsync(e->pool.rgbw, 0, nvox * 4, e->stream));
@@ -672,7 +672,10 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
   hipLaunchKernelGGL(k_alloc_list, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->tab, P, d, n,
                      e->req, e->req_cap, e->slow, kSlowCap, e->ctl);
-  st = e->alloc_tail((uint32_t)n, false);
+  st = e->alloc_rank((uint32_t)n);
+  hipLaunchKernelGGL(k_commit_only, dim3(256), dim3(256), 0, e->stream, e->tab, e->pool, e->req,
+                     e->req_cap, e->abitmap[e->apass & 1], e->aprefix, e->ctl);
+  ++e->apass;
   // frames expect a clean control block (normally left behind by k_carve)
   HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
   const int st2 = e->sticky();

@@ -13,6 +13,15 @@ sys.path.insert(0, str(ROOT))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # PyTorch bundles its own HIP runtime.  If libratsdf.so (system ROCm runtime) initialises HIP
+    # first, torch later reports "No HIP GPUs are available"; initialising torch first makes both
+    # share one runtime.  Only matters for tests that also use torch tensors on the GPU.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -122,19 +122,21 @@ def case_pool(make):
     for i in range(n):
         assert (w["weight"][i] == i).all()
     nf0, _ = e.dump_heap()
+    ei, bl = e.dump_directory()
     e.test_delete(pos)
     assert e.num_active_blocks() == 0
     nf1, heap = e.dump_heap()
     assert nf1 == nf0 + n and nf1 == NUM_BLOCK
-    # released in list order: heap[free++] = idx (voxel_mem.cu:56-60)
-    assert [int(v) for v in heap[nf0:nf1]] == idx
+    # released in hash-entry order (the carve pass order): heap[free++] = idx (voxel_mem.cu:56-60)
+    released = [int(v) for v in bl["idx"]]          # dump_directory is in entry order
+    assert [int(v) for v in heap[nf0:nf1]] == released
     _, w, _ = e.dump_voxels(idx)
     for i in range(n):
         assert (w["weight"][i] == i).all()  # release keeps the data (:68-78)
     e.test_allocate(pos)
     _, _, _, b2 = e.test_retrieve([[i * BLOCK_LEN, 0, 0] for i in range(n)])
     # LIFO free list: the most recently released block is handed out first
-    assert [int(v) for v in b2["idx"]] == idx[::-1]
+    assert [int(v) for v in b2["idx"]] == released[::-1]
     t, w, p = e.dump_voxels(idx)
     for i in range(n):
         assert (w["weight"][i] == 1).all()  # re-acquire resets weight (:79-89) ...

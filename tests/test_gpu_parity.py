@@ -73,7 +73,7 @@ def test_query_and_gather_match(make_engine, make_oracle):
     assert np.max(np.abs(sa["tsdf"] - sb["tsdf"]), initial=0) <= 1e-4
 
 
-@pytest.mark.parametrize("world,slab", [(2, 1), (4, 0)])
+@pytest.mark.parametrize("world,slab", [(2, 1), (4, 1)])
 def test_sharded_engines_match_sharded_oracle(world, slab, make_engine, make_oracle):
     """Block-ownership sharding (BASELINE config 4): every shard's map is bit-exact vs the oracle
     with the same shard parameters, and the shards partition the blocks."""
