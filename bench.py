@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=40,
                     help="frames of the stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of k_integrate")
+    ap.add_argument("--sync-every", type=int, default=0,
+                    help="diagnostic: host-synchronise every N frames (0 = only at the end)")
     return ap.parse_args()
 
 
@@ -149,6 +151,8 @@ def main():
         for i in range(len(frames)):
             eng.integrate_device(d_rgb[i].data_ptr(), d_depth[i].data_ptr(), d_ht[i].data_ptr(),
                                  d_lt[i].data_ptr(), H, W, a.max_depth, intr[i], pose[i])
+            if a.sync_every and (i + 1) % a.sync_every == 0:
+                eng.synchronize()
         if world > 1:
             exchange()
 
@@ -168,6 +172,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    t_enqueue = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
     k_ms, k_n = (0.0, 0)
@@ -227,6 +232,7 @@ def main():
             "frame": {"avg_visible_blocks": round(V, 1), "avg_updated_voxels": round(U, 1),
                       "alg_bytes": round(b_alg), "alg_gbps_whole_frame": round(b_alg * fps / world / 1e9, 1),
                       "active_blocks": stats["active_blocks"]},
+            "host_enqueue_frac": round(t_enqueue / dt, 3),
             "roofline": roof,
             "cpu_baseline": cpu_baseline,
             "parity": parity,

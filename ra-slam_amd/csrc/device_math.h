@@ -54,12 +54,13 @@ inline Intr intr_inverse(const Intr& K) {
   return Intr{fxi, fyi, -K.cx * fxi, -K.cy * fyi};
 }
 
-// float -> int, CUDA cvt.rzi semantics: NaN -> 0, saturating
+// float -> int with CUDA cvt.rzi.s32.f32 semantics (round toward zero, saturating, NaN -> 0).
+// v_cvt_i32_f32 has exactly these semantics in hardware; the asm keeps the compiler from treating
+// out-of-range inputs as undefined behaviour.
 __device__ inline int f2i(float f) {
-  if (f != f) return 0;
-  if (f >= 2147483648.f) return 2147483647;
-  if (f <= -2147483648.f) return (-2147483647 - 1);
-  return (int)f;
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
 }
 
 // Hash(), utils/tsdf/voxel_hash.cu:19-23

@@ -47,8 +47,9 @@ static_assert(sizeof(SlowRequest) == 12, "slow request is 12 bytes");
 
 struct SlowDelete {
   int16_t x, y, z;
-  uint16_t pad;
-  uint32_t vis;  // index in the visible list (= rank of the carve pass)
+  uint16_t state;  // 0 = lost the bucket, 1 = winner, 2 = winner and block released
+  uint32_t entry;  // where the block sat when the list was built (= its rank in the carve pass)
+  int32_t freed;   // pool index released
 };
 
 // Device-resident control block.  Words [0, kCtlFrameWords) are zeroed at the start of every frame.
@@ -64,8 +65,7 @@ struct Ctl {
   uint32_t alloc_base;    // num_free at the start of the allocation pass
   uint32_t free_base;     // num_free at the start of the carve pass
   uint32_t n_sel;         // selected blocks of a query / export
-  uint32_t rank_chunk;    // words per thread-chunk of the allocation rank bitmap scan
-  uint32_t pad0[5];
+  uint32_t pad0[6];
   // --- persistent ---
   int32_t num_free;       // VoxelMemPool::num_free_blocks_
   uint32_t error;         // sticky ratsdf_status

@@ -24,6 +24,9 @@
 namespace ratsdf {
 
 __device__ inline void set_error(Ctl* ctl, uint32_t code) { atomicCAS(&ctl->error, 0u, code); }
+__device__ inline uint32_t ld_agent_u32(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct EntryWords {
   uint32_t w0, w1;  // x | y << 16,  z | offset << 16
@@ -553,47 +556,92 @@ __device__ inline uint32_t bitmap_rank(const uint32_t* bitmap, const uint32_t* p
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_alloc_rank: one workgroup.  resolve -> mark winners -> rank scan -> free-list bookkeeping.
-// Also cleans the other (previous pass's) rank bitmap, group by group, for the next pass.
+// k_alloc_rank: one workgroup.  resolve -> winners -> rank among winners -> free-list bookkeeping.
+// The order of the AquireBlock calls is the raster order of the winners: winner i gets
+// req_k[i] = number of winners with a smaller rank.
+//   * few requests (the steady state, <= kSmallRank): winners' ranks go to an LDS list and every
+//     winner counts the smaller ones -- no global atomics, no bitmap
+//   * many requests (first frames of a scene): rank-indexed bitmap + popcount prefix (self-cleaning)
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSmallRank = 4096;  // LDS list capacity (16 KiB of the resolver's sort buffer)
+
 __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, uint32_t req_cap,
-                                                     const SlowRequest* slow, uint32_t slow_cap,
-                                                     XLock* xlocks, SlowRequest* distinct,
-                                                     uint32_t* bitmap, uint32_t* summary,
-                                                     uint32_t* prefix, uint32_t nwords,
-                                                     uint32_t* next_bitmap, uint32_t* next_summary,
-                                                     Ctl* ctl) {
+                                                     uint32_t* req_k, const SlowRequest* slow,
+                                                     uint32_t slow_cap, XLock* xlocks,
+                                                     SlowRequest* distinct, uint32_t* bitmap,
+                                                     uint32_t* summary, uint32_t* prefix,
+                                                     uint32_t nwords, Ctl* ctl) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
-  uint32_t* lds = reinterpret_cast<uint32_t*>(skeys);
+  uint32_t* lds = reinterpret_cast<uint32_t*>(skeys);  // [0,32): scan scratch, [32]: counter
+  uint32_t* lds_rank = lds + 64;                       // kSmallRank words
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
   RATSDF_STAMP(ctl->stamps, 8);
-  if (ctl->n_slow != 0) {  // uniform
+  const uint32_t n_slow = ctl->n_slow;
+  const int32_t nf = ctl->num_free;
+  if (n_slow != 0) {  // uniform
     resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, distinct, ctl, skeys);
     __syncthreads();
   }
-  uint32_t n = ctl->n_req;
+  uint32_t n = n_slow ? ld_agent_u32(&ctl->n_req) : ctl->n_req;  // the resolver appends requests
   if (n > req_cap) n = req_cap;
   RATSDF_STAMP(ctl->stamps, 12);
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const Request r = req[i];
-    bool win = (r.flags & kReqWinner) != 0;
-    if (!(r.flags & kReqPlaced)) {
-      const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
-      win = tab.claim[bucket] == r.rank;
-      if (win) req[i].flags = kReqWinner;
-    }
-    if (win) bitmap_set(bitmap, summary, r.rank);
-  }
-  __syncthreads();
-  RATSDF_STAMP(ctl->stamps, 9);
-  const uint32_t chunk = bitmap_chunk(nwords, blockDim.x);
-  const uint32_t sum = chunk_popcount(bitmap, summary, nwords, chunk);
   uint32_t total = 0;
-  const uint32_t excl = block_exclusive_scan(sum, lds, &total);
-  bitmap_write_prefix(bitmap, summary, prefix, nwords, chunk, sum, excl);
-  RATSDF_STAMP(ctl->stamps, 10);
-  bitmap_clean(next_bitmap, next_summary, nwords);
-  if (threadIdx.x == 0) {
-    const int32_t nf = ctl->num_free;
+  if (n <= kSmallRank) {
+    uint32_t* lds_req = lds_rank + kSmallRank;  // request index of each listed winner
+    if (tid == 0) lds[32] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nt) {
+      const Request r = req[i];
+      bool win = (r.flags & kReqWinner) != 0;
+      if (!(r.flags & kReqPlaced)) {
+        const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
+        win = tab.claim[bucket] == r.rank;
+        if (win) req[i].flags = kReqWinner;
+      }
+      if (win) {
+        const uint32_t slot = atomicAdd(&lds[32], 1u);
+        lds_rank[slot] = r.rank;
+        lds_req[slot] = i;
+      }
+    }
+    __syncthreads();
+    RATSDF_STAMP(ctl->stamps, 9);
+    total = lds[32];
+    for (uint32_t w = tid; w < total; w += nt) {  // winner w: count the winners with smaller rank
+      const uint32_t mine = lds_rank[w];
+      uint32_t k = 0;
+#pragma unroll 4
+      for (uint32_t j = 0; j < total; ++j) k += lds_rank[j] < mine;
+      req_k[lds_req[w]] = k;
+    }
+    RATSDF_STAMP(ctl->stamps, 10);
+  } else {
+    for (uint32_t i = tid; i < n; i += nt) {
+      const Request r = req[i];
+      bool win = (r.flags & kReqWinner) != 0;
+      if (!(r.flags & kReqPlaced)) {
+        const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
+        win = tab.claim[bucket] == r.rank;
+        if (win) req[i].flags = kReqWinner;
+      }
+      if (win) bitmap_set(bitmap, summary, r.rank);
+    }
+    __syncthreads();
+    RATSDF_STAMP(ctl->stamps, 9);
+    const uint32_t chunk = bitmap_chunk(nwords, nt);
+    const uint32_t sum = chunk_popcount(bitmap, summary, nwords, chunk);
+    const uint32_t excl = block_exclusive_scan(sum, lds, &total);
+    bitmap_write_prefix(bitmap, summary, prefix, nwords, chunk, sum, excl);
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nt) {
+      const Request r = req[i];
+      if (r.flags & kReqWinner) req_k[i] = bitmap_rank(bitmap, prefix, r.rank);
+    }
+    __syncthreads();
+    bitmap_clean(bitmap, summary, nwords);
+    RATSDF_STAMP(ctl->stamps, 10);
+  }
+  if (tid == 0) {
     uint32_t take = total;
     if ((int64_t)total > (int64_t)nf) {  // voxel_mem.cu:39 assert(idx >= 1)
       set_error(ctl, RATSDF_ERR_POOL_EXHAUSTED);
@@ -612,16 +660,14 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, ui
 // (voxel_hash.cu:72-74,101-103); every request releases its bucket's claim (ResetLocks).
 // Returns true for a winner that received a block; *out_k / *out_idx / *out_entry describe it.
 __device__ inline bool commit_request(const Table& tab, const Pool& pool, const Request& r,
-                                      const uint32_t* bitmap, const uint32_t* prefix,
-                                      uint32_t alloc_base, uint32_t n_win, bool writer,
-                                      uint32_t* out_k, int32_t* out_idx, uint32_t* out_entry) {
+                                      uint32_t k, uint32_t alloc_base, uint32_t n_win, bool writer,
+                                      int32_t* out_idx, uint32_t* out_entry) {
   const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
   const bool placed = (r.flags & kReqPlaced) != 0;
   if (!(r.flags & kReqWinner)) {
     if (writer && !placed) tab.claim[bucket] = kInf;
     return false;
   }
-  const uint32_t k = bitmap_rank(bitmap, prefix, r.rank);
   uint32_t e = r.entry;
   if (writer && !placed) {
     const uint32_t e0 = bucket << 1;
@@ -645,7 +691,6 @@ __device__ inline bool commit_request(const Table& tab, const Pool& pool, const 
     pe[2] = (uint32_t)idx;
     atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
   }
-  *out_k = k;
   *out_idx = idx;
   *out_entry = e;
   return true;
@@ -654,8 +699,8 @@ __device__ inline bool commit_request(const Table& tab, const Pool& pool, const 
 // Stand-alone commit (test hook: allocation passes without a frame): one wave per request, block
 // initialised to weight 1 / tsdf -1 / probability .5 with rgb left untouched (voxel_mem.cu:43-51).
 __global__ __launch_bounds__(256) void k_commit_only(Table tab, Pool pool, const Request* req,
-                                                     uint32_t req_cap, const uint32_t* bitmap,
-                                                     const uint32_t* prefix, Ctl* ctl) {
+                                                     uint32_t req_cap, const uint32_t* req_k,
+                                                     Ctl* ctl) {
   uint32_t n = ctl->n_req;
   if (n > req_cap) n = req_cap;
   const uint32_t lane = threadIdx.x & 63;
@@ -664,9 +709,10 @@ __global__ __launch_bounds__(256) void k_commit_only(Table tab, Pool pool, const
   const uint32_t base = ctl->alloc_base, n_win = ctl->n_win;
   for (uint32_t i = wave; i < n; i += nwaves) {
     const Request r = req[i];
-    uint32_t k, e;
+    uint32_t e;
     int32_t idx;
-    if (!commit_request(tab, pool, r, bitmap, prefix, base, n_win, lane == 0, &k, &idx, &e)) continue;
+    const uint32_t k = (r.flags & kReqWinner) ? req_k[i] : 0u;
+    if (!commit_request(tab, pool, r, k, base, n_win, lane == 0, &idx, &e)) continue;
     const size_t v = ((size_t)idx << 9) + lane * 8;
     float4* pt = reinterpret_cast<float4*>(pool.tsdf + v);
     float4* ps = reinterpret_cast<float4*>(pool.segm + v);

@@ -76,10 +76,9 @@ struct VecIO<2> {
 template <int VPL>
 __global__ __launch_bounds__(256) void k_integrate(Table tab, Pool pool, FrameParams P, VisItem* vis,
                                                    uint32_t vis_cap, const Request* req,
-                                                   uint32_t req_cap, const uint32_t* abitmap,
-                                                   const uint32_t* aprefix, const float4* texA,
-                                                   const uint2* texB, uint32_t* blk_info,
-                                                   Ctl* ctl) {
+                                                   uint32_t req_cap, const uint32_t* req_k,
+                                                   const float4* texA, const uint2* texB,
+                                                   uint32_t* blk_info, Ctl* ctl) {
   constexpr int WPB = 8 / VPL;  // waves per voxel block
   constexpr int BPW = 4 / WPB;  // voxel blocks per 256-thread workgroup
   __shared__ float smin[4];
@@ -106,10 +105,11 @@ __global__ __launch_bounds__(256) void k_integrate(Table tab, Pool pool, FramePa
         item = vis[t];
       } else {
         const Request r = req[t - n_exist];
-        uint32_t k = 0, e = 0;
+        uint32_t e = 0;
         int32_t idx = -1;
         const bool writer = part == 0 && lane == 0;
-        active = commit_request(tab, pool, r, abitmap, aprefix, alloc_base, n_win, writer, &k, &idx, &e);
+        const uint32_t k = (r.flags & kReqWinner) ? req_k[t - n_exist] : 0u;
+        active = commit_request(tab, pool, r, k, alloc_base, n_win, writer, &idx, &e);
         fresh = active;
         b = n_exist + k;  // winners occupy slots n_exist .. n_exist + n_win - 1
         if (b >= vis_cap) active = false;
@@ -250,34 +250,42 @@ __device__ inline uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-struct Released {  // a successful delete: where the block sat when the list was built, its pool index
-  uint32_t entry;
-  int32_t idx;
-};
-
 // ---------------------------------------------------------------------------------------------
 // k_carve: the whole carve pass in ONE workgroup.
 //   (1) every flagged block: slot-0-of-home deletes happen directly (no lock, voxel_hash.cu:114-123),
 //       the others claim their home bucket with atomicMin(entry index) and go to a small list
 //   (2) head / chain deletes: one winner per home bucket = the first in entry order
 //       (voxel_hash.cu:125-158); claims are released (ResetLocks)
-//   (3) popcount prefix over the entry-indexed delete bitmap = order of the ReleaseBlock calls
-//   (4) heap pushes, free-list bookkeeping, frame statistics; the control block and the delete
-//       bitmap are left clean for the next pass
+//   (3) order of the ReleaseBlock calls = ascending hash entry of the deleted blocks:
+//         few deletes (the steady state): entries in an LDS list, every delete counts the smaller
+//         many deletes: entry-indexed bitmap + popcount prefix (self-cleaning)
+//   (4) heap pushes, free-list bookkeeping, frame statistics; the control block is zeroed for the
+//       next pass
 // Data produced with atomics inside this kernel (bitmap words, claims, counters) is read either with
 // agent-scope atomic loads or from lines this kernel has not touched before (L1 is cold).
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSmallCarve = 2048;
+
 __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisItem* vis,
                                                 uint32_t vis_cap, const uint32_t* blk_info,
                                                 uint32_t* bitmap, uint32_t* summary,
-                                                uint32_t* prefix, Released* rel, uint32_t rel_cap,
-                                                SlowDelete* slow, uint32_t slow_cap, Ctl* ctl,
+                                                uint32_t* prefix, SlowDelete* slow,
+                                                uint32_t slow_cap, Ctl* ctl,
                                                 ratsdf_frame_stats* stats) {
   __shared__ uint32_t lds[32];
+  __shared__ uint32_t n_list;                 // deletes recorded in the LDS list (may exceed cap)
+  __shared__ uint32_t del_entry[kSmallCarve];
+  __shared__ int32_t del_pool[kSmallCarve];   // pool index released by that delete
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   RATSDF_STAMP(ctl->stamps, 0);
+#ifdef RATSDF_STAMPS
+  if (threadIdx.x == 0) ctl->stamps[20] += wall_clock64();
+#endif
   uint32_t nv = ctl->n_vis + ctl->n_win;  // existing visible blocks + blocks inserted this frame
+  const int32_t nf = ctl->num_free;
   if (nv > vis_cap) nv = vis_cap;
+  if (tid == 0) n_list = 0;
+  __syncthreads();
   uint32_t upd_part = 0;
   for (uint32_t i = tid; i < nv; i += nt) {
     const uint32_t info = blk_info[i];
@@ -290,14 +298,16 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
       pe[1] = key1(it.z);  // offset = 0
       pe[2] = (uint32_t)-1;
       occ_clear(tab, it.entry);
-      bitmap_set(bitmap, summary, it.entry);
-      const uint32_t slot = atomicAdd(&ctl->n_del, 1u);
-      if (slot < rel_cap) rel[slot] = Released{it.entry, it.idx};
+      const uint32_t slot = atomicAdd(&n_list, 1u);
+      if (slot < kSmallCarve) {
+        del_entry[slot] = it.entry;
+        del_pool[slot] = it.idx;
+      }
     } else {
       atomicMin(&tab.claim[bucket], it.entry);
       const uint32_t slot = atomicAdd(&ctl->n_slow_del, 1u);
       if (slot < slow_cap) {
-        slow[slot] = SlowDelete{it.x, it.y, it.z, 0, it.entry};
+        slow[slot] = SlowDelete{it.x, it.y, it.z, 0, it.entry, -1};
       } else {
         set_error(ctl, RATSDF_ERR_CAPACITY);
       }
@@ -308,19 +318,19 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
   uint32_t ns = ld_agent(&ctl->n_slow_del);
   if (ns > slow_cap) ns = slow_cap;
   if (ns) {  // uniform
-    // decide every winner before any claim is released (the flag is parked in the item itself and
+    // decide every winner before any claim is released (the state is parked in the item itself and
     // re-read by the same thread)
     for (uint32_t j = tid; j < ns; j += nt) {
       const SlowDelete s = slow[j];
       const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
-      slow[j].pad = (ld_agent(&tab.claim[bucket]) == s.vis) ? 1 : 0;
+      slow[j].state = (ld_agent(&tab.claim[bucket]) == s.entry) ? 1 : 0;
     }
     __syncthreads();
     for (uint32_t j = tid; j < ns; j += nt) {
       const SlowDelete s = slow[j];
       const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
       tab.claim[bucket] = kInf;  // ResetLocks
-      if (!s.pad) continue;
+      if (!s.state) continue;
       const uint32_t k0 = key0(s.x, s.y), k1 = key1(s.z);
       uint32_t last = (bucket << 1) + 1;
       uint32_t* ph = reinterpret_cast<uint32_t*>(tab.entries + last);
@@ -362,9 +372,13 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
         }
       }
       if (freed >= 0) {
-        bitmap_set(bitmap, summary, s.vis);
-        const uint32_t slot = atomicAdd(&ctl->n_del, 1u);
-        if (slot < rel_cap) rel[slot] = Released{s.vis, freed};
+        slow[j].state = 2;
+        slow[j].freed = freed;
+        const uint32_t slot = atomicAdd(&n_list, 1u);
+        if (slot < kSmallCarve) {
+          del_entry[slot] = s.entry;
+          del_pool[slot] = freed;
+        }
       }
     }
     __syncthreads();
@@ -372,10 +386,28 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
   RATSDF_STAMP(ctl->stamps, 2);
   uint32_t upd = 0;
   (void)block_exclusive_scan(upd_part, lds, &upd);
-  uint32_t n_rel = ld_agent(&ctl->n_del);
-  if (n_rel > rel_cap) n_rel = rel_cap;
-  const int32_t nf = ctl->num_free;
-  if (n_rel) {  // uniform
+  const uint32_t n_del = n_list;  // uniform (read after the barriers above)
+  RATSDF_STAMP(ctl->stamps, 3);
+  if (n_del && n_del <= kSmallCarve) {
+    // rank of a delete = number of deleted entries below its own (all in LDS)
+    for (uint32_t w = tid; w < n_del; w += nt) {
+      const uint32_t mine = del_entry[w];
+      uint32_t k = 0;
+#pragma unroll 4
+      for (uint32_t j = 0; j < n_del; ++j) k += del_entry[j] < mine;
+      pool.heap[(uint32_t)nf + k] = del_pool[w];                          // voxel_mem.cu:56-60
+    }
+  } else if (n_del) {
+    for (uint32_t i = tid; i < nv; i += nt) {
+      const uint32_t info = blk_info[i];
+      if (!(info >> 31)) continue;
+      const VisItem it = vis[i];
+      if (it.entry == (block_hash(it.x, it.y, it.z, tab.bucket_mask) << 1))
+        bitmap_set(bitmap, summary, it.entry);
+    }
+    for (uint32_t j = tid; j < ns; j += nt)
+      if (slow[j].state == 2) bitmap_set(bitmap, summary, slow[j].entry);
+    __syncthreads();
     const uint32_t nwords = tab.num_entry >> 5;
     const uint32_t chunk = bitmap_chunk(nwords, nt);
     const uint32_t sum = chunk_popcount(bitmap, summary, nwords, chunk);
@@ -383,36 +415,44 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
     const uint32_t excl = block_exclusive_scan(sum, lds, &total);
     bitmap_write_prefix(bitmap, summary, prefix, nwords, chunk, sum, excl);
     __syncthreads();
-    RATSDF_STAMP(ctl->stamps, 3);
-    for (uint32_t j = tid; j < n_rel; j += nt) {
-      const Released r = rel[j];
-      pool.heap[(uint32_t)nf + bitmap_rank(bitmap, prefix, r.entry)] = r.idx;  // voxel_mem.cu:56-60
+    for (uint32_t i = tid; i < nv; i += nt) {
+      const uint32_t info = blk_info[i];
+      if (!(info >> 31)) continue;
+      const VisItem it = vis[i];
+      if (it.entry != (block_hash(it.x, it.y, it.z, tab.bucket_mask) << 1)) continue;
+      pool.heap[(uint32_t)nf + bitmap_rank(bitmap, prefix, it.entry)] = it.idx;
+    }
+    for (uint32_t j = tid; j < ns; j += nt) {
+      const SlowDelete s = slow[j];
+      if (s.state == 2) pool.heap[(uint32_t)nf + bitmap_rank(bitmap, prefix, s.entry)] = s.freed;
     }
     __syncthreads();  // every reader of the delete bitmap is done: leave it clean for the next pass
-    RATSDF_STAMP(ctl->stamps, 4);
     bitmap_clean(bitmap, summary, nwords);
   }
-  RATSDF_STAMP(ctl->stamps, 5);
+  RATSDF_STAMP(ctl->stamps, 4);
   if (tid == 0) {
-    ctl->num_free = nf + (int32_t)n_rel;
+    ctl->num_free = nf + (int32_t)n_del;
     if (stats) {
       stats->visible_blocks = (int32_t)nv;
       stats->updated_voxels = (int32_t)upd;
       stats->allocated_blocks = (int32_t)ctl->n_win;
-      stats->deleted_blocks = (int32_t)n_rel;
-      stats->active_blocks = tab.num_block - (nf + (int32_t)n_rel);
+      stats->deleted_blocks = (int32_t)n_del;
+      stats->active_blocks = tab.num_block - (nf + (int32_t)n_del);
       stats->slow_requests = (int32_t)ctl->n_slow;
       ctl->totals[0] += 1;
       ctl->totals[1] += nv;
       ctl->totals[2] += upd;
       ctl->totals[3] += ctl->n_win;
-      ctl->totals[4] += n_rel;
+      ctl->totals[4] += n_del;
     }
     // control block ready for the next pass (saves a memset node per frame)
     uint32_t* z = reinterpret_cast<uint32_t*>(ctl);
     for (int i = 0; i < kCtlFrameBytes / 4; ++i) z[i] = 0;
   }
-  RATSDF_STAMP(ctl->stamps, 6);
+  RATSDF_STAMP(ctl->stamps, 5);
+#ifdef RATSDF_STAMPS
+  if (threadIdx.x == 0) ctl->stamps[21] += wall_clock64();
+#endif
 }
 
 }  // namespace ratsdf

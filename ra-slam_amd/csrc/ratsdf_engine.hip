@@ -68,11 +68,11 @@ struct ratsdf_engine {
   uint2* texB = nullptr;
   Request* req = nullptr;
   uint32_t req_cap = 0;
-  uint32_t* abitmap[2] = {nullptr, nullptr};   // rank bitmaps (padded to whole 32-word groups)
-  uint32_t* asummary[2] = {nullptr, nullptr};  // one bit per group
+  uint32_t* abitmap = nullptr;   // rank bitmap, many-request path only (whole 32-word groups)
+  uint32_t* asummary = nullptr;  // one bit per group
+  uint32_t* req_k = nullptr;     // rank among the winners, per request
   uint32_t* aprefix = nullptr;       // per-word prefix of the rank bitmap (set groups only)
   uint32_t awords_cap = 0, asum_words = 0;
-  int apass = 0;
 
   SlowRequest* slow = nullptr;
   XLock* xlocks = nullptr;
@@ -87,7 +87,6 @@ struct ratsdf_engine {
   uint32_t* dbitmap = nullptr;   // delete bitmap indexed by hash entry (self-cleaning)
   uint32_t* dsummary = nullptr;
   uint32_t* dprefix = nullptr;
-  Released* rel = nullptr;       // (entry, pool idx) of this pass's successful deletes
   uint32_t vis_cap = 0;
   uint32_t dwords = 0;
   SlowDelete* slowdel = nullptr;
@@ -140,9 +139,9 @@ FrameParams ratsdf_engine::base_params() const {
 int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
   void* ptrs[] = {tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
-                  d_stats, texA, texB, req, abitmap[0], abitmap[1], asummary[0], asummary[1], aprefix,
+                  d_stats, texA, texB, req, req_k, abitmap, asummary, aprefix,
                   slow, xlocks,
-                  distinct, masks, wg_count, vis, carve_flag, dbitmap, dsummary, dprefix, rel,
+                  distinct, masks, wg_count, vis, carve_flag, dbitmap, dsummary, dprefix,
                   slowdel, d_stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -167,30 +166,25 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
   }
   if (nranks > rank_cap) {
     if (req) (void)hipFree(req);
-    if (abitmap[0]) (void)hipFree(abitmap[0]);
-    if (abitmap[1]) (void)hipFree(abitmap[1]);
-    if (asummary[0]) (void)hipFree(asummary[0]);
-    if (asummary[1]) (void)hipFree(asummary[1]);
+    if (req_k) (void)hipFree(req_k);
+    if (abitmap) (void)hipFree(abitmap);
+    if (asummary) (void)hipFree(asummary);
     if (aprefix) (void)hipFree(aprefix);
     req_cap = (uint32_t)nranks;
     awords_cap = (uint32_t)((nranks + 31) / 32);
     awords_cap = (awords_cap + kGroupWords - 1) / kGroupWords * kGroupWords;
     asum_words = (awords_cap / kGroupWords + 31) / 32;
     HIPCHK(hipMalloc(&req, (size_t)req_cap * sizeof(Request)));
-    HIPCHK(hipMalloc(&abitmap[0], (size_t)awords_cap * 4));
-    HIPCHK(hipMalloc(&abitmap[1], (size_t)awords_cap * 4));
-    HIPCHK(hipMalloc(&asummary[0], (size_t)asum_words * 4));
-    HIPCHK(hipMalloc(&asummary[1], (size_t)asum_words * 4));
+    HIPCHK(hipMalloc(&req_k, (size_t)req_cap * 4));
+    HIPCHK(hipMalloc(&abitmap, (size_t)awords_cap * 4));
+    HIPCHK(hipMalloc(&asummary, (size_t)asum_words * 4));
     HIPCHK(hipMalloc(&aprefix, (size_t)awords_cap * 4));
     rank_cap = nranks;
   }
-  // Each pass's scan kernel cleans the other bitmap only over the current rank space, so both must
-  // be cleaned whenever the rank space (image size / list length) changes.
+  // the rank bitmap cleans itself after every use; start from a clean one when (re)allocated
   if (nranks != cur_nranks) {
-    HIPCHK(hipMemsetAsync(abitmap[0], 0, (size_t)awords_cap * 4, stream));
-    HIPCHK(hipMemsetAsync(abitmap[1], 0, (size_t)awords_cap * 4, stream));
-    HIPCHK(hipMemsetAsync(asummary[0], 0, (size_t)asum_words * 4, stream));
-    HIPCHK(hipMemsetAsync(asummary[1], 0, (size_t)asum_words * 4, stream));
+    HIPCHK(hipMemsetAsync(abitmap, 0, (size_t)awords_cap * 4, stream));
+    HIPCHK(hipMemsetAsync(asummary, 0, (size_t)asum_words * 4, stream));
     cur_nranks = nranks;
   }
   return RATSDF_OK;
@@ -215,17 +209,16 @@ int ratsdf_engine::ensure_stage(size_t npix) {
 int ratsdf_engine::alloc_rank(uint32_t nranks) {
   const uint32_t nwords = (nranks + 31) / 32;
   hipLaunchKernelGGL(k_alloc_rank, dim3(1), dim3(1024), kSlowSortCap * sizeof(unsigned long long),
-                     stream, tab, req, req_cap, slow, kSlowCap, xlocks, distinct, abitmap[apass & 1],
-                     asummary[apass & 1], aprefix, nwords, abitmap[(apass + 1) & 1],
-                     asummary[(apass + 1) & 1], ctl);
+                     stream, tab, req, req_cap, req_k, slow, kSlowCap, xlocks, distinct, abitmap,
+                     asummary, aprefix, nwords, ctl);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
 
 int ratsdf_engine::carve_tail(bool is_frame) {
   hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, stream, tab, pool, vis, vis_cap, carve_flag,
-                     dbitmap, dsummary, dprefix, rel, (uint32_t)tab.num_block, slowdel, kSlowDelCap,
-                     ctl, is_frame ? d_stats : (ratsdf_frame_stats*)nullptr);
+                     dbitmap, dsummary, dprefix, slowdel, kSlowDelCap, ctl,
+                     is_frame ? d_stats : (ratsdf_frame_stats*)nullptr);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
@@ -264,13 +257,11 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
 
   // the control block was zeroed by the previous pass's last kernel (k_carve) or at creation
   const unsigned n_pix_wg = (unsigned)((npix + 255) / 256);
-  hipLaunchKernelGGL(k_front, dim3(n_pix_wg + nwg), dim3(256), 0, stream, tab, P, n_pix_wg,
+  hipLaunchKernelGGL(k_front, dim3(nwg + n_pix_wg), dim3(256), 0, stream, tab, P, nwg,
                      (const float*)d_depth, (const uint8_t*)d_rgb, (const float*)d_ht,
                      (const float*)d_lt, texA, texB, req, req_cap, slow, kSlowCap, vis, vis_cap, ctl);
   st = alloc_rank((uint32_t)(npix * (size_t)S));
   if (st != RATSDF_OK) return st;
-  const uint32_t* bm = abitmap[apass & 1];
-  ++apass;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (profiling) {
@@ -288,15 +279,15 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
   switch (vpl) {
     case 8:
       hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, vis_cap, req, req_cap, bm, aprefix, texA, texB, carve_flag, ctl);
+                         vis, vis_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
       break;
     case 4:
       hipLaunchKernelGGL(k_integrate<4>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, vis_cap, req, req_cap, bm, aprefix, texA, texB, carve_flag, ctl);
+                         vis, vis_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
       break;
     default:
       hipLaunchKernelGGL(k_integrate<2>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, vis_cap, req, req_cap, bm, aprefix, texA, texB, carve_flag, ctl);
+                         vis, vis_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
   }
   if (profiling) HIPCHK(hipEventRecord(ev1, stream));
 
@@ -405,7 +396,6 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->dbitmap, (size_t)e->dwords * 4));
   CREATE_CHK(hipMalloc(&e->dsummary, (size_t)dsum_words * 4));
   CREATE_CHK(hipMalloc(&e->dprefix, (size_t)e->dwords * 4));
-  CREATE_CHK(hipMalloc(&e->rel, (size_t)t.num_block * sizeof(Released)));
   CREATE_CHK(hipMalloc(&e->slowdel, (size_t)kSlowDelCap * sizeof(SlowDelete)));
   // voxel memory starts zeroed (defined value for the reference's uninitialised rgb)
   CREATE_CHK(hipMemsetAsync(e->pool.rgbw, 0, nvox * 4, e->stream));
@@ -535,10 +525,13 @@ extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
   HIPCHK(hipStreamSynchronize(e->stream));
   const double n = tot[0] ? (double)tot[0] : 1.0;
   fprintf(stderr, "[stamps] frames=%llu  carve phases (cycles/frame):", tot[0]);
-  for (int i = 1; i <= 6; ++i) fprintf(stderr, " %d:%.0f", i, (double)(t[i] - t[i - 1]) / n);
+  for (int i = 1; i <= 5; ++i) fprintf(stderr, " %d:%.0f", i, (double)(t[i] - t[i - 1]) / n);
   fprintf(stderr, "\n[stamps] rank phases: read_n:%.0f mark:%.0f scan:%.0f tail:%.0f\n",
           (double)(t[12] - t[8]) / n, (double)(t[9] - t[12]) / n, (double)(t[10] - t[9]) / n,
           (double)(t[11] - t[10]) / n);
+  fprintf(stderr, "[stamps] k_carve: %.0f shader cycles in %.0f wall ticks (100 MHz) -> %.2f GHz\n",
+          (double)(t[5] - t[0]) / n, (double)(t[21] - t[20]) / n,
+          (double)(t[5] - t[0]) / (double)(t[21] - t[20]) * 0.1);
   return RATSDF_OK;
 }
 
@@ -674,8 +667,7 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
                      e->req, e->req_cap, e->slow, kSlowCap, e->ctl);
   st = e->alloc_rank((uint32_t)n);
   hipLaunchKernelGGL(k_commit_only, dim3(256), dim3(256), 0, e->stream, e->tab, e->pool, e->req,
-                     e->req_cap, e->abitmap[e->apass & 1], e->aprefix, e->ctl);
-  ++e->apass;
+                     e->req_cap, e->req_k, e->ctl);
   // frames expect a clean control block (normally left behind by k_carve)
   HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
   const int st2 = e->sticky();
