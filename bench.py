@@ -107,7 +107,9 @@ def main():
         from parity import assert_maps_equal
         from ratsdf._abi import Engine
         ncpu = min(a.cpu_frames, len(frames))
-        cores = os.cpu_count() or 1
+        # the 1-GPU box exposes every host CPU but grants a 16-core share; use that many threads
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16")))
         cpu = Engine(load_oracle(), vs, 6 * vs, threads=cores)
         chk = ratsdf.TSDFGrid(vs, 6 * vs, device=local_rank)
         t0 = time.perf_counter()
