@@ -149,12 +149,19 @@ def main():
         ev2.record(torch.cuda.current_stream())
         ext.wait_event(ev2)
 
+    batch = eng.make_batch([t.data_ptr() for t in d_rgb], [t.data_ptr() for t in d_depth],
+                           [t.data_ptr() for t in d_ht], [t.data_ptr() for t in d_lt], H, W,
+                           a.max_depth, intr, pose)
+
     def step():
-        for i in range(len(frames)):
-            eng.integrate_device(d_rgb[i].data_ptr(), d_depth[i].data_ptr(), d_ht[i].data_ptr(),
-                                 d_lt[i].data_ptr(), H, W, a.max_depth, intr[i], pose[i])
-            if a.sync_every and (i + 1) % a.sync_every == 0:
-                eng.synchronize()
+        if a.sync_every:
+            for i in range(len(frames)):
+                eng.integrate_device(d_rgb[i].data_ptr(), d_depth[i].data_ptr(), d_ht[i].data_ptr(),
+                                     d_lt[i].data_ptr(), H, W, a.max_depth, intr[i], pose[i])
+                if (i + 1) % a.sync_every == 0:
+                    eng.synchronize()
+        else:
+            eng.integrate_device_batch(batch)  # one C call enqueues the step's frames in order
         if world > 1:
             exchange()
 

@@ -140,6 +140,16 @@ int ratsdf_integrate_device(ratsdf_engine* e, const void* d_rgb, const void* d_d
                             const void* d_ht, const void* d_lt, int height, int width,
                             float max_depth, const ratsdf_intrinsics* intrinsics,
                             const ratsdf_pose* cam_T_world);
+/* n consecutive frames of one stream, all inputs resident in HBM: d_rgb/d_depth/d_ht/d_lt are host
+ * arrays of n device pointers (d_ht / d_lt may be NULL = no semantics), intrinsics and cam_T_world
+ * are host arrays of n elements.  Equivalent to n calls of ratsdf_integrate_device in order (what the
+ * reference's TSDFSystem worker does with its queue, modules/tsdf_module.cc:88-115), without the
+ * per-call cost of crossing a language boundary.  HIP engine only. */
+int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_rgb,
+                                  const void* const* d_depth, const void* const* d_ht,
+                                  const void* const* d_lt, int height, int width, float max_depth,
+                                  const ratsdf_intrinsics* intrinsics,
+                                  const ratsdf_pose* cam_T_world);
 /* cudaStreamSynchronize(stream_), voxel_tsdf.cu:450; also surfaces sticky device-side errors
  * (pool exhausted, work-list overflow). */
 int ratsdf_synchronize(ratsdf_engine* e);

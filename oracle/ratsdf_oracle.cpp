@@ -646,6 +646,11 @@ int ratsdf_oracle_integrate_device(ratsdf_engine*, const void*, const void*, con
                                    const ratsdf_pose*) {
   return RATSDF_ERR_NOT_IMPLEMENTED;
 }
+int ratsdf_oracle_integrate_device_batch(ratsdf_engine*, int, const void* const*, const void* const*,
+                                         const void* const*, const void* const*, int, int, float,
+                                         const ratsdf_intrinsics*, const ratsdf_pose*) {
+  return RATSDF_ERR_NOT_IMPLEMENTED;
+}
 int ratsdf_oracle_synchronize(ratsdf_engine* e) { return e ? e->sticky : RATSDF_ERR_BAD_ARGUMENT; }
 int ratsdf_oracle_stream(ratsdf_engine*, void** s) {
   if (s) *s = nullptr;

@@ -449,6 +449,23 @@ int ratsdf_integrate_device(ratsdf_engine* e, const void* d_rgb, const void* d_d
   return e->frame(d_rgb, d_depth, d_ht, d_lt, height, width, max_depth, K, T);
 }
 
+int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_rgb,
+                                  const void* const* d_depth, const void* const* d_ht,
+                                  const void* const* d_lt, int height, int width, float max_depth,
+                                  const ratsdf_intrinsics* K, const ratsdf_pose* T) {
+  if (!e || n < 0 || (n > 0 && (!d_rgb || !d_depth || !K || !T)) || height <= 0 || width <= 0)
+    return RATSDF_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < n; ++i) {
+    const void* ht = (d_ht && d_lt) ? d_ht[i] : nullptr;
+    const void* lt = (d_ht && d_lt) ? d_lt[i] : nullptr;
+    if (!d_rgb[i] || !d_depth[i]) return RATSDF_ERR_BAD_ARGUMENT;
+    if (!ht || !lt) ht = lt = nullptr;
+    const int st = e->frame(d_rgb[i], d_depth[i], ht, lt, height, width, max_depth, &K[i], &T[i]);
+    if (st != RATSDF_OK) return st;
+  }
+  return RATSDF_OK;
+}
+
 int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, const float* ht,
                      const float* lt, int height, int width, float max_depth,
                      const ratsdf_intrinsics* K, const ratsdf_pose* T) {

@@ -65,7 +65,8 @@ assert VOXEL_SEGM_DTYPE.itemsize == 20 and RGBW_DTYPE.itemsize == 4
 
 # every symbol include/ratsdf.h declares (without prefix)
 SYMBOLS = [
-    "create", "create_ex", "destroy", "integrate", "integrate_device", "synchronize", "stream",
+    "create", "create_ex", "destroy", "integrate", "integrate_device", "integrate_device_batch",
+    "synchronize", "stream",
     "profile_enable", "profile_read", "totals",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "export_directory_device", "test_allocate", "test_delete",
@@ -99,6 +100,8 @@ class Library:
         self.fn["integrate"].argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float,
                                          C.POINTER(Intrinsics), C.POINTER(Pose)]
         self.fn["integrate_device"].argtypes = self.fn["integrate"].argtypes
+        self.fn["integrate_device_batch"].argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
+                                                      C.c_float, vp, vp]
         self.fn["synchronize"].argtypes = [vp]
         self.fn["stream"].argtypes = [vp, C.POINTER(vp)]
         self.fn["profile_enable"].argtypes = [vp, C.c_int]
@@ -219,6 +222,21 @@ class Engine:
                                              height, width, float(max_depth), C.byref(k),
                                              C.byref(p))
         _check(st, "integrate_device")
+
+    def make_batch(self, d_rgb, d_depth, d_ht, d_lt, height, width, max_depth, intrinsics, poses):
+        """Pre-marshals n frames (lists of raw device pointers, intrinsics, poses) for
+        integrate_device_batch; returns an opaque tuple that can be replayed many times."""
+        n = len(d_rgb)
+        arr = lambda ptrs: (C.c_void_p * n)(*ptrs) if ptrs is not None else None
+        ks = (Intrinsics * n)(*[_as_intr(k) for k in intrinsics])
+        ps = (Pose * n)(*[_as_pose(p) for p in poses])
+        return (n, arr(d_rgb), arr(d_depth), arr(d_ht), arr(d_lt), int(height), int(width),
+                float(max_depth), ks, ps)
+
+    def integrate_device_batch(self, batch):
+        n, rgb, depth, ht, lt, h, w, md, ks, ps = batch
+        st = self.lib.fn["integrate_device_batch"](self._h, n, rgb, depth, ht, lt, h, w, md, ks, ps)
+        _check(st, "integrate_device_batch")
 
     def synchronize(self):
         _check(self.lib.fn["synchronize"](self._h), "synchronize")
