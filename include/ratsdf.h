@@ -186,6 +186,19 @@ int ratsdf_gather_valid_semantic(ratsdf_engine* e, ratsdf_voxel_segm** out, size
 int ratsdf_download_all(ratsdf_engine* e, const char* file_path);
 int ratsdf_free_buffer(void* p);
 
+/* ---- rendering ------------------------------------------------------------------ */
+/* TSDFGrid::RayCast(max_depth, virtual_cam, cam_T_world, tsdf_rgba, tsdf_normal),
+ * utils/tsdf/voxel_tsdf.cu:278-374,885-902 == TSDFSystem::Render (modules/tsdf_module.cc:45-55, which
+ * passes 2 * max_depth).  The reference writes two uchar4 images into OpenGL textures through
+ * CUDA-GL interop (utils/gl/image.cc:108-119); here they are written to host buffers of
+ * height*width*4 bytes (either may be NULL).  Step size is truncation / 2 (voxel_tsdf.cu:892). */
+int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* virtual_cam, int height, int width,
+                   const ratsdf_pose* cam_T_world, float max_depth, uint8_t* rgba, uint8_t* normal);
+/* Same, output to device buffers, asynchronous on the engine's stream.  HIP engine only. */
+int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* virtual_cam, int height,
+                          int width, const ratsdf_pose* cam_T_world, float max_depth, void* d_rgba,
+                          void* d_normal);
+
 /* ---- multi-GPU support --------------------------------------------------------------------- */
 /* Writes the compact block directory (allocated entries in ascending entry order, 12 B each) into a
  * caller-provided DEVICE buffer so it can be all-gathered with RCCL without touching the host.

@@ -540,6 +540,112 @@ struct ratsdf_engine {
     return -1;
   }
 
+  // ---- Retrieve<Voxel>(point, cache): value lookups used by the ray caster ---------------------
+  inline float voxel_tsdf_at(const S3& p, Entry& cache) const {
+    const long vi = retrieve_index(p, cache);
+    return vi >= 0 ? tsdf[vi] : -10.f;  // VoxelTSDF() default, voxel_types.cu:8
+  }
+  // VoxelHashTable::RetrieveTSDF, voxel_hash.cu:161-188 (corner / weight pairing as written there)
+  float retrieve_tsdf(const V3& pt, Entry& cache) const {
+    const V3 pl{floorf(pt.x), floorf(pt.y), floorf(pt.z)};
+    const V3 ph{pl.x + 1.f, pl.y + 1.f, pl.z + 1.f};
+    const V3 al{ph.x - pt.x, ph.y - pt.y, ph.z - pt.z};
+    float t[8];
+    for (int i = 0; i < 8; ++i) {
+      const S3 c{f2s((i >> 2) & 1 ? pl.x : ph.x), f2s((i >> 1) & 1 ? pl.y : ph.y),
+                 f2s((i >> 0) & 1 ? pl.z : ph.z)};
+      t[i] = voxel_tsdf_at(c, cache);
+    }
+    const float t00 = t[0] * al.z + t[1] * (1 - al.z);
+    const float t01 = t[2] * al.z + t[3] * (1 - al.z);
+    const float t10 = t[4] * al.z + t[5] * (1 - al.z);
+    const float t11 = t[6] * al.z + t[7] * (1 - al.z);
+    const float t0 = t00 * al.y + t01 * (1 - al.y);
+    const float t1 = t10 * al.y + t11 * (1 - al.y);
+    return t0 * al.x + t1 * (1 - al.x);
+  }
+
+  // ---- ray_cast_kernel, voxel_tsdf.cu:278-374 ---------------------------------------------------
+  void raycast(const Intr& K, int H, int W, const Se3& T, float max_depth, uint8_t* rgba,
+               uint8_t* normal) {
+    const Se3 Ti = T.inverse();
+    const Intr Ki = K.inverse();
+    const float step_size = trunc / 2;  // voxel_tsdf.cu:892
+    const int max_step = f2i(ceilf(max_depth / step_size));
+    parallel_for((size_t)H, [&](size_t ylo, size_t yhi, int) {
+      for (size_t y = ylo; y < yhi; ++y)
+        for (int x = 0; x < W; ++x) {
+          const size_t idx = y * W + x;
+          uint8_t out_c[4] = {0, 0, 0, 0}, out_n[4] = {0, 0, 0, 0};
+          const V3 pc = Ki.mul(V3{(float)x, (float)y, 1.f});
+          const float n2 = pc.x * pc.x + (pc.y * pc.y + pc.z * pc.z);
+          V3 dc = pc;  // Eigen normalized(): v / sqrt(squaredNorm) when squaredNorm > 0
+          if (n2 > 0.f) {
+            const float nn = std::sqrt(n2);
+            dc = V3{pc.x / nn, pc.y / nn, pc.z / nn};
+          }
+          const V3 dw = qrot(Ti.q, dc);
+          const V3 full{dw.x * step_size / vs, dw.y * step_size / vs, dw.z * step_size / vs};
+          V3 stepv = full;
+          V3 p{Ti.t.x / vs, Ti.t.y / vs, Ti.t.z / vs};
+          Entry cache{{0, 0, 0}, 0, -1};
+          auto rnd = [](const V3& v) { return S3{f2s(roundf(v.x)), f2s(roundf(v.y)), f2s(roundf(v.z))}; };
+          float prev = voxel_tsdf_at(rnd(p), cache);
+          p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
+          for (int i = 1; i < max_step; ++i) {
+            const S3 g = rnd(p);
+            const float cur = voxel_tsdf_at(g, cache);
+            const long wi = retrieve_index(g, cache);
+            const uint8_t wcur = wi >= 0 ? rgbw[wi].weight : (uint8_t)0;
+            if (wcur < 10) {
+              p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
+              prev = cur;
+              continue;
+            }
+            if (prev > 0 && cur <= 0 && prev - cur <= 2.0f) {
+              const V3 p1{p.x - stepv.x, p.y - stepv.y, p.z - stepv.z};
+              const float ac = retrieve_tsdf(p, cache);
+              const float ap = retrieve_tsdf(p1, cache);
+              const float f = ac / (ap - ac);
+              const V3 pi{p.x + f * stepv.x, p.y + f * stepv.y, p.z + f * stepv.z};
+              const S3 fg = rnd(pi);
+              const long vi = retrieve_index(fg, cache);
+              const ratsdf_rgbw c = vi >= 0 ? rgbw[vi] : ratsdf_rgbw{0, 0, 0, 0};
+              const float prob = vi >= 0 ? segm[vi] : 0.f;
+              auto at = [&](int dx, int dy, int dz) {
+                return voxel_tsdf_at(S3{(int16_t)(fg.x + dx), (int16_t)(fg.y + dy), (int16_t)(fg.z + dz)},
+                                     cache);
+              };
+              const V3 nr{at(1, 0, 0) - at(-1, 0, 0), at(0, 1, 0) - at(0, -1, 0),
+                          at(0, 0, 1) - at(0, 0, -1)};
+              const float dotv = nr.x * (-dw.x) + (nr.y * (-dw.y) + nr.z * (-dw.z));
+              const float nn = std::sqrt(nr.x * nr.x + (nr.y * nr.y + nr.z * nr.z));
+              const float diff = fmaxf(dotv / nn, 0);
+              const float alpha = fmaxf(prob - 0.5f, 0) / .5f;
+              out_c[0] = (uint8_t)f2i(alpha * 255 + (1 - alpha) * (float)c.r);
+              out_c[1] = (uint8_t)f2i((1 - alpha) * (float)c.g);
+              out_c[2] = (uint8_t)f2i((1 - alpha) * (float)c.b);
+              out_c[3] = 255;
+              out_n[0] = (uint8_t)f2i(alpha * 255 + (1 - alpha) * diff * 255);
+              out_n[1] = (uint8_t)f2i((1 - alpha) * diff * 255);
+              out_n[2] = out_n[1];
+              out_n[3] = 255;
+              break;
+            }
+            prev = cur;
+            if (cur < 0.5f) {
+              stepv = V3{full.x / 10, full.y / 10, full.z / 10};
+            } else {
+              stepv = full;
+            }
+            p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
+          }
+          if (rgba) memcpy(rgba + idx * 4, out_c, 4);
+          if (normal) memcpy(normal + idx * 4, out_n, 4);
+        }
+    });
+  }
+
   template <class Rec, bool Semantic>
   int download(const std::vector<Entry>& blocks, Rec** out, size_t* n) {
     const size_t cnt = blocks.size() * RATSDF_BLOCK_VOLUME;
@@ -742,6 +848,18 @@ int ratsdf_oracle_download_all(ratsdf_engine* e, const char* path) {
 int ratsdf_oracle_free_buffer(void* p) {
   free(p);
   return RATSDF_OK;
+}
+
+int ratsdf_oracle_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
+                          const ratsdf_pose* P, float max_depth, uint8_t* rgba, uint8_t* normal) {
+  if (!e || !K || !P || height <= 0 || width <= 0 || !(max_depth > 0)) return RATSDF_ERR_BAD_ARGUMENT;
+  e->raycast(Intr{K->fx, K->fy, K->cx, K->cy}, height, width,
+             Se3{{P->qx, P->qy, P->qz, P->qw}, {P->tx, P->ty, P->tz}}, max_depth, rgba, normal);
+  return RATSDF_OK;
+}
+int ratsdf_oracle_raycast_device(ratsdf_engine*, const ratsdf_intrinsics*, int, int,
+                                 const ratsdf_pose*, float, void*, void*) {
+  return RATSDF_ERR_NOT_IMPLEMENTED;
 }
 
 int ratsdf_oracle_export_directory_device(ratsdf_engine*, void*, int32_t, void*) {

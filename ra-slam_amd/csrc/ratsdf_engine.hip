@@ -12,7 +12,7 @@
 #include <new>
 #include <vector>
 
-#include "kernels_integrate.h"
+#include "kernels_raycast.h"
 
 using namespace ratsdf;
 
@@ -650,6 +650,45 @@ int ratsdf_download_all(ratsdf_engine* e, const char* path) {
 int ratsdf_free_buffer(void* p) {
   free(p);
   return RATSDF_OK;
+}
+
+int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
+                          const ratsdf_pose* T, float max_depth, void* d_rgba, void* d_normal) {
+  if (!e || !K || !T || height <= 0 || width <= 0 || !(max_depth > 0))
+    return RATSDF_ERR_BAD_ARGUMENT;
+  FrameParams P = e->base_params();
+  P.T = Se3{Quat{T->qx, T->qy, T->qz, T->qw}, V3{T->tx, T->ty, T->tz}};
+  P.Ti = se3_inverse(P.T);                      // voxel_tsdf.cu:892 cam_T_world.Inverse()
+  P.K = Intr{K->fx, K->fy, K->cx, K->cy};
+  P.Ki = intr_inverse(P.K);
+  P.W = width;
+  P.H = height;
+  const float step_size = e->trunc / 2;         // voxel_tsdf.cu:892
+  const float ms = ceilf(max_depth / step_size);
+  const int max_step = ms >= 2147483648.f ? 2147483647 : (int)ms;  // voxel_tsdf.cu:298
+  hipLaunchKernelGGL(k_raycast, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, e->stream,
+                     e->tab, e->pool, P, step_size, max_step, (uint32_t*)d_rgba, (uint32_t*)d_normal);
+  HIPCHK(hipGetLastError());
+  return RATSDF_OK;
+}
+
+int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
+                   const ratsdf_pose* T, float max_depth, uint8_t* rgba, uint8_t* normal) {
+  if (!e || height <= 0 || width <= 0) return RATSDF_ERR_BAD_ARGUMENT;
+  const size_t bytes = (size_t)height * width * 4;
+  uint8_t* d = nullptr;
+  HIPCHK(hipMalloc(&d, bytes * 2));
+  int st = ratsdf_raycast_device(e, K, height, width, T, max_depth, d, d + bytes);
+  if (st == RATSDF_OK) {
+    hipError_t err = hipSuccess;
+    if (rgba) err = hipMemcpyAsync(rgba, d, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess && normal)
+      err = hipMemcpyAsync(normal, d + bytes, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);  // voxel_tsdf.cu:901
+    if (err != hipSuccess) st = RATSDF_ERR_DEVICE;
+  }
+  (void)hipFree(d);
+  return st;
 }
 
 int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t capacity,

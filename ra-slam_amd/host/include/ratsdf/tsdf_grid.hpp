@@ -19,6 +19,8 @@ struct Api {
   int (*gather_valid)(ratsdf_engine*, ratsdf_voxel_tsdf**, size_t*) = nullptr;
   int (*gather_valid_semantic)(ratsdf_engine*, ratsdf_voxel_segm**, size_t*) = nullptr;
   int (*download_all)(ratsdf_engine*, const char*) = nullptr;
+  int (*raycast)(ratsdf_engine*, const ratsdf_intrinsics*, int, int, const ratsdf_pose*, float,
+                 uint8_t*, uint8_t*) = nullptr;
   int (*free_buffer)(void*) = nullptr;
   int (*num_active_blocks)(ratsdf_engine*, int32_t*) = nullptr;
   const char* (*status_string)(int) = nullptr;
@@ -41,6 +43,10 @@ class TSDFGrid {
   void Integrate(const Image& img_rgb, const Image& img_depth, const Image& img_ht,
                  const Image& img_lt, float max_depth, const CameraIntrinsics<float>& intrinsics,
                  const SE3<float>& cam_T_world);
+  // voxel_tsdf.cuh:78-79; the two uchar4 images go to host buffers (H*W*4 bytes each, may be null)
+  // instead of GLImage8UC4 textures
+  void RayCast(float max_depth, const CameraParams& virtual_cam, const SE3<float>& cam_T_world,
+               uint8_t* tsdf_rgba = nullptr, uint8_t* tsdf_normal = nullptr);
   std::vector<VoxelSpatialTSDF> GatherValid();                                   // :86
   std::vector<VoxelSpatialTSDFSEGM> GatherValidSemantic();                       // :93
   std::vector<VoxelSpatialTSDF> GatherVoxels(const BoundingCube<float>& volumn);  // :102

@@ -11,7 +11,8 @@
 //     the reference (tsdf_module.cc:91-94,119-125).  Knowingly fixed: terminate() is idempotent
 //     (the reference's destructor joins a second time and would throw), and Flush() is added so a
 //     harness can wait for the queue to drain first.
-//   * Render / DownloadAllMesh (ray casting, marching cubes) are outside this build's scope.
+//   * Render writes into host buffers instead of OpenGL textures; DownloadAllMesh (marching cubes)
+//     is outside this build's scope.
 #pragma once
 #include <condition_variable>
 #include <memory>
@@ -43,6 +44,11 @@ class TSDFSystem {
   void Integrate(const SE3<float>& posecam_T_world, const Image& img_rgb, const Image& img_depth,
                  const Image& img_ht = {}, const Image& img_lt = {});
   std::vector<VoxelSpatialTSDF> Query(const BoundingCube<float>& volumn);
+  // tsdf_module.h:87-99: rgba / normal-shaded views of the map; host buffers replace GLImage8UC4
+  void Render(const CameraParams& virtual_cam, const SE3<float> cam_T_world, uint8_t* img_rgba,
+              uint8_t* img_normal);
+  void Render(const CameraParams& virtual_cam, const SE3<float> cam_T_world, uint8_t* img_rgba,
+              uint8_t* img_normal, float max_depth);
   void DownloadAll(const std::string& file_path);
   bool is_terminated();
   void terminate();

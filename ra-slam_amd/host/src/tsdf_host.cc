@@ -57,6 +57,7 @@ const Api& Api::Load(const char* path, const char* prefix) {
   api.gather_valid_semantic =
       reinterpret_cast<decltype(api.gather_valid_semantic)>(sym("gather_valid_semantic"));
   api.download_all = reinterpret_cast<decltype(api.download_all)>(sym("download_all"));
+  api.raycast = reinterpret_cast<decltype(api.raycast)>(sym("raycast"));
   api.free_buffer = reinterpret_cast<decltype(api.free_buffer)>(sym("free_buffer"));
   api.num_active_blocks = reinterpret_cast<decltype(api.num_active_blocks)>(sym("num_active_blocks"));
   api.status_string = reinterpret_cast<decltype(api.status_string)>(sym("status_string"));
@@ -100,6 +101,16 @@ void TSDFGrid::Integrate(const Image& rgb, const Image& depth, const Image& ht, 
                        lt.empty() ? nullptr : static_cast<const float*>(lt.data), depth.rows,
                        depth.cols, max_depth, &k, &p),
        "Integrate");
+}
+
+void TSDFGrid::RayCast(float max_depth, const CameraParams& cam, const SE3<float>& cam_T_world,
+                       uint8_t* tsdf_rgba, uint8_t* tsdf_normal) {
+  if (!engine_) return;
+  const ratsdf_intrinsics k{cam.intrinsics.fx, cam.intrinsics.fy, cam.intrinsics.cx,
+                            cam.intrinsics.cy};
+  const ratsdf_pose p = cam_T_world.abi();
+  note(api_->raycast(engine_, &k, cam.img_h, cam.img_w, &p, max_depth, tsdf_rgba, tsdf_normal),
+       "RayCast");
 }
 
 std::vector<VoxelSpatialTSDF> TSDFGrid::GatherValid() {
@@ -190,6 +201,18 @@ void TSDFSystem::Integrate(const SE3<float>& posecam_T_world, const Image& rgb, 
 std::vector<VoxelSpatialTSDF> TSDFSystem::Query(const BoundingCube<float>& volumn) {
   std::lock_guard<std::mutex> lock(mtx_read_);
   return tsdf_.GatherVoxels(volumn);
+}
+
+void TSDFSystem::Render(const CameraParams& virtual_cam, const SE3<float> cam_T_world,
+                        uint8_t* img_rgba, uint8_t* img_normal) {
+  std::lock_guard<std::mutex> lock(mtx_read_);
+  tsdf_.RayCast(max_depth_ * 2, virtual_cam, cam_T_world, img_rgba, img_normal);  // tsdf_module.cc:45-49
+}
+
+void TSDFSystem::Render(const CameraParams& virtual_cam, const SE3<float> cam_T_world,
+                        uint8_t* img_rgba, uint8_t* img_normal, float max_depth) {
+  std::lock_guard<std::mutex> lock(mtx_read_);
+  tsdf_.RayCast(max_depth, virtual_cam, cam_T_world, img_rgba, img_normal);       // tsdf_module.cc:51-55
 }
 
 void TSDFSystem::DownloadAll(const std::string& file_path) {

@@ -69,7 +69,7 @@ SYMBOLS = [
     "synchronize", "stream",
     "profile_enable", "profile_read", "totals",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
-    "download_all", "free_buffer", "export_directory_device", "test_allocate", "test_delete",
+    "download_all", "free_buffer", "raycast", "raycast_device", "export_directory_device", "test_allocate", "test_delete",
     "test_retrieve", "test_assign_rgbw", "dump_directory", "dump_voxels", "dump_heap",
     "status_string", "backend",
 ]
@@ -114,6 +114,9 @@ class Library:
         self.fn["gather_valid_semantic"].argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         self.fn["download_all"].argtypes = [vp, C.c_char_p]
         self.fn["free_buffer"].argtypes = [vp]
+        self.fn["raycast"].argtypes = [vp, C.POINTER(Intrinsics), C.c_int, C.c_int, C.POINTER(Pose),
+                                       C.c_float, vp, vp]
+        self.fn["raycast_device"].argtypes = self.fn["raycast"].argtypes
         self.fn["export_directory_device"].argtypes = [vp, vp, C.c_int32, vp]
         self.fn["test_allocate"].argtypes = [vp, vp, C.c_int32]
         self.fn["test_delete"].argtypes = [vp, vp, C.c_int32]
@@ -303,6 +306,16 @@ class Engine:
 
     def download_all(self, path):
         _check(self.lib.fn["download_all"](self._h, str(path).encode()), "download_all")
+
+    def raycast(self, intrinsics, height, width, pose, max_depth):
+        """TSDFGrid::RayCast (voxel_tsdf.cu:885-902): returns (rgba, normal) HxWx4 uint8 images."""
+        k, p = _as_intr(intrinsics), _as_pose(pose)
+        rgba = np.zeros((height, width, 4), dtype=np.uint8)
+        normal = np.zeros((height, width, 4), dtype=np.uint8)
+        _check(self.lib.fn["raycast"](self._h, C.byref(k), height, width, C.byref(p),
+                                      float(max_depth), rgba.ctypes.data, normal.ctypes.data),
+               "raycast")
+        return rgba, normal
 
     def export_directory_device(self, d_blocks, capacity, d_count):
         _check(self.lib.fn["export_directory_device"](self._h, d_blocks, capacity, d_count),

@@ -108,3 +108,30 @@ def test_export_directory_device(make_engine):
     assert n == len(blocks)
     got = buf.cpu().numpy()[:n * 3].view(BLOCK_DTYPE)
     assert np.array_equal(got, blocks)
+
+
+def test_raycast_matches_oracle(make_engine, make_oracle):
+    """TSDFGrid::RayCast / TSDFSystem::Render (voxel_tsdf.cu:278-374): rgba + normal images of a
+    virtual view.  Voxel weights must reach 10 before a surface is rendered, so integrate enough
+    frames first."""
+    vs = 0.02
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=8)
+    frames = [synthetic.frame("room", 0, scale=0.25) for _ in range(6)]
+    frames += synthetic.stream("room", 4, scale=0.25)
+    for f in frames:
+        for e in (gpu, cpu):
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+    f = frames[-1]
+    h, w = f["depth"].shape
+    for pose, k, hh, ww in [(f["pose"], f["intrinsics"], h, w),
+                            (synthetic.frame("room", 2, scale=0.25)["pose"], f["intrinsics"], h, w),
+                            (f["pose"], tuple(v * 2 for v in f["intrinsics"]), 2 * h, 2 * w)]:
+        ga, gn = gpu.raycast(k, hh, ww, pose, 8.0)
+        ca, cn = cpu.raycast(k, hh, ww, pose, 8.0)
+        assert (ca[..., 3] == 255).mean() > 0.3, "oracle rendered almost nothing"
+        for a, b, name in ((ga, ca, "rgba"), (gn, cn, "normal")):
+            d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+            # identical arithmetic except probability (expf/logf, <= 1e-6) feeding alpha: allow a
+            # one-step difference on a handful of pixels
+            assert d.max() <= 1, f"{name}: max byte difference {d.max()}"
+            assert (d > 0).mean() < 1e-3, f"{name}: {(d > 0).sum()} bytes differ"
