@@ -38,6 +38,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -375,12 +376,14 @@ struct ratsdf_engine {
   }
 
   // ---- block_allocate_kernel + TSDFGrid::Allocate, voxel_tsdf.cu:120-168,454-463 -------------
-  void allocate_pass(const float* depth, int H, int W, float md, const Intr& K, const Se3& T) {
-    const Se3 Ti = T.inverse();
-    const Intr Ki = K.inverse();
-    range.resize((size_t)H * W);
-    int inserted = 0;
-    for (int y = 0; y < H; ++y) {
+  // Candidate blocks of pixel rows [y0, y1) in raster order.  With `skip_present` the candidates
+  // that already exist in the directory (or fail the frustum test) are dropped: Allocate() returns
+  // at once for them without changing any state (voxel_hash.cu:48-65), so dropping them is
+  // result-neutral; that is what lets the multithreaded baseline generate candidates in parallel.
+  void candidates_rows(const float* depth, int y0, int y1, int W, int H, float md, const Intr& K,
+                       const Intr& Ki, const Se3& T, const Se3& Ti, bool skip_present,
+                       std::vector<S3>& out) {
+    for (int y = y0; y < y1; ++y) {
       for (int x = 0; x < W; ++x) {
         const int idx = y * W + x;
         const float d = depth[idx];
@@ -403,17 +406,50 @@ struct ratsdf_engine {
         const float den = fmaxf((float)steps, 1);
         const V3 st{rg.x / den, rg.y / den, rg.z / den};
         V3 p = sg;
+        S3 prev{0, 0, 0};
+        bool have_prev = false;
         for (int i = 0; i <= steps; ++i) {
           const S3 g{f2s(roundf(p.x)), f2s(roundf(p.y)), f2s(roundf(p.z))};
           const S3 bp{(int16_t)(g.x >> 3), (int16_t)(g.y >> 3), (int16_t)(g.z >> 3)};
-          if (owned(bp) && block_visible<true>(bp, T, K, W, H)) {
-            if (allocate(bp)) ++inserted;
-          }
           p.x += st.x;
           p.y += st.y;
           p.z += st.z;
+          if (skip_present) {
+            if (have_prev && bp == prev) continue;  // same block as the previous sample
+            prev = bp;
+            have_prev = true;
+            Entry tmp;
+            get_block(bp, &tmp);
+            if (tmp.idx >= 0) continue;
+          }
+          if (owned(bp) && block_visible<true>(bp, T, K, W, H)) out.push_back(bp);
         }
       }
+    }
+  }
+
+  void allocate_pass(const float* depth, int H, int W, float md, const Intr& K, const Se3& T) {
+    const Se3 Ti = T.inverse();
+    const Intr Ki = K.inverse();
+    range.resize((size_t)H * W);
+    int inserted = 0;
+    if (threads <= 1) {
+      std::vector<S3> cand;
+      for (int y = 0; y < H; ++y) {  // strictly sequential: candidate, Allocate, next candidate
+        cand.clear();
+        candidates_rows(depth, y, y + 1, W, H, md, K, Ki, T, Ti, false, cand);
+        for (const S3& bp : cand)
+          if (allocate(bp)) ++inserted;
+      }
+    } else {
+      const int nt = threads;
+      std::vector<std::vector<S3>> parts(nt);
+      parallel_for((size_t)H, [&](size_t lo, size_t hi, int t) {
+        candidates_rows(depth, (int)lo, (int)hi, W, H, md, K, Ki, T, Ti, true, parts[t]);
+      });
+      for (auto& part : parts)  // row chunks are in raster order
+        for (const S3& bp : part)
+          if (allocate(bp)) ++inserted;
     }
     stats.allocated_blocks = inserted;
     reset_locks();
@@ -492,8 +528,13 @@ struct ratsdf_engine {
   int integrate(const uint8_t* rgb, const float* depth, const float* ht, const float* lt, int H,
                 int W, float md, const Intr& K, const Se3& T) {
     stats = ratsdf_frame_stats{};
+    const bool prof = getenv("RATSDF_ORACLE_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     allocate_pass(depth, H, W, md, K, T);
+    const double t1 = now();
     gather_visible(H, W, K, T);
+    const double t2 = now();
     const size_t V = visible.size();
     std::atomic<long> updated{0};
     std::vector<uint8_t> carve(V, 0);
@@ -511,6 +552,10 @@ struct ratsdf_engine {
       updated += u;
     });
     stats.updated_voxels = (int)updated.load();
+    const double t3 = now();
+    if (prof)
+      fprintf(stderr, "[oracle] alloc %.1f ms, visible %.1f ms, integrate %.1f ms (threads %d)\n",
+              (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, threads);
     int deleted = 0;
     for (size_t i = 0; i < V; ++i) {
       if (carve[i] && erase(visible[i].blk.pos)) ++deleted;

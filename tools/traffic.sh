@@ -1,0 +1,31 @@
+#!/bin/bash
+# HBM traffic of the dominant kernel from PMC counters (separate passes, as the microarch guide
+# prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass).  Writes profiles/traffic_latest.json.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/traffic_$c
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/traffic_$c -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 --no-profile > gpurun_out/traffic_$c.log 2>&1
+done
+python3 - <<'PY'
+import csv,glob,json,collections,os
+out={}
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    f=sorted(glob.glob(f'gpurun_out/traffic_{c}/*/*counter_collection.csv'), key=os.path.getmtime)[-1]
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        n=r['Kernel_Name'].split('(')[0].replace('ratsdf::','').replace('void ','')
+        if r['Counter_Name']==c: agg[n].append(float(r['Counter_Value']))
+    for n,v in agg.items():
+        v=v[len(v)//3:]   # skip the map-building frames
+        out.setdefault(n,{})[c+"_KB_per_launch"]=sum(v)/len(v)
+ki=[k for k in out if k.startswith('k_integrate')][0]
+f_kb=out[ki]["FETCH_SIZE_KB_per_launch"]; w_kb=out[ki]["WRITE_SIZE_KB_per_launch"]
+res={"kernel":ki,"fetch_size_kb":round(f_kb,1),"write_size_kb":round(w_kb,1),
+     "k_integrate_bytes_per_launch": round((2*f_kb+w_kb)*1024),
+     "raw_bytes_per_launch_uncorrected": round((f_kb+w_kb)*1024),
+     "note":"FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B read request); WRITE_SIZE as is; bench workload, steady-state frames",
+     "all_kernels_kb":{k:{kk:round(vv,1) for kk,vv in v.items()} for k,v in out.items()}}
+os.makedirs('gpurun_out/profiles_out',exist_ok=True)
+json.dump(res,open('gpurun_out/profiles_out/traffic_latest.json','w'),indent=1)
+print(json.dumps(res))
+PY
