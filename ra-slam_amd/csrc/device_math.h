@@ -97,6 +97,22 @@ __device__ inline bool block_visible(int bx, int by, int bz, const FrameParams& 
   return vis;
 }
 
+// Which of the 8 per-XCD work lists a block belongs to: the image is cut into 8x8 tiles and tiles
+// are dealt to the lists so that every list covers 8 scattered tiles (load balance).  Workgroup b of
+// k_integrate serves list b & 7 and workgroups b, b+8, ... share an XCD (observed round-robin
+// placement), so the per-pixel texels of a tile are pulled into ONE XCD's L2 instead of all eight.
+// Placement only affects speed: any list is a correct home for any block.
+__device__ inline int block_list_of(int bx, int by, int bz, const FrameParams& P) {
+  const V3 pw{(float)(bx * 8 + 4) * P.vs, (float)(by * 8 + 4) * P.vs, (float)(bz * 8 + 4) * P.vs};
+  const V3 pc = se3_apply(P.T, pw);
+  const V3 ph = intr_mul(P.K, pc);
+  float u = ph.x / ph.z, v = ph.y / ph.z;
+  u = fminf(fmaxf(u, 0.f), (float)(P.W - 1));  // NaN -> 0
+  v = fminf(fmaxf(v, 0.f), (float)(P.H - 1));
+  const int tx = (int)(u * 8.f / (float)P.W), ty = (int)(v * 8.f / (float)P.H);
+  return (tx + 3 * ty) & 7;
+}
+
 __device__ inline bool shard_owned(int bx, const FrameParams& P) {
   if (P.shard_count <= 1) return true;
   const int s = bx >> P.shard_slab_bits;

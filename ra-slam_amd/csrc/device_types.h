@@ -58,14 +58,15 @@ struct Ctl {
   uint32_t n_req;         // requests appended this pass
   uint32_t n_slow;        // slow (chained-bucket) requests appended this pass
   uint32_t n_win;         // winners of the allocation pass
-  uint32_t n_vis;         // V
+  uint32_t n_vis;         // V (total, filled in by k_carve / the test hook)
   uint32_t n_updated;     // U
   uint32_t n_slow_del;    // slow deletes appended
   uint32_t n_del;         // successful deletes
   uint32_t alloc_base;    // num_free at the start of the allocation pass
   uint32_t free_base;     // num_free at the start of the carve pass
   uint32_t n_sel;         // selected blocks of a query / export
-  uint32_t pad0[6];
+  uint32_t n_list[8];     // visible blocks per XCD list (image-tile buckets)
+  uint32_t pad0[14];
   // --- persistent ---
   int32_t num_free;       // VoxelMemPool::num_free_blocks_
   uint32_t error;         // sticky ratsdf_status
@@ -73,7 +74,8 @@ struct Ctl {
   uint32_t pad1[4];
   unsigned long long stamps[32];  // diagnostic build only
 };
-constexpr int kCtlFrameBytes = 64;
+constexpr int kCtlFrameBytes = 128;
+constexpr int kNumLists = 8;  // one block list per XCD; list 8 (the 9th segment) holds this frame's new blocks
 
 // Diagnostic build only (-DRATSDF_STAMPS): thread 0 of the single-workgroup kernels accumulates
 // shader-clock stamps per phase into Ctl-adjacent memory; never compiled into the product library.

@@ -183,8 +183,8 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
   if (inb) {
     float lh = 0.f, ll = 0.f;
     if (P.has_sem) {
-      lh = logf(ht[pix]);
-      ll = logf(lt[pix]);
+      lh = __logf(ht[pix]);  // same function as the per-voxel log in k_integrate
+      ll = __logf(lt[pix]);
     }
     const float wn = (1 - d / P.md) * 4;
     const uint32_t c = (uint32_t)rgb[3 * pix] | ((uint32_t)rgb[3 * pix + 1] << 8) |

@@ -73,9 +73,147 @@ struct VecIO<2> {
   }
 };
 
+// Update of one voxel block by the waves that own it (WPB waves, `part` = which one).  Returns the
+// number of voxels this lane updated and the lane's min |tsdf| after the update.
+template <int VPL>
+__device__ inline void integrate_block(const Pool& pool, const FrameParams& P, const VisItem& item,
+                                       bool fresh_in, uint32_t vi0, const float4* texA,
+                                       const uint2* texB, uint32_t* out_nupd, float* out_min) {
+  bool fresh = fresh_in;
+  const int tx0 = vi0 & 7, ty = (vi0 >> 3) & 7, tz = vi0 >> 6;
+  const size_t v = ((size_t)item.idx << 9) + vi0;
+  uint32_t tv[VPL], sv[VPL], cv[VPL];
+  if (P.debug == 5) fresh = true;  // diagnostic: no voxel loads / stores
+  if (P.debug != 5) VecIO<VPL>::load(pool.rgbw + v, cv);
+  else
+    for (int j = 0; j < VPL; ++j) cv[j] = 0;
+  if (!fresh) {
+    VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.tsdf + v), tv);
+    VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.segm + v), sv);
+  } else {  // AquireBlock initial values, voxel_mem.cu:43-51 (rgb stays as found)
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      tv[j] = __float_as_uint(-1.f);
+      sv[j] = __float_as_uint(.5f);
+      cv[j] = (cv[j] & 0x00FFFFFFu) | 0x01000000u;
+    }
+  }
+  const int gy = (int16_t)((int16_t)(item.y << 3) + ty);
+  const int gz = (int16_t)((int16_t)(item.z << 3) + tz);
+  const float wy = (float)gy * P.vs, wz = (float)gz * P.vs;
+  float phz[VPL];
+  int kk[VPL];
+  bool inb[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int gx = (int16_t)((int16_t)(item.x << 3) + tx0 + j);         // :183-184
+    const V3 pw{(float)gx * P.vs, wy, wz};                              // :187
+    const V3 pc3 = se3_apply(P.T, pw);                                  // :190
+    const V3 ph = intr_mul(P.K, pc3);                                   // :193
+    const int u = f2i(roundf(ph.x / ph.z));                             // :196-199
+    const int w = f2i(roundf(ph.y / ph.z));                             // :202
+    inb[j] = u >= 0 && u < P.W && w >= 0 && w < P.H;                    // :205
+    kk[j] = inb[j] ? w * P.W + u : 0;
+    phz[j] = ph.z;
+  }
+  float4 ta[VPL];
+  uint2 tb[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {  // all gathers in flight together
+    if (P.debug == 4) {            // diagnostic: no gathers
+      ta[j] = make_float4(2.f, 1.f, -0.5f, -0.7f);
+      tb[j] = make_uint2(0x00808080u, __float_as_uint(2.f));
+      continue;
+    }
+    ta[j] = texA[kk[j]];           // depth, range, log ht, log lt
+    tb[j] = texB[kk[j]];           // rgb, w_new
+  }
+  uint32_t nupd = 0;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float d = ta[j].x;
+    const float sdf = ta[j].y * (d - phz[j]);                           // :216
+    if (inb[j] && !(d == 0 || d > P.md) && sdf > -P.trunc) {            // :211,217
+      const float ts = fminf(1, sdf / P.trunc);                         // :218
+      const float wn = __uint_as_float(tb[j].y);                        // :226
+      const uint32_t c = cv[j];
+      const float wo = (float)(c >> 24);                                // :227
+      const float wc = wo + wn;                                         // :228
+      const float r_old = (float)(c & 0xFFu), g_old = (float)((c >> 8) & 0xFFu),
+                  b_old = (float)((c >> 16) & 0xFFu);
+      const uint32_t cn = tb[j].x;
+      const float r_new = (float)(cn & 0xFFu), g_new = (float)((cn >> 8) & 0xFFu),
+                  b_new = (float)((cn >> 16) & 0xFFu);
+      const float rc = (r_old * wo + r_new * wn) / wc;                  // :234-235
+      const float gc = (g_old * wo + g_new * wn) / wc;
+      const float bc = (b_old * wo + b_new * wn) / wc;
+      const float t_old = __uint_as_float(tv[j]);
+      tv[j] = __float_as_uint((t_old * wo + ts * wn) / wc);             // :236
+      const uint32_t wq = (uint32_t)f2i(fminf(roundf(wc), 40)) & 0xFFu; // :238
+      cv[j] = ((uint32_t)f2i(roundf(rc)) & 0xFFu) | (((uint32_t)f2i(roundf(gc)) & 0xFFu) << 8) |
+              (((uint32_t)f2i(roundf(bc)) & 0xFFu) << 16) | (wq << 24); // :239-240
+      const float pr = __uint_as_float(sv[j]);
+      if (P.debug != 6) {  // diagnostic 6: no transcendental part
+      // hardware exp2/log2 based exp/log (v_exp_f32 / v_log_f32, ~1e-7 relative): the only
+      // functions of the path whose last bits differ between any two libms anyway
+      const float pos = __expf((wo * __logf(pr) + wn * ta[j].z) / wc);      // :242-244
+      const float neg = __expf((wo * __logf(1 - pr) + wn * ta[j].w) / wc);  // :245-247
+      sv[j] = __float_as_uint(pos / (pos + neg));                       // :248
+      }
+      ++nupd;
+    }
+  }
+  if ((nupd || fresh) && P.debug != 5 && P.debug != 7) {
+    VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.tsdf + v), tv);
+    VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), sv);
+    VecIO<VPL>::store(pool.rgbw + v, cv);
+  }
+  // space_carving_kernel, :253-276: min |tsdf| over the block after the update
+  float m = fabsf(__uint_as_float(tv[0]));
+#pragma unroll
+  for (int j = 1; j < VPL; ++j) m = fminf(m, fabsf(__uint_as_float(tv[j])));
+  *out_nupd = nupd;
+  *out_min = m;
+}
+
+// Per-block result word for the carve pass: bit 31 = carve candidate (min |tsdf| >= .9), low bits =
+// voxels updated.  (A single device-wide atomic counter here costs more than the whole update:
+// ~90 atomics/us per address.)  Combines the WPB waves of a block through LDS.
+template <int WPB>
+__device__ inline void publish_block(uint32_t* blk_info, size_t slot, bool active, float m,
+                                     uint32_t nupd, uint32_t wv, uint32_t part, uint32_t lane,
+                                     float* smin, uint32_t* supd) {
+  m = wave_min(m);
+  nupd = wave_sum(nupd);
+  if (WPB == 1) {
+    if (active && lane == 0) blk_info[slot] = nupd | ((m >= .9f) ? 0x80000000u : 0u);
+  } else {
+    __syncthreads();  // smin / supd free again
+    if (lane == 0) {
+      smin[wv] = m;
+      supd[wv] = nupd;
+    }
+    __syncthreads();
+    if (active && part == 0 && lane == 0) {
+      float mm = smin[wv];
+      uint32_t uu = supd[wv];
+#pragma unroll
+      for (int i = 1; i < WPB; ++i) {
+        mm = fminf(mm, smin[wv + i]);
+        uu += supd[wv + i];
+      }
+      blk_info[slot] = uu | ((mm >= .9f) ? 0x80000000u : 0u);
+    }
+  }
+}
+
+// Work lists: `vis` / `blk_info` are kNumLists + 1 segments of seg_cap items.  Segments 0..7 hold the
+// visible blocks that existed before the frame, bucketed by image tile (block_list_of); workgroup b
+// serves list b & 7, which keeps a tile's texels in one XCD's L2.  Segment 8 receives this frame's
+// new blocks (slot = rank among the winners), committed and integrated here by every workgroup.
 template <int VPL>
 __global__ __launch_bounds__(256) void k_integrate(Table tab, Pool pool, FrameParams P, VisItem* vis,
-                                                   uint32_t vis_cap, const Request* req,
+                                                   uint32_t seg_cap, const Request* req,
                                                    uint32_t req_cap, const uint32_t* req_k,
                                                    const float4* texA, const uint2* texB,
                                                    uint32_t* blk_info, Ctl* ctl) {
@@ -86,146 +224,52 @@ __global__ __launch_bounds__(256) void k_integrate(Table tab, Pool pool, FramePa
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wv = threadIdx.x >> 6;
   const uint32_t blk_in_wg = wv / WPB, part = wv % WPB;
-  uint32_t n_exist = ctl->n_vis;  // blocks that existed before this frame and are in view
-  if (n_exist > vis_cap) n_exist = vis_cap;
+  const uint32_t vi0 = (part * 64 + lane) * VPL;  // first voxel of this lane, x + 8y + 64z
+  const uint32_t list = blockIdx.x & (kNumLists - 1);
+  const uint32_t wg_in_list = blockIdx.x / kNumLists, wgs_per_list = gridDim.x / kNumLists;
+  const VisItem* my_vis = vis + (size_t)list * seg_cap;
+  // the first item is fetched together with the counters (the slot exists even if the list is
+  // shorter; it is only used when in range), which takes one memory round trip off every wave
+  const uint32_t j0 = wg_in_list * BPW + blk_in_wg;
+  const VisItem first = my_vis[j0 < seg_cap ? j0 : 0];
+  uint32_t n_mine = ctl->n_list[list];
+  if (n_mine > seg_cap) n_mine = seg_cap;
   uint32_t n_req = ctl->n_req;
   if (n_req > req_cap) n_req = req_cap;
   const uint32_t n_win = ctl->n_win, alloc_base = ctl->alloc_base;
-  const uint32_t n_items = n_exist + n_req;
-  const uint32_t vi0 = (part * 64 + lane) * VPL;  // first voxel of this lane, x + 8y + 64z
-  const int tx0 = vi0 & 7, ty = (vi0 >> 3) & 7, tz = vi0 >> 6;
-  for (uint32_t it = blockIdx.x; it * BPW < n_items; it += gridDim.x) {
-    const uint32_t t = it * BPW + blk_in_wg;
-    bool active = t < n_items;
-    bool fresh = false;
-    uint32_t b = t;  // slot in the frame's block list
-    VisItem item{};
-    if (active) {
-      if (t < n_exist) {
-        item = vis[t];
-      } else {
-        const Request r = req[t - n_exist];
-        uint32_t e = 0;
-        int32_t idx = -1;
-        const bool writer = part == 0 && lane == 0;
-        const uint32_t k = (r.flags & kReqWinner) ? req_k[t - n_exist] : 0u;
-        active = commit_request(tab, pool, r, k, alloc_base, n_win, writer, &idx, &e);
-        fresh = active;
-        b = n_exist + k;  // winners occupy slots n_exist .. n_exist + n_win - 1
-        if (b >= vis_cap) active = false;
-        item = VisItem{r.x, r.y, r.z, 0, idx, e};
-        if (active && writer) vis[b] = item;  // the carve pass needs the block's directory entry
-      }
-    }
-    float m = 3.0e38f;
-    uint32_t nupd_blk = 0;
-    if (active) {
-      const size_t v = ((size_t)item.idx << 9) + vi0;
-      uint32_t tv[VPL], sv[VPL], cv[VPL];
-      VecIO<VPL>::load(pool.rgbw + v, cv);
-      if (!fresh) {
-        VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.tsdf + v), tv);
-        VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.segm + v), sv);
-      } else {  // AquireBlock initial values, voxel_mem.cu:43-51 (rgb stays as found)
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          tv[j] = __float_as_uint(-1.f);
-          sv[j] = __float_as_uint(.5f);
-          cv[j] = (cv[j] & 0x00FFFFFFu) | 0x01000000u;
-        }
-      }
 
-      const int gy = (int16_t)((int16_t)(item.y << 3) + ty);
-      const int gz = (int16_t)((int16_t)(item.z << 3) + tz);
-      const float wy = (float)gy * P.vs, wz = (float)gz * P.vs;
-      float phz[VPL];
-      int kk[VPL];
-      bool inb[VPL];
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        const int gx = (int16_t)((int16_t)(item.x << 3) + tx0 + j);         // :183-184
-        const V3 pw{(float)gx * P.vs, wy, wz};                              // :187
-        const V3 pc3 = se3_apply(P.T, pw);                                  // :190
-        const V3 ph = intr_mul(P.K, pc3);                                   // :193
-        const int u = f2i(roundf(ph.x / ph.z));                             // :196-199
-        const int w = f2i(roundf(ph.y / ph.z));                             // :202
-        inb[j] = u >= 0 && u < P.W && w >= 0 && w < P.H;                    // :205
-        kk[j] = inb[j] ? w * P.W + u : 0;
-        phz[j] = ph.z;
-      }
-      float4 ta[VPL];
-      uint2 tb[VPL];
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {  // all gathers in flight together
-        ta[j] = texA[kk[j]];           // depth, range, log ht, log lt
-        tb[j] = texB[kk[j]];           // rgb, w_new
-      }
-      uint32_t nupd = 0;
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        const float d = ta[j].x;
-        const float sdf = ta[j].y * (d - phz[j]);                           // :216
-        if (inb[j] && !(d == 0 || d > P.md) && sdf > -P.trunc) {            // :211,217
-          const float ts = fminf(1, sdf / P.trunc);                         // :218
-          const float wn = __uint_as_float(tb[j].y);                        // :226
-          const uint32_t c = cv[j];
-          const float wo = (float)(c >> 24);                                // :227
-          const float wc = wo + wn;                                         // :228
-          const float r_old = (float)(c & 0xFFu), g_old = (float)((c >> 8) & 0xFFu),
-                      b_old = (float)((c >> 16) & 0xFFu);
-          const uint32_t cn = tb[j].x;
-          const float r_new = (float)(cn & 0xFFu), g_new = (float)((cn >> 8) & 0xFFu),
-                      b_new = (float)((cn >> 16) & 0xFFu);
-          const float rc = (r_old * wo + r_new * wn) / wc;                  // :234-235
-          const float gc = (g_old * wo + g_new * wn) / wc;
-          const float bc = (b_old * wo + b_new * wn) / wc;
-          const float t_old = __uint_as_float(tv[j]);
-          tv[j] = __float_as_uint((t_old * wo + ts * wn) / wc);             // :236
-          const uint32_t wq = (uint32_t)f2i(fminf(roundf(wc), 40)) & 0xFFu; // :238
-          cv[j] = ((uint32_t)f2i(roundf(rc)) & 0xFFu) | (((uint32_t)f2i(roundf(gc)) & 0xFFu) << 8) |
-                  (((uint32_t)f2i(roundf(bc)) & 0xFFu) << 16) | (wq << 24); // :239-240
-          const float pr = __uint_as_float(sv[j]);
-          const float pos = expf((wo * logf(pr) + wn * ta[j].z) / wc);      // :242-244
-          const float neg = expf((wo * logf(1 - pr) + wn * ta[j].w) / wc);  // :245-247
-          sv[j] = __float_as_uint(pos / (pos + neg));                       // :248
-          ++nupd;
-        }
-      }
-      if (nupd || fresh) {
-        VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.tsdf + v), tv);
-        VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), sv);
-        VecIO<VPL>::store(pool.rgbw + v, cv);
-      }
-      // space_carving_kernel, :253-276: min |tsdf| over the block after the update
-      m = fabsf(__uint_as_float(tv[0]));
-#pragma unroll
-      for (int j = 1; j < VPL; ++j) m = fminf(m, fabsf(__uint_as_float(tv[j])));
-      nupd_blk = nupd;
-    }
-    // per-block result word: bit 31 = carve candidate, low bits = voxels updated.  (A single
-    // device-wide atomic counter here costs more than the whole update: ~90 atomics/us per address.)
-    m = wave_min(m);
-    nupd_blk = wave_sum(nupd_blk);
-    if (WPB == 1) {
-      if (active && lane == 0) blk_info[b] = nupd_blk | ((m >= .9f) ? 0x80000000u : 0u);
-    } else {
-      __syncthreads();  // smin / supd free again
-      if (lane == 0) {
-        smin[wv] = m;
-        supd[wv] = nupd_blk;
-      }
-      __syncthreads();
-      if (active && part == 0 && lane == 0) {
-        float mm = smin[wv];
-        uint32_t uu = supd[wv];
-#pragma unroll
-        for (int i = 1; i < WPB; ++i) {
-          mm = fminf(mm, smin[wv + i]);
-          uu += supd[wv + i];
-        }
-        blk_info[b] = uu | ((mm >= .9f) ? 0x80000000u : 0u);
+  for (uint32_t it = wg_in_list; it * BPW < n_mine; it += wgs_per_list) {
+    const uint32_t j = it * BPW + blk_in_wg;
+    const bool active = j < n_mine;
+    float m = 3.0e38f;
+    uint32_t nupd = 0;
+    if (active) integrate_block<VPL>(pool, P, it == wg_in_list ? first : my_vis[j], false, vi0, texA,
+                                     texB, &nupd, &m);
+    publish_block<WPB>(blk_info, (size_t)list * seg_cap + j, active, m, nupd, wv, part, lane, smin,
+                       supd);
+  }
+  // this frame's allocation requests: commit (pool index, directory entry, occupancy) + first update
+  for (uint32_t it = blockIdx.x; it * BPW < n_req; it += gridDim.x) {
+    const uint32_t t = it * BPW + blk_in_wg;
+    bool active = t < n_req;
+    uint32_t k = 0;
+    float m = 3.0e38f;
+    uint32_t nupd = 0;
+    if (active) {
+      const Request r = req[t];
+      uint32_t e = 0;
+      int32_t idx = -1;
+      const bool writer = part == 0 && lane == 0;
+      k = (r.flags & kReqWinner) ? req_k[t] : 0u;
+      active = commit_request(tab, pool, r, k, alloc_base, n_win, writer, &idx, &e) && k < seg_cap;
+      if (active) {
+        const VisItem item{r.x, r.y, r.z, 0, idx, e};
+        if (writer) vis[(size_t)kNumLists * seg_cap + k] = item;  // the carve pass needs the entry
+        integrate_block<VPL>(pool, P, item, true, vi0, texA, texB, &nupd, &m);
       }
     }
+    publish_block<WPB>(blk_info, (size_t)kNumLists * seg_cap + k, active, m, nupd, wv, part, lane, smin,
+                       supd);
   }
 }
 
@@ -233,7 +277,7 @@ __global__ __launch_bounds__(256) void k_integrate(Table tab, Pool pool, FramePa
 __global__ void k_lookup_list(Table tab, const int16_t* pos, int n, VisItem* vis,
                               uint32_t* blk_info, Ctl* ctl) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) ctl->n_vis = (uint32_t)n;
+  if (i == 0) ctl->n_list[0] = (uint32_t)n;  // everything in list 0
   if (i >= n) return;
   EntryWords w;
   const int x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
@@ -267,7 +311,7 @@ __device__ inline uint32_t ld_agent(const uint32_t* p) {
 constexpr uint32_t kSmallCarve = 2048;
 
 __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisItem* vis,
-                                                uint32_t vis_cap, const uint32_t* blk_info,
+                                                uint32_t seg_cap, const uint32_t* blk_info,
                                                 uint32_t* bitmap, uint32_t* summary,
                                                 uint32_t* prefix, SlowDelete* slow,
                                                 uint32_t slow_cap, Ctl* ctl,
@@ -281,15 +325,38 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
 #ifdef RATSDF_STAMPS
   if (threadIdx.x == 0) ctl->stamps[20] += wall_clock64();
 #endif
-  uint32_t nv = ctl->n_vis + ctl->n_win;  // existing visible blocks + blocks inserted this frame
+  // lists 0..7: visible blocks that existed before the frame; list 8: blocks inserted this frame
+  uint32_t n_seg[kNumLists + 1];
+  uint32_t nv = 0;
+#pragma unroll
+  for (int l = 0; l < kNumLists; ++l) {
+    n_seg[l] = ctl->n_list[l] < seg_cap ? ctl->n_list[l] : seg_cap;
+    nv += n_seg[l];
+  }
+  n_seg[kNumLists] = ctl->n_win < seg_cap ? ctl->n_win : seg_cap;
+  nv += n_seg[kNumLists];
+  // flat index over all lists -> position in the segmented arrays
+  auto locate = [&](uint32_t g) -> size_t {
+    size_t at = 0;
+#pragma unroll
+    for (int l = 0; l <= kNumLists; ++l) {
+      if (g < n_seg[l]) {
+        at = (size_t)l * seg_cap + g;
+        g = 0xFFFFFFFFu;
+      } else if (g != 0xFFFFFFFFu) {
+        g -= n_seg[l];
+      }
+    }
+    return at;
+  };
   const int32_t nf = ctl->num_free;
-  if (nv > vis_cap) nv = vis_cap;
   if (tid == 0) n_list = 0;
   __syncthreads();
   uint32_t upd_part = 0;
-  for (uint32_t i = tid; i < nv; i += nt) {
-    const uint32_t info = blk_info[i];
-    const VisItem it = vis[i];
+  for (uint32_t g = tid; g < nv; g += nt) {
+    const size_t at = locate(g);
+    const uint32_t info = blk_info[at];
+    const VisItem it = vis[at];
     upd_part += info & 0x7FFFFFFFu;
     if (!(info >> 31)) continue;
     const uint32_t bucket = block_hash(it.x, it.y, it.z, tab.bucket_mask);
@@ -398,10 +465,11 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
       pool.heap[(uint32_t)nf + k] = del_pool[w];                          // voxel_mem.cu:56-60
     }
   } else if (n_del) {
-    for (uint32_t i = tid; i < nv; i += nt) {
-      const uint32_t info = blk_info[i];
+    for (uint32_t g = tid; g < nv; g += nt) {
+      const size_t at = locate(g);
+      const uint32_t info = blk_info[at];
       if (!(info >> 31)) continue;
-      const VisItem it = vis[i];
+      const VisItem it = vis[at];
       if (it.entry == (block_hash(it.x, it.y, it.z, tab.bucket_mask) << 1))
         bitmap_set(bitmap, summary, it.entry);
     }
@@ -415,10 +483,11 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
     const uint32_t excl = block_exclusive_scan(sum, lds, &total);
     bitmap_write_prefix(bitmap, summary, prefix, nwords, chunk, sum, excl);
     __syncthreads();
-    for (uint32_t i = tid; i < nv; i += nt) {
-      const uint32_t info = blk_info[i];
+    for (uint32_t g = tid; g < nv; g += nt) {
+      const size_t at = locate(g);
+      const uint32_t info = blk_info[at];
       if (!(info >> 31)) continue;
-      const VisItem it = vis[i];
+      const VisItem it = vis[at];
       if (it.entry != (block_hash(it.x, it.y, it.z, tab.bucket_mask) << 1)) continue;
       pool.heap[(uint32_t)nf + bitmap_rank(bitmap, prefix, it.entry)] = it.idx;
     }

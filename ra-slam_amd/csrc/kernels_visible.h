@@ -73,45 +73,57 @@ __device__ inline void select_flags_role(const Table& tab, const FrameParams& P,
 // Visibility of the blocks that exist before this frame (check_visibility_kernel +
 // gather_visible_blocks_kernel, voxel_tsdf.cu:98-118): one lane per 64-entry occupancy word tests
 // the allocated entries of its word (any of the 8 corners in view) and the workgroup appends its
-// visible blocks to the frame's work list with ONE atomicAdd.  The list is unordered; nothing in
-// a frame depends on its order (blocks are independent; the carve pass orders its pool releases by
-// hash entry through an entry-indexed bitmap).
+// visible blocks to the frame's 8 work lists (one per XCD, see block_list_of) with one atomicAdd per
+// non-empty list.  The lists are unordered; nothing in a frame depends on their order (blocks are
+// independent; the carve pass orders its pool releases by hash entry).
 __device__ inline void visible_append_role(const Table& tab, const FrameParams& P, uint32_t wg,
-                                           VisItem* vis, uint32_t vis_cap, Ctl* ctl) {
-  __shared__ uint32_t lds[32];
-  __shared__ uint32_t base_slot;
+                                           VisItem* vis, uint32_t seg_cap, Ctl* ctl) {
+  __shared__ uint32_t cnt[kNumLists], base[kNumLists], cnt2[kNumLists];
   const uint32_t nwords = tab.num_entry >> 6;
   const uint32_t w = wg * kVisWG + threadIdx.x;
+  if (threadIdx.x < kNumLists) {
+    cnt[threadIdx.x] = 0;
+    cnt2[threadIdx.x] = 0;
+  }
+  __syncthreads();
   unsigned long long occ = w < nwords ? tab.occ[w] : 0ull;
-  unsigned long long sel = 0;
+  unsigned long long sel = 0, l0 = 0, l1 = 0, l2 = 0;  // selection mask + 3 bit planes of the list id
   while (occ) {
     const int b = __ffsll((long long)occ) - 1;
     occ &= occ - 1;
     const uint32_t* p = reinterpret_cast<const uint32_t*>(tab.entries + ((size_t)w * 64 + b));
     const uint32_t w0 = p[0], w1 = p[1];
     const int bx = (int16_t)(w0 & 0xFFFFu), by = (int16_t)(w0 >> 16), bz = (int16_t)(w1 & 0xFFFFu);
-    if (block_visible<false>(bx, by, bz, P)) sel |= 1ull << b;           // voxel_tsdf.cu:98-109
+    if (block_visible<false>(bx, by, bz, P)) {                             // voxel_tsdf.cu:98-109
+      const int l = block_list_of(bx, by, bz, P);
+      sel |= 1ull << b;
+      l0 |= (unsigned long long)(l & 1) << b;
+      l1 |= (unsigned long long)((l >> 1) & 1) << b;
+      l2 |= (unsigned long long)((l >> 2) & 1) << b;
+      atomicAdd(&cnt[l], 1u);
+    }
   }
-  uint32_t total = 0;
-  const uint32_t excl = block_exclusive_scan((uint32_t)__popcll(sel), lds, &total);
-  if (total == 0) return;  // uniform
-  if (threadIdx.x == 0) base_slot = atomicAdd(&ctl->n_vis, total);
   __syncthreads();
-  uint32_t pos = base_slot + excl;
+  if (threadIdx.x < kNumLists) {
+    const uint32_t c = cnt[threadIdx.x];
+    base[threadIdx.x] = c ? atomicAdd(&ctl->n_list[threadIdx.x], c) : 0u;
+  }
+  __syncthreads();
   while (sel) {
     const int b = __ffsll((long long)sel) - 1;
     sel &= sel - 1;
-    const uint32_t e = w * 64 + b;
-    if (pos < vis_cap) {
+    const int l = (int)((l0 >> b) & 1) | ((int)((l1 >> b) & 1) << 1) | ((int)((l2 >> b) & 1) << 2);
+    const uint32_t pos = base[l] + atomicAdd(&cnt2[l], 1u);
+    if (pos < seg_cap) {
+      const uint32_t e = w * 64 + b;
       const EntryWords ew = load_entry(tab.entries, e);
       uint4 v;
       v.x = ew.w0;
       v.y = ew.w1;
       v.z = (uint32_t)ew.idx;
       v.w = e;
-      reinterpret_cast<uint4*>(vis)[pos] = v;
+      reinterpret_cast<uint4*>(vis)[(size_t)l * seg_cap + pos] = v;
     }
-    ++pos;
   }
 }
 
@@ -125,12 +137,12 @@ __global__ __launch_bounds__(256) void k_front(Table tab, FrameParams P, uint32_
                                                const float* ht, const float* lt, float4* texA,
                                                uint2* texB, Request* req, uint32_t req_cap,
                                                SlowRequest* slow, uint32_t slow_cap, VisItem* vis,
-                                               uint32_t vis_cap, Ctl* ctl) {
+                                               uint32_t seg_cap, Ctl* ctl) {
   if (blockIdx.x >= n_vis_wg) {
     alloc_pixels_role(tab, P, blockIdx.x - n_vis_wg, depth, rgb, ht, lt, texA, texB, req, req_cap,
                       slow, slow_cap, ctl);
   } else if (P.debug != 3) {
-    visible_append_role(tab, P, blockIdx.x, vis, vis_cap, ctl);
+    visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl);
   }
 }
 

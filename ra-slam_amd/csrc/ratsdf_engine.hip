@@ -87,7 +87,8 @@ struct ratsdf_engine {
   uint32_t* dbitmap = nullptr;   // delete bitmap indexed by hash entry (self-cleaning)
   uint32_t* dsummary = nullptr;
   uint32_t* dprefix = nullptr;
-  uint32_t vis_cap = 0;
+  uint32_t vis_cap = 0;   // total items of `vis` / `carve_flag`
+  uint32_t seg_cap = 0;   // items per work list (vis holds kNumLists + 1 segments)
   uint32_t dwords = 0;
   SlowDelete* slowdel = nullptr;
 
@@ -217,7 +218,7 @@ int ratsdf_engine::alloc_rank(uint32_t nranks) {
 }
 
 int ratsdf_engine::carve_tail(bool is_frame) {
-  hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, stream, tab, pool, vis, vis_cap, carve_flag,
+  hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, stream, tab, pool, vis, seg_cap, carve_flag,
                      dbitmap, dsummary, dprefix, slowdel, kSlowDelCap, ctl,
                      is_frame ? d_stats : (ratsdf_frame_stats*)nullptr);
   HIPCHK(hipGetLastError());
@@ -260,7 +261,7 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
   const unsigned n_pix_wg = (unsigned)((npix + 255) / 256);
   hipLaunchKernelGGL(k_front, dim3(nwg + n_pix_wg), dim3(256), 0, stream, tab, P, nwg,
                      (const float*)d_depth, (const uint8_t*)d_rgb, (const float*)d_ht,
-                     (const float*)d_lt, texA, texB, req, req_cap, slow, kSlowCap, vis, vis_cap, ctl);
+                     (const float*)d_lt, texA, texB, req, req_cap, slow, kSlowCap, vis, seg_cap, ctl);
   st = alloc_rank((uint32_t)(npix * (size_t)S));
   if (st != RATSDF_OK) return st;
 
@@ -281,15 +282,15 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
   switch (vpl) {
     case 8:
       hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, vis_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
       break;
     case 4:
       hipLaunchKernelGGL(k_integrate<4>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, vis_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
       break;
     default:
       hipLaunchKernelGGL(k_integrate<2>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, vis_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
   }
   if (timed) HIPCHK(hipEventRecord(ev1, stream));
 
@@ -390,7 +391,8 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->distinct, (size_t)kSlowDistinctCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * kVisWG * 8));
   CREATE_CHK(hipMalloc(&e->wg_count, (size_t)e->nwg * 4));
-  e->vis_cap = 2u * (uint32_t)t.num_block;  // visible existing blocks + blocks inserted this frame
+  e->seg_cap = (uint32_t)t.num_block;              // any list can hold every block
+  e->vis_cap = (kNumLists + 1) * e->seg_cap;       // 8 per-XCD lists + this frame's new blocks
   CREATE_CHK(hipMalloc(&e->vis, (size_t)e->vis_cap * sizeof(VisItem)));
   CREATE_CHK(hipMalloc(&e->carve_flag, (size_t)e->vis_cap * 4));
   e->dwords = (e->dwords + kGroupWords - 1) / kGroupWords * kGroupWords;
