@@ -76,11 +76,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the TSDF engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RATSDF_BENCH_DEVICE / RATSDF_BENCH_BACKEND exist only to rehearse the N > 1 control flow on a
+    # one-GPU box (all ranks on device 0, gloo instead of RCCL); the driver never sets them.
+    dev_index = int(os.environ.get("RATSDF_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("RATSDF_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import ratsdf
     vs = a.voxel
@@ -98,7 +105,7 @@ def main():
     pose = [ratsdf.Pose(*f["pose"]) for f in frames]
     torch.cuda.synchronize()
 
-    eng = ratsdf.TSDFGrid(vs, 6 * vs, device=local_rank)
+    eng = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
     ext = torch.cuda.ExternalStream(eng.stream(), device=dev)
 
     # ---- parity + CPU baseline on a bounded prefix (rank 0, N = 1) ---------------------------
@@ -113,7 +120,7 @@ def main():
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         cores = min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16")))
         cpu = Engine(load_oracle(), vs, 6 * vs, threads=cores)
-        chk = ratsdf.TSDFGrid(vs, 6 * vs, device=local_rank)
+        chk = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
         t0 = time.perf_counter()
         for j in range(ncpu):
             f = frames[j % len(frames)]
@@ -144,12 +151,21 @@ def main():
         cnt_all = torch.zeros(world, dtype=torch.int32, device=dev)
 
     def exchange():
+        # engine stream -> (event) -> torch stream -> RCCL all-gather -> (event) -> engine stream
         eng.export_directory_device(dir_local.data_ptr(), cap, dir_count.data_ptr())
         ev = torch.cuda.Event()
         ev.record(ext)
         torch.cuda.current_stream().wait_event(ev)
-        dist.all_gather_into_tensor(dir_all, dir_local)
-        dist.all_gather_into_tensor(cnt_all, dir_count)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(dir_all, dir_local)
+            dist.all_gather_into_tensor(cnt_all, dir_count)
+        else:  # rehearsal backend: stage through the host
+            a_cpu, c_cpu = torch.zeros(world * cap * 3, dtype=torch.int32), torch.zeros(
+                world, dtype=torch.int32)
+            dist.all_gather_into_tensor(a_cpu, dir_local.cpu())
+            dist.all_gather_into_tensor(c_cpu, dir_count.cpu())
+            dir_all.copy_(a_cpu)
+            cnt_all.copy_(c_cpu)
         ev2 = torch.cuda.Event()
         ev2.record(torch.cuda.current_stream())
         ext.wait_event(ev2)
@@ -200,7 +216,7 @@ def main():
     # reference's Integrate).  Reported separately; never the headline value.
     host_path = None
     if rank == 0 and world == 1 and a.host_frames > 0:
-        hp = ratsdf.TSDFGrid(vs, 6 * vs, device=local_rank)
+        hp = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
         nh = min(a.host_frames, len(frames))
         for f in frames[:4]:
             hp.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"], f["pose"])
@@ -260,6 +276,7 @@ def main():
                 "streams": world,
                 "directory_allgather_every_frames": len(frames) if world > 1 else None,
             },
+            "directory_blocks_all_ranks": (int(cnt_all.sum().item()) if world > 1 else None),
             "frame": {"avg_visible_blocks": round(V, 1), "avg_updated_voxels": round(U, 1),
                       "alg_bytes": round(b_alg), "alg_gbps_whole_frame": round(b_alg * fps / world / 1e9, 1),
                       "active_blocks": stats["active_blocks"]},
