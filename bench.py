@@ -46,6 +46,13 @@ def parse():
     ap.add_argument("--max-depth", type=float, default=4.0)
     ap.add_argument("--cpu-frames", type=int, default=1080,
                     help="frames of the stream timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--config", default="vga5mm", choices=["vga5mm", "hd2mm"],
+                    help="vga5mm: BASELINE metric config (640x480, 5 mm); hd2mm: 1280x720, 2 mm "
+                         "(BASELINE configs[3] workload, single GPU unless --shard)")
+    ap.add_argument("--shard", action="store_true",
+                    help="N > 1: every rank integrates the SAME stream and owns the blocks "
+                         "owner(block) == rank (spatial subvolumes, strong scaling) instead of "
+                         "one independent stream per rank")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of k_integrate")
     ap.add_argument("--host-frames", type=int, default=60,
                     help="frames timed through the host-image entry point, PCIe included (0 = skip)")
@@ -90,10 +97,16 @@ def main():
             dist.init_process_group(backend)
 
     import ratsdf
+    if a.config == "hd2mm":
+        a.cam, a.voxel = "l515_720p", 0.002
+        if a.frames_per_step == 90:
+            a.frames_per_step = 30
+        if a.cpu_frames == 1080:
+            a.cpu_frames = 60
     vs = a.voxel
     B = a.frames_per_step
     half = (B + 1) // 2
-    frames = make_stream(a.scene, a.cam, half, phase=45 * rank)
+    frames = make_stream(a.scene, a.cam, half, phase=0 if a.shard else 45 * rank)
     frames = frames[:B] if len(frames) >= B else frames
     H, W = frames[0]["depth"].shape
     # resident inputs
@@ -105,7 +118,8 @@ def main():
     pose = [ratsdf.Pose(*f["pose"]) for f in frames]
     torch.cuda.synchronize()
 
-    eng = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
+    shard_kw = dict(shard_rank=rank, shard_count=world, shard_slab_bits=2) if (a.shard and world > 1) else {}
+    eng = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index, **shard_kw)
     ext = torch.cuda.ExternalStream(eng.stream(), device=dev)
 
     # ---- parity + CPU baseline on a bounded prefix (rank 0, N = 1) ---------------------------
@@ -236,7 +250,7 @@ def main():
 
     nframes = a.steps * len(frames)
     if rank == 0:
-        fps = world * nframes / dt
+        fps = (1 if a.shard else world) * nframes / dt
         V = tot["visible_blocks"] / max(tot["frames"], 1)
         U = tot["updated_voxels"] / max(tot["frames"], 1)
         b_alg = 15.0 * W * H + 12.0 * V + 24.0 * U
@@ -246,7 +260,7 @@ def main():
             achieved = b_alg / k_avg_s / 1e9
             traffic = None
             tpath = ROOT / "profiles" / "traffic_latest.json"
-            if tpath.exists():
+            if tpath.exists() and a.config == "vga5mm":  # the PMC passes were made on this workload
                 try:
                     traffic = json.loads(tpath.read_text()).get("k_integrate_bytes_per_launch")
                 except Exception:
@@ -256,7 +270,8 @@ def main():
                         traffic=traffic, alg_bytes_per_launch=round(b_alg),
                         avg_launch_us=round(k_avg_s * 1e6, 2), launches=k_n)
         out = {
-            "metric": "depth+semantic frames/sec integrated @640x480, 5mm voxels",
+            "metric": ("depth+semantic frames/sec integrated @640x480, 5mm voxels" if a.config == "vga5mm"
+                       else f"depth+semantic frames/sec integrated @{W}x{H}, {vs * 1e3:g}mm voxels"),
             "value": round(fps, 1),
             "unit": "frames/s",
             "n_gpus": world,
@@ -264,7 +279,7 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (a.shard and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -273,7 +288,8 @@ def main():
                             f"voxel {vs * 1e3:g} mm, truncation {6 * vs * 1e3:g} mm, max depth "
                             f"{a.max_depth:g} m, 1 deg/frame ping-pong sweep, 1 mm depth noise, 1% holes",
                 "frames_per_step": len(frames),
-                "streams": world,
+                "streams": 1 if a.shard else world,
+                "sharding": ("block ownership: floormod(block.x >> 2, N)" if (a.shard and world > 1) else None),
                 "directory_allgather_every_frames": len(frames) if world > 1 else None,
             },
             "directory_blocks_all_ranks": (int(cnt_all.sum().item()) if world > 1 else None),

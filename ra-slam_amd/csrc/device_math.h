@@ -78,23 +78,23 @@ __device__ inline bool voxel_visible(int gx, int gy, int gz, const FrameParams& 
   return (u >= 0 && u <= (float)(P.W - 1) && v >= 0 && v <= (float)(P.H - 1) && ph.z >= 0);
 }
 
-// is_block_visible<Full>, utils/tsdf/voxel_tsdf.cu:75-96 (corner coordinates in short arithmetic)
+// is_block_visible<Full>, utils/tsdf/voxel_tsdf.cu:75-96 (corner coordinates in short arithmetic).
+// The reference ANDs / ORs all 8 corner tests; the result is the same when the loop stops at the
+// first corner that decides it, which matters here: blocks straddling the image border are requested
+// again every frame and fail on an early corner, blocks in view pass the "any corner" test at once.
 template <bool Full>
 __device__ inline bool block_visible(int bx, int by, int bz, const FrameParams& P) {
   const int x = (int16_t)(bx << 3), y = (int16_t)(by << 3), z = (int16_t)(bz << 3);
-  bool vis = Full;
-#pragma unroll
+#pragma unroll 1
   for (int i = 0; i < 8; ++i) {
     const int cx = (int16_t)(x + ((i >> 0) & 1) * 7);
     const int cy = (int16_t)(y + ((i >> 1) & 1) * 7);
     const int cz = (int16_t)(z + ((i >> 2) & 1) * 7);
     const bool v = voxel_visible(cx, cy, cz, P);
-    if (Full)
-      vis = vis && v;
-    else
-      vis = vis || v;
+    if (Full && !v) return false;
+    if (!Full && v) return true;
   }
-  return vis;
+  return Full;
 }
 
 // Which of the 8 per-XCD work lists a block belongs to: the image is cut into 8x8 tiles and tiles

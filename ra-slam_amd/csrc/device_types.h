@@ -73,6 +73,7 @@ struct Ctl {
   unsigned long long totals[5];  // frames, sum V, sum U, sum allocated, sum deleted
   uint32_t pad1[4];
   unsigned long long stamps[32];  // diagnostic build only
+  unsigned long long* debug_buf;  // diagnostic build only: per-wave stamps of k_integrate
 };
 constexpr int kCtlFrameBytes = 128;
 constexpr int kNumLists = 8;  // one block list per XCD; list 8 (the 9th segment) holds this frame's new blocks

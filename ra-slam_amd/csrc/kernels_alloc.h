@@ -169,6 +169,13 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
                                          const float* lt, float4* texA, uint2* texB, Request* req,
                                          uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap,
                                          Ctl* ctl) {
+#ifdef RATSDF_STAMPS
+  unsigned long long* ws = (ctl->debug_buf && P.debug == 8) ? ctl->debug_buf + (size_t)((wg * 4 + (threadIdx.x >> 6)) & 16383) * 8 : nullptr;
+  if (ws && (threadIdx.x & 63) == 0) { ws[0] = (unsigned long long)clock64(); ws[5] = wall_clock64(); }
+#define PSTAMP(i) do { if (ws && (threadIdx.x & 63) == 0) ws[i] = (unsigned long long)clock64(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
   const int npix = P.W * P.H;
   const int pix = (int)wg * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -193,6 +200,7 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
     texB[pix] = make_uint2(c, __float_as_uint(wn));
   }
   const bool valid = inb && !(d == 0 || d > P.md);                      // :141
+  PSTAMP(1);
 
   const V3 pcd{pc.x * d, pc.y * d, pc.z * d};
   const V3 pw = se3_apply(P.Ti, pcd);                                   // :146
@@ -245,6 +253,7 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
         p.z += st.z;
       }
     }
+    PSTAMP(2);
     EntryWords ea[4], eb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -256,6 +265,10 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
         eb[i] = load_entry(tab.entries, e0 + 1);
       }
     }
+#ifdef RATSDF_STAMPS
+    if (ws) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PSTAMP(3);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (!need[i]) continue;
@@ -267,6 +280,9 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
       alloc_request_absent(tab, bxs[i], bys[i], bzs[i], (uint32_t)pix * (uint32_t)P.S + (uint32_t)i,
                            ea[i], eb[i], req, req_cap, slow, slow_cap, ctl);
     }
+#ifdef RATSDF_STAMPS
+    if (ws && (threadIdx.x & 63) == 0) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }
+#endif
     return;
   }
   for (int i = 0; i < P.S; ++i) {       // uniform trip count: the shuffles below need every lane

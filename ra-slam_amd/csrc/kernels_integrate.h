@@ -75,10 +75,16 @@ struct VecIO<2> {
 
 // Update of one voxel block by the waves that own it (WPB waves, `part` = which one).  Returns the
 // number of voxels this lane updated and the lane's min |tsdf| after the update.
+#ifdef RATSDF_STAMPS
+#define WSTAMP(i) do { if (wstamps && (threadIdx.x & 63) == 0) wstamps[i] = (unsigned long long)clock64(); } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
 template <int VPL>
 __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, const VisItem& item,
                                        bool fresh_in, uint32_t vi0, const float4* texA,
-                                       const uint2* texB, uint32_t* out_nupd, float* out_min) {
+                                       const uint2* texB, uint32_t* out_nupd, float* out_min,
+                                       unsigned long long* wstamps = nullptr) {
   bool fresh = fresh_in;
   const int tx0 = vi0 & 7, ty = (vi0 >> 3) & 7, tz = vi0 >> 6;
   const size_t v = ((size_t)item.idx << 9) + vi0;
@@ -116,6 +122,7 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
     kk[j] = inb[j] ? w * P.W + u : 0;
     phz[j] = ph.z;
   }
+  WSTAMP(1);
   float4 ta[VPL];
   uint2 tb[VPL];
 #pragma unroll
@@ -128,6 +135,10 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
     ta[j] = texA[kk[j]];           // depth, range, log ht, log lt
     tb[j] = texB[kk[j]];           // rgb, w_new
   }
+#ifdef RATSDF_STAMPS
+  if (wstamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+  WSTAMP(2);
   uint32_t nupd = 0;
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
@@ -163,6 +174,7 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
       ++nupd;
     }
   }
+  WSTAMP(3);
   if ((nupd || fresh) && P.debug != 5 && P.debug != 7) {
     VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.tsdf + v), tv);
     VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), sv);
@@ -207,12 +219,216 @@ __device__ inline void publish_block(uint32_t* blk_info, size_t slot, bool activ
   }
 }
 
+// ---- software-pipelined form of the block update ------------------------------------------------
+// A Stage is one voxel block in flight in a lane's registers.  stage_issue() starts every memory
+// operation of the block (voxel loads, then -- after projecting the lane's voxels -- the texel
+// gathers) and returns without waiting; stage_finish() does the arithmetic and the stores.  A
+// persistent wave keeps one block's loads in flight while it finishes the previous one, so memory
+// latency overlaps arithmetic even with only two waves per SIMD and the grid is small enough to be
+// fully resident (no per-block wave launches).
+template <int VPL>
+struct Stage {
+  VisItem item;
+  uint32_t tv[VPL], sv[VPL], cv[VPL];
+  float4 ta[VPL];
+  uint2 tb[VPL];
+  float phz[VPL];
+  bool inb[VPL];
+  bool active;
+};
+
+template <int VPL>
+__device__ inline void stage_issue(Stage<VPL>& s, const VisItem& item, bool active, const Pool& pool,
+                                   const FrameParams& P, uint32_t vi0, const float4* texA,
+                                   const uint2* texB) {
+  s.item = item;
+  s.active = active;
+  if (!active) return;
+  const int tx0 = vi0 & 7, ty = (vi0 >> 3) & 7, tz = vi0 >> 6;
+  const size_t v = ((size_t)item.idx << 9) + vi0;
+  VecIO<VPL>::load(pool.rgbw + v, s.cv);
+  VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.tsdf + v), s.tv);
+  VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.segm + v), s.sv);
+  const int gy = (int16_t)((int16_t)(item.y << 3) + ty);
+  const int gz = (int16_t)((int16_t)(item.z << 3) + tz);
+  const float wy = (float)gy * P.vs, wz = (float)gz * P.vs;
+  int kk[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int gx = (int16_t)((int16_t)(item.x << 3) + tx0 + j);         // :183-184
+    const V3 pw{(float)gx * P.vs, wy, wz};                              // :187
+    const V3 pc3 = se3_apply(P.T, pw);                                  // :190
+    const V3 ph = intr_mul(P.K, pc3);                                   // :193
+    const int u = f2i(roundf(ph.x / ph.z));                             // :196-199
+    const int w = f2i(roundf(ph.y / ph.z));                             // :202
+    s.inb[j] = u >= 0 && u < P.W && w >= 0 && w < P.H;                  // :205
+    kk[j] = s.inb[j] ? w * P.W + u : 0;
+    s.phz[j] = ph.z;
+  }
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    s.ta[j] = texA[kk[j]];  // depth, range, log ht, log lt
+    s.tb[j] = texB[kk[j]];  // rgb, w_new
+  }
+}
+
+template <int VPL>
+__device__ inline void stage_finish(Stage<VPL>& s, const Pool& pool, const FrameParams& P,
+                                    uint32_t vi0, uint32_t* out_nupd, float* out_min) {
+  *out_nupd = 0;
+  *out_min = 3.0e38f;
+  if (!s.active) return;
+  const size_t v = ((size_t)s.item.idx << 9) + vi0;
+  uint32_t nupd = 0;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float d = s.ta[j].x;
+    const float sdf = s.ta[j].y * (d - s.phz[j]);                       // :216
+    if (s.inb[j] && !(d == 0 || d > P.md) && sdf > -P.trunc) {          // :211,217
+      const float ts = fminf(1, sdf / P.trunc);                         // :218
+      const float wn = __uint_as_float(s.tb[j].y);                      // :226
+      const uint32_t c = s.cv[j];
+      const float wo = (float)(c >> 24);                                // :227
+      const float wc = wo + wn;                                         // :228
+      const float r_old = (float)(c & 0xFFu), g_old = (float)((c >> 8) & 0xFFu),
+                  b_old = (float)((c >> 16) & 0xFFu);
+      const uint32_t cn = s.tb[j].x;
+      const float r_new = (float)(cn & 0xFFu), g_new = (float)((cn >> 8) & 0xFFu),
+                  b_new = (float)((cn >> 16) & 0xFFu);
+      const float rc = (r_old * wo + r_new * wn) / wc;                  // :234-235
+      const float gc = (g_old * wo + g_new * wn) / wc;
+      const float bc = (b_old * wo + b_new * wn) / wc;
+      const float t_old = __uint_as_float(s.tv[j]);
+      s.tv[j] = __float_as_uint((t_old * wo + ts * wn) / wc);           // :236
+      const uint32_t wq = (uint32_t)f2i(fminf(roundf(wc), 40)) & 0xFFu; // :238
+      s.cv[j] = ((uint32_t)f2i(roundf(rc)) & 0xFFu) | (((uint32_t)f2i(roundf(gc)) & 0xFFu) << 8) |
+                (((uint32_t)f2i(roundf(bc)) & 0xFFu) << 16) | (wq << 24);  // :239-240
+      const float pr = __uint_as_float(s.sv[j]);
+      const float pos = __expf((wo * __logf(pr) + wn * s.ta[j].z) / wc);      // :242-244
+      const float neg = __expf((wo * __logf(1 - pr) + wn * s.ta[j].w) / wc);  // :245-247
+      s.sv[j] = __float_as_uint(pos / (pos + neg));                     // :248
+      ++nupd;
+    }
+  }
+  if (nupd) {
+    VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.tsdf + v), s.tv);
+    VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), s.sv);
+    VecIO<VPL>::store(pool.rgbw + v, s.cv);
+  }
+  float m = fabsf(__uint_as_float(s.tv[0]));                            // :253-276
+#pragma unroll
+  for (int j = 1; j < VPL; ++j) m = fminf(m, fabsf(__uint_as_float(s.tv[j])));
+  *out_nupd = nupd;
+  *out_min = m;
+}
+
+// Persistent, software-pipelined k_integrate: grid = kNumLists * G workgroups (G per list, all
+// resident); workgroup (list, g) walks blocks g, g + G, ... of its list with one block's loads always
+// in flight behind the block being updated.  New blocks (allocation winners) are committed and
+// integrated afterwards by all workgroups, as in k_integrate.
+template <int VPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_integrate_pipe(
+    Table tab, Pool pool, FrameParams P, VisItem* vis, uint32_t seg_cap, const Request* req,
+    uint32_t req_cap, const uint32_t* req_k, const float4* texA, const uint2* texB,
+    uint32_t* blk_info, Ctl* ctl) {
+  constexpr int WPB = 8 / VPL;
+  constexpr int BPW = 4 / WPB;
+  __shared__ float smin[4];
+  __shared__ uint32_t supd[4];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t blk_in_wg = wv / WPB, part = wv % WPB;
+  const uint32_t vi0 = (part * 64 + lane) * VPL;
+  const uint32_t list = blockIdx.x & (kNumLists - 1);
+  const uint32_t wg_in_list = blockIdx.x / kNumLists, wgs_per_list = gridDim.x / kNumLists;
+  const VisItem* my_vis = vis + (size_t)list * seg_cap;
+  uint32_t* my_info = blk_info + (size_t)list * seg_cap;
+  // first two items are fetched together with the counters (slots exist even past the list's end)
+  uint32_t it = wg_in_list;
+  const uint32_t ja = it * BPW + blk_in_wg, jb = (it + wgs_per_list) * BPW + blk_in_wg;
+  VisItem item_a = my_vis[ja < seg_cap ? ja : 0];
+  VisItem item_b = my_vis[jb < seg_cap ? jb : 0];
+  uint32_t n_mine = ctl->n_list[list];
+  if (n_mine > seg_cap) n_mine = seg_cap;
+  uint32_t n_req = ctl->n_req;
+  if (n_req > req_cap) n_req = req_cap;
+  const uint32_t n_win = ctl->n_win, alloc_base = ctl->alloc_base;
+
+  Stage<VPL> A, B;
+  if (it * BPW < n_mine) {  // uniform per workgroup
+    stage_issue<VPL>(A, item_a, ja < n_mine, pool, P, vi0, texA, texB);
+    while (true) {
+      // ---- A in flight; start B = next block, then finish A
+      const uint32_t itb = it + wgs_per_list;
+      const bool has_b = itb * BPW < n_mine;
+      const uint32_t jB = itb * BPW + blk_in_wg;
+      if (has_b) {
+        stage_issue<VPL>(B, item_b, jB < n_mine, pool, P, vi0, texA, texB);
+        const uint32_t jn = (itb + wgs_per_list) * BPW + blk_in_wg;
+        item_a = my_vis[jn < seg_cap ? jn : 0];  // prefetch for the block after B
+      }
+      {
+        uint32_t nupd;
+        float m;
+        const uint32_t jA = it * BPW + blk_in_wg;
+        stage_finish<VPL>(A, pool, P, vi0, &nupd, &m);
+        publish_block<WPB>(my_info, jA, A.active, m, nupd, wv, part, lane, smin, supd);
+      }
+      if (!has_b) break;
+      it = itb;
+      // ---- B in flight; start A = next block, then finish B
+      const uint32_t ita = it + wgs_per_list;
+      const bool has_a = ita * BPW < n_mine;
+      const uint32_t jA2 = ita * BPW + blk_in_wg;
+      if (has_a) {
+        stage_issue<VPL>(A, item_a, jA2 < n_mine, pool, P, vi0, texA, texB);
+        const uint32_t jn = (ita + wgs_per_list) * BPW + blk_in_wg;
+        item_b = my_vis[jn < seg_cap ? jn : 0];
+      }
+      {
+        uint32_t nupd;
+        float m;
+        stage_finish<VPL>(B, pool, P, vi0, &nupd, &m);
+        publish_block<WPB>(my_info, jB, B.active, m, nupd, wv, part, lane, smin, supd);
+      }
+      if (!has_a) break;
+      it = ita;
+    }
+  }
+  // this frame's allocation requests: commit (pool index, directory entry, occupancy) + first update
+  for (uint32_t itq = blockIdx.x; itq * BPW < n_req; itq += gridDim.x) {
+    const uint32_t t = itq * BPW + blk_in_wg;
+    bool active = t < n_req;
+    uint32_t k = 0;
+    float m = 3.0e38f;
+    uint32_t nupd = 0;
+    if (active) {
+      const Request r = req[t];
+      uint32_t e = 0;
+      int32_t idx = -1;
+      const bool writer = part == 0 && lane == 0;
+      k = (r.flags & kReqWinner) ? req_k[t] : 0u;
+      active = commit_request(tab, pool, r, k, alloc_base, n_win, writer, &idx, &e) && k < seg_cap;
+      if (active) {
+        const VisItem item{r.x, r.y, r.z, 0, idx, e};
+        if (writer) vis[(size_t)kNumLists * seg_cap + k] = item;
+        integrate_block<VPL>(pool, P, item, true, vi0, texA, texB, &nupd, &m);
+      }
+    }
+    publish_block<WPB>(blk_info, (size_t)kNumLists * seg_cap + k, active, m, nupd, wv, part, lane, smin,
+                       supd);
+  }
+}
+
 // Work lists: `vis` / `blk_info` are kNumLists + 1 segments of seg_cap items.  Segments 0..7 hold the
 // visible blocks that existed before the frame, bucketed by image tile (block_list_of); workgroup b
 // serves list b & 7, which keeps a tile's texels in one XCD's L2.  Segment 8 receives this frame's
 // new blocks (slot = rank among the winners), committed and integrated here by every workgroup.
+// SGPR cap: above 80 SGPRs the hardware admits only 6-7 instead of 8 workgroups of 256 threads per
+// CU (MI355X_MICROARCH.md, residency formula), which pushed the last 20 % of the blocks into a
+// second round of waves.
 template <int VPL>
-__global__ __launch_bounds__(256) void k_integrate(Table tab, Pool pool, FrameParams P, VisItem* vis,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_integrate(Table tab, Pool pool, FrameParams P, VisItem* vis,
                                                    uint32_t seg_cap, const Request* req,
                                                    uint32_t req_cap, const uint32_t* req_k,
                                                    const float4* texA, const uint2* texB,
@@ -243,8 +459,17 @@ __global__ __launch_bounds__(256) void k_integrate(Table tab, Pool pool, FramePa
     const bool active = j < n_mine;
     float m = 3.0e38f;
     uint32_t nupd = 0;
+#ifdef RATSDF_STAMPS
+    unsigned long long* ws = (ctl->debug_buf && P.debug != 8) ? ctl->debug_buf + (size_t)((blockIdx.x * 4 + wv) & 16383) * 8 : nullptr;
+    if (ws && lane == 0 && it == wg_in_list) { ws[0] = (unsigned long long)clock64(); ws[5] = wall_clock64(); }
+#else
+    unsigned long long* ws = nullptr;
+#endif
     if (active) integrate_block<VPL>(pool, P, it == wg_in_list ? first : my_vis[j], false, vi0, texA,
-                                     texB, &nupd, &m);
+                                     texB, &nupd, &m, it == wg_in_list ? ws : nullptr);
+#ifdef RATSDF_STAMPS
+    if (ws && lane == 0 && it == wg_in_list) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }
+#endif
     publish_block<WPB>(blk_info, (size_t)list * seg_cap + j, active, m, nupd, wv, part, lane, smin,
                        supd);
   }
@@ -335,6 +560,14 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
   }
   n_seg[kNumLists] = ctl->n_win < seg_cap ? ctl->n_win : seg_cap;
   nv += n_seg[kNumLists];
+#ifdef RATSDF_STAMPS
+  if (threadIdx.x == 0) {
+    uint32_t mx = 0;
+    for (int l = 0; l < kNumLists; ++l) { ctl->stamps[22] += 0; mx = n_seg[l] > mx ? n_seg[l] : mx; }
+    ctl->stamps[22] += mx;          // max list length
+    ctl->stamps[23] += nv - n_seg[kNumLists];  // sum of list lengths
+  }
+#endif
   // flat index over all lists -> position in the segmented arrays
   auto locate = [&](uint32_t g) -> size_t {
     size_t at = 0;

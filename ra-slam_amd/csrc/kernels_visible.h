@@ -132,7 +132,7 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
 //                                     (longest dependency chain, so it is dispatched first)
 //   workgroups [n_vis_wg, gridDim.x)  allocation candidates + packed texels (alloc_pixels_role)
 // Blocks inserted by this frame join the list in k_integrate (they are visible by construction).
-__global__ __launch_bounds__(256) void k_front(Table tab, FrameParams P, uint32_t n_vis_wg,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(Table tab, FrameParams P, uint32_t n_vis_wg,
                                                const float* depth, const uint8_t* rgb,
                                                const float* ht, const float* lt, float4* texA,
                                                uint2* texB, Request* req, uint32_t req_cap,

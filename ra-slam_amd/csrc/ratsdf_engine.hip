@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "kernels_raycast.h"
@@ -56,6 +57,7 @@ struct ratsdf_engine {
   int vpl = kDefaultVPL;
   int debug = 0;
   unsigned integrate_grid = 4096;
+  unsigned pipe_grid = 0;  // > 0: persistent software-pipelined k_integrate with this many workgroups
 
   Table tab{};
   Pool pool{};
@@ -279,6 +281,14 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
     ++prof_used;
     HIPCHK(hipEventRecord(ev0, stream));
   }
+  if (pipe_grid) {
+    if (vpl == 4)
+      hipLaunchKernelGGL(k_integrate_pipe<4>, dim3(pipe_grid), dim3(256), 0, stream, tab, pool, P,
+                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+    else
+      hipLaunchKernelGGL(k_integrate_pipe<2>, dim3(pipe_grid), dim3(256), 0, stream, tab, pool, P,
+                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+  } else
   switch (vpl) {
     case 8:
       hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
@@ -351,6 +361,10 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     if (x == 2 || x == 4 || x == 8) e->vpl = x;
   }
   if (const char* v = getenv("RATSDF_DEBUG")) e->debug = atoi(v);
+  if (const char* v = getenv("RATSDF_PIPE")) {
+    const int x = atoi(v);
+    if (x >= 8 && x <= 8192 && x % 8 == 0) e->pipe_grid = (unsigned)x;
+  }
   if (const char* v = getenv("RATSDF_GRID")) {
     const int x = atoi(v);
     if (x >= 64 && x <= 65536) e->integrate_grid = (unsigned)x;
@@ -537,6 +551,67 @@ int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
   return RATSDF_OK;
 }
 
+// diagnostic: per-wave stamps of the LAST k_integrate launch (stamps build only)
+extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
+  static unsigned long long* buf = nullptr;
+  const size_t n = 16384 * 8;
+  if (enable) {
+    if (!buf) HIPCHK(hipMalloc(&buf, n * 8));
+    HIPCHK(hipMemsetAsync(buf, 0, n * 8, e->stream));
+    HIPCHK(hipMemcpyAsync(&e->ctl->debug_buf, &buf, sizeof(buf), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RATSDF_OK;
+  }
+  std::vector<unsigned long long> h(n);
+  HIPCHK(hipMemcpyAsync(h.data(), buf, n * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  unsigned long long t0 = ~0ull, t1 = 0;
+  double ph[4] = {0, 0, 0, 0};
+  size_t cnt = 0;
+  std::vector<unsigned long long> starts, ends;
+  for (size_t w = 0; w < 16384; ++w) {
+    const unsigned long long* s = &h[w * 8];
+    if (!s[0] || !s[4] || !s[1]) continue;
+    t0 = s[5] < t0 ? s[5] : t0;
+    t1 = s[6] > t1 ? s[6] : t1;
+    ph[0] += (double)(s[1] - s[0]);
+    ph[1] += (double)(s[2] - s[1]);
+    ph[2] += (double)(s[3] - s[2]);
+    ph[3] += (double)(s[4] - s[3]);
+    starts.push_back(s[5]);
+    ends.push_back(s[6]);
+    ++cnt;
+  }
+  if (!cnt) { fprintf(stderr, "[wave stamps] none\n"); return RATSDF_OK; }
+  {  // phase profile of the slowest 5 % of the waves
+    std::vector<std::pair<unsigned long long, size_t>> dur;
+    for (size_t w = 0; w < 16384; ++w) {
+      const unsigned long long* s = &h[w * 8];
+      if (!s[0] || !s[4] || !s[1]) continue;
+      dur.emplace_back(s[4] - s[0], w);
+    }
+    std::sort(dur.begin(), dur.end());
+    const size_t lo = dur.size() * 95 / 100;
+    double q[4] = {0, 0, 0, 0};
+    for (size_t i = lo; i < dur.size(); ++i) {
+      const unsigned long long* s = &h[dur[i].second * 8];
+      q[0] += (double)(s[1] - s[0]); q[1] += (double)(s[2] - s[1]);
+      q[2] += (double)(s[3] - s[2]); q[3] += (double)(s[4] - s[3]);
+    }
+    const double m = (double)(dur.size() - lo);
+    fprintf(stderr, "[wave stamps] wave duration cycles: p50 %llu p95 %llu max %llu; slowest 5%% phases: %.0f | %.0f | %.0f | %.0f\n",
+            dur[dur.size() / 2].first, dur[lo].first, dur.back().first, q[0] / m, q[1] / m, q[2] / m, q[3] / m);
+  }
+  std::sort(starts.begin(), starts.end());
+  std::sort(ends.begin(), ends.end());
+  fprintf(stderr, "[wave stamps] %zu waves (first block of each); span first-start..last-end = %llu ticks of 10 ns\n", cnt, t1 - t0);
+  fprintf(stderr, "[wave stamps] mean cycles per phase: %.0f | %.0f | %.0f | %.0f  (k_integrate: issue+project | wait loads | math | store; k_front pixels with RATSDF_DEBUG=8: load+texel | ray math | wait lookups | evaluate)\n",
+          ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt);
+  fprintf(stderr, "[wave stamps] start spread: p50 %llu p99 %llu max %llu ; end: p1 %llu p50 %llu (relative to first start)\n",
+          starts[cnt / 2] - t0, starts[cnt * 99 / 100] - t0, starts[cnt - 1] - t0, ends[cnt / 100] - t0, ends[cnt / 2] - t0);
+  return RATSDF_OK;
+}
+
 // diagnostic: prints the accumulated phase stamps of the single-workgroup kernels (stamps build only)
 extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
   unsigned long long t[32];
@@ -550,6 +625,8 @@ extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
   fprintf(stderr, "\n[stamps] rank phases: read_n:%.0f mark:%.0f scan:%.0f tail:%.0f\n",
           (double)(t[12] - t[8]) / n, (double)(t[9] - t[12]) / n, (double)(t[10] - t[9]) / n,
           (double)(t[11] - t[10]) / n);
+  fprintf(stderr, "[stamps] work lists: mean max-list %.1f vs mean per-list %.1f blocks (imbalance %.2fx)\n",
+          (double)t[22] / n, (double)t[23] / n / 8.0, (double)t[22] * 8.0 / (double)(t[23] ? t[23] : 1));
   fprintf(stderr, "[stamps] k_carve: %.0f shader cycles in %.0f wall ticks (100 MHz) -> %.2f GHz\n",
           (double)(t[5] - t[0]) / n, (double)(t[21] - t[20]) / n,
           (double)(t[5] - t[0]) / (double)(t[21] - t[20]) * 0.1);

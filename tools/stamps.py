@@ -19,6 +19,14 @@ for rep in range(4):
         eng.integrate_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), H, W,
                              4.0, f["intrinsics"], f["pose"])
 eng.synchronize()
+ws = eng.lib.dll.ratsdf_debug_wave_stamps
+ws.argtypes = [ctypes.c_void_p, ctypes.c_int]
+import os
+ws(eng._h, 1)
+f, d = frames[10], dd[10]
+eng.integrate_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), H, W, 4.0, f['intrinsics'], f['pose'])
+eng.synchronize()
+ws(eng._h, 0)
 print(eng.last_frame_stats())
 fn = eng.lib.dll.ratsdf_debug_stamps
 fn.argtypes = [ctypes.c_void_p]
