@@ -135,3 +135,100 @@ def test_raycast_matches_oracle(make_engine, make_oracle):
             # one-step difference on a handful of pixels
             assert d.max() <= 1, f"{name}: max byte difference {d.max()}"
             assert (d > 0).mean() < 1e-3, f"{name}: {(d > 0).sum()} bytes differ"
+
+
+def _frame_like(depth, seed=0, pose=None, intr=(300.0, 300.0, 0.0, 0.0)):
+    h, w = depth.shape
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = intr
+    if cx == 0.0:
+        intr = (fx, fy, (w - 1) / 2.0, (h - 1) / 2.0)
+    return dict(rgb=rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8), depth=depth.astype(np.float32),
+                ht=np.clip(rng.random((h, w)), 0.02, 0.98).astype(np.float32),
+                lt=np.clip(rng.random((h, w)), 0.02, 0.98).astype(np.float32),
+                pose=pose or (0, 0, 0, 1, 0, 0, 0), intrinsics=intr)
+
+
+def test_edge_case_inputs(make_engine, make_oracle):
+    """Ragged / degenerate frames the reference would accept: odd image sizes, empty and all-invalid
+    depth, depth exactly at max_depth, NaN depth, ht = 0 (log -> -inf), a 1x1 image."""
+    vs = 0.02
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    rng = np.random.default_rng(3)
+    frames = []
+    d = np.full((61, 83), 1.5, np.float32)                      # odd, non-multiple-of-64 sizes
+    frames.append(_frame_like(d, 1))
+    frames.append(_frame_like(np.zeros((61, 83), np.float32), 2))          # nothing valid
+    frames.append(_frame_like(np.full((61, 83), 9.0, np.float32), 3))      # everything > max_depth
+    d2 = d.copy()
+    d2[::2, ::3] = 4.0                                          # exactly max_depth: w_new = 0
+    d2[5, 7] = np.nan
+    d2[6, 7] = np.inf
+    d2[7, 7] = -1.0                                             # negative depth passes the reference test
+    frames.append(_frame_like(d2, 4))
+    f = _frame_like(d, 5)
+    f["ht"][10:20, 10:30] = 0.0                                 # logf(0) = -inf -> pos = 0
+    f["lt"][10:20, 10:30] = 1.0
+    frames.append(f)
+    frames.append(_frame_like(d + rng.normal(0, 0.01, d.shape).astype(np.float32), 6))
+    for i, f in enumerate(frames):
+        for e in (gpu, cpu):
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+        assert_stats_equal(gpu, cpu)
+        ei, bl = gpu.dump_directory()
+        eo, bo = cpu.dump_directory()
+        assert np.array_equal(ei, eo) and np.array_equal(bl, bo), f"frame {i}"
+        tg, cg, pg = gpu.dump_voxels(bl["idx"])
+        to, co, po = cpu.dump_voxels(bo["idx"])
+        assert np.array_equal(cg, co), f"frame {i}: rgbw"
+        assert np.array_equal(np.isnan(tg), np.isnan(to)) and np.array_equal(np.isnan(pg), np.isnan(po))
+        assert np.nanmax(np.abs(tg - to), initial=0) <= 1e-4 and np.nanmax(np.abs(pg - po), initial=0) <= 1e-4
+    # a different image size on the same engine, then a 1x1 image
+    for shape in [(48, 64), (1, 1)]:
+        f = _frame_like(np.full(shape, 1.2, np.float32), 9)
+        for e in (gpu, cpu):
+            e.integrate(f["rgb"], f["depth"], None, None, 4.0, f["intrinsics"], f["pose"])
+        assert_stats_equal(gpu, cpu)
+    assert_maps_equal(gpu, cpu)
+
+
+def test_rotated_poses_and_long_motion(make_engine, make_oracle):
+    """Poses whose rotation matrix takes the trace <= 0 branches of the matrix->quaternion conversion
+    (180 degree turns about each axis) and a 40-frame sphere sequence with carving churn."""
+    from ratsdf import pose_from_matrix
+    vs = 0.02
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=8)
+    d = np.full((60, 80), 1.0, np.float32)
+    for k, diag in enumerate([(1, -1, -1), (-1, 1, -1), (-1, -1, 1), (1, 1, 1)]):
+        m = np.eye(4, dtype=np.float32)
+        m[0, 0], m[1, 1], m[2, 2] = diag
+        m[:3, 3] = (0.01 * k, -0.02 * k, 0.03)
+        f = _frame_like(d, 20 + k, pose=pose_from_matrix(m))
+        for e in (gpu, cpu):
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+        assert_stats_equal(gpu, cpu)
+    assert_maps_equal(gpu, cpu)
+    deleted = 0
+    for f in synthetic.stream("sphere", 40, scale=0.25, noise=True, holes=True):
+        for e in (gpu, cpu):
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+        assert_stats_equal(gpu, cpu)
+        deleted += gpu.last_frame_stats()["deleted_blocks"]
+    assert deleted > 0
+    assert_maps_equal(gpu, cpu)
+
+
+def test_max_image_size_1080p(make_engine, make_oracle):
+    """The reference's maximum image (MAX_IMG 1920x1080, voxel_tsdf.cu:11-13) at 1 cm voxels."""
+    vs = 0.01
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+    h, w = 1080, 1920
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    d = (1.2 + 0.3 * np.sin(xx / 211.0) * np.cos(yy / 173.0)).astype(np.float32)
+    f = _frame_like(d, 31, intr=(1400.0, 1400.0, 959.5, 539.5))
+    for _ in range(2):
+        for e in (gpu, cpu):
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+        assert_stats_equal(gpu, cpu)
+    assert gpu.last_frame_stats()["visible_blocks"] > 500
+    assert_maps_equal(gpu, cpu)
