@@ -199,6 +199,20 @@ int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* virtual_cam
                           int width, const ratsdf_pose* cam_T_world, float max_depth, void* d_rgba,
                           void* d_normal);
 
+/* ---- mesh export ---------------------------------------------------------------- */
+/* TSDFGrid::GatherValidMesh(vertex_buffer, index_buffer, vertex_prob_buffer),
+ * utils/tsdf/voxel_tsdf.cu:736-845 with marching_cube_kernel :561-715: marching cubes over every
+ * allocated block (voxels observed with weight > 10 only), vertices in metres (3 floats each),
+ * triangles as 3 vertex indices, one probability per vertex.  Buffers are owned by the library until
+ * ratsdf_free_buffer. */
+int ratsdf_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_vertices,
+                             int32_t** indices, size_t* n_triangles, float** vertex_prob);
+/* TSDFSystem::DownloadAllMesh(vertices_path, indices_path, prob_path), modules/tsdf_module.cc:66-86:
+ * three raw files (float3 per vertex, int3 per triangle, float per vertex), the format read by
+ * python_utils/mesh_processor.py:10-15. */
+int ratsdf_download_all_mesh(ratsdf_engine* e, const char* vertices_path, const char* indices_path,
+                             const char* prob_path);
+
 /* ---- multi-GPU support --------------------------------------------------------------------- */
 /* Writes the compact block directory (allocated entries in ascending entry order, 12 B each) into a
  * caller-provided DEVICE buffer so it can be all-gathered with RCCL without touching the host.

@@ -691,6 +691,139 @@ struct ratsdf_engine {
     });
   }
 
+  // ---- marching_cube_kernel + GatherValidMesh, voxel_tsdf.cu:561-845 ---------------------------
+  // Corner / edge conventions of the published table (mcube_table.cuh:14-36): corner i at
+  // kCorner[i]; edge e joins kEdge[e]; a cube owns the three edges leaving its corner 0 along +x,
+  // +y, +z, and every other edge is the owned edge of a neighbouring cube's corner 0.
+  void gather_valid_mesh(std::vector<float>& out_v, std::vector<int32_t>& out_i,
+                         std::vector<float>& out_p) {
+    static const int kCorner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 0, 1}, {0, 0, 1},
+                                      {0, 1, 0}, {1, 1, 0}, {1, 1, 1}, {0, 1, 1}};
+    static const int kEdge[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6},
+                                     {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    static const char* const kCases[256] = {
+#include "mc_cases.inc"
+    };
+    // lower corner and axis of every edge (edge_vertex_map, mcube_table.cuh:34-36), derived
+    int edge_lower[12], edge_dim[12];
+    for (int e = 0; e < 12; ++e) {
+      const int* a = kCorner[kEdge[e][0]];
+      const int* b = kCorner[kEdge[e][1]];
+      int dim = 0;
+      for (int d = 0; d < 3; ++d)
+        if (a[d] != b[d]) dim = d;
+      edge_dim[e] = dim;
+      edge_lower[e] = a[dim] < b[dim] ? kEdge[e][0] : kEdge[e][1];
+    }
+    static const int kAxis[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};  // corners 1, 4, 3
+
+    std::vector<Entry> blocks;
+    for (uint32_t i = 0; i < num_entry; ++i)
+      if (table[i].idx >= 0) blocks.push_back(table[i]);
+    const size_t nb = blocks.size();
+    const size_t VV = 729;  // BLOCK_VERT_VOLUME = 9^3
+    std::vector<float> verts(nb * VV * 9), vprob(nb * VV * 3);
+    std::vector<uint8_t> vmask(nb * VV * 3, 0), tmask(nb * 512 * 5, 0);
+    std::vector<int32_t> tids(nb * 512 * 15, 0);
+    parallel_for(nb, [&](size_t lo, size_t hi, int) {
+      std::vector<float> ct(16 * 16 * 16), cp(16 * 16 * 16);
+      auto at = [](int z, int y, int x) { return (z * 16 + y) * 16 + x; };
+      for (size_t bi = lo; bi < hi; ++bi) {
+        const Entry& base = blocks[bi];
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 2; ++j)
+            for (int k = 0; k < 2; ++k) {
+              Entry nb_e;
+              get_block(S3{(int16_t)(base.pos.x + k), (int16_t)(base.pos.y + j),
+                           (int16_t)(base.pos.z + i)}, &nb_e);
+              for (int tz = 0; tz < 8; ++tz)
+                for (int ty = 0; ty < 8; ++ty)
+                  for (int tx = 0; tx < 8; ++tx) {
+                    float t = -10.f, pr = 0.f;
+                    if (nb_e.idx >= 0) {
+                      const size_t vi = ((size_t)nb_e.idx << 9) + tx + ty * 8 + tz * 64;
+                      if ((int)rgbw[vi].weight > 10) {
+                        t = tsdf[vi];
+                        pr = segm[vi];
+                      }
+                    }
+                    ct[at(i * 8 + tz, j * 8 + ty, k * 8 + tx)] = t;
+                    cp[at(i * 8 + tz, j * 8 + ty, k * 8 + tx)] = pr;
+                  }
+            }
+        // three candidate vertices per lattice point of the 9^3 vertex grid
+        for (size_t c = 0; c < VV; ++c) {
+          const int vx = (int)(c % 9), vy = (int)(c / 9 % 9), vz = (int)(c / 81);
+          const float v1[3] = {(float)(int16_t)((int16_t)(base.pos.x << 3) + vx),
+                               (float)(int16_t)((int16_t)(base.pos.y << 3) + vy),
+                               (float)(int16_t)((int16_t)(base.pos.z << 3) + vz)};
+          const float t1 = ct[at(vz, vy, vx)], p1 = cp[at(vz, vy, vx)];
+          const size_t cube_idx = bi * VV + c;
+          for (int j = 0; j < 3; ++j) {
+            const int* o = kAxis[j];
+            const float t2 = ct[at(vz + o[2], vy + o[1], vx + o[0])];
+            const float p2 = cp[at(vz + o[2], vy + o[1], vx + o[0])];
+            const float sfac = (-t1) / (t2 - t1);
+            for (int d = 0; d < 3; ++d)
+              verts[(cube_idx * 3 + j) * 3 + d] = (v1[d] + sfac * (float)o[d]) * vs;
+            vprob[cube_idx * 3 + j] = (p1 + p2) / 2;
+          }
+        }
+        for (int tz = 0; tz < 8; ++tz)
+          for (int ty = 0; ty < 8; ++ty)
+            for (int tx = 0; tx < 8; ++tx) {
+              float lt[8];
+              int cubeindex = 0;
+              for (int i = 0; i < 8; ++i) {
+                lt[i] = ct[at(tz + kCorner[i][2], ty + kCorner[i][1], tx + kCorner[i][0])];
+                cubeindex |= (lt[i] < 0) << i;
+              }
+              const char* cs = kCases[cubeindex];
+              const int ntri = (int)(strlen(cs) / 3);
+              const size_t thread_idx = bi * 512 + (size_t)(tx + ty * 8 + tz * 64);
+              for (int i = 0; i < 5; ++i) {
+                const size_t tri = thread_idx * 5 + i;
+                if (i >= ntri) continue;  // mask stays 0
+                tmask[tri] = 1;
+                for (int j = 0; j < 3; ++j) {
+                  const char ch = cs[i * 3 + j];
+                  const int e = ch <= '9' ? ch - '0' : ch - 'a' + 10;
+                  const float diff = fabsf(lt[kEdge[e][1]] - lt[kEdge[e][0]]);
+                  if ((double)diff < 1e-3 || diff >= 2) {  // :692-696
+                    tmask[tri] = 0;
+                    break;
+                  }
+                  const int* lo_c = kCorner[edge_lower[e]];
+                  const size_t coi = (size_t)((lo_c[2] + tz) * 81 + (lo_c[1] + ty) * 9 + (lo_c[0] + tx));
+                  const size_t cube_idx = bi * VV + coi;
+                  tids[tri * 3 + j] = (int32_t)(cube_idx * 3 + edge_dim[e]);
+                  vmask[cube_idx * 3 + edge_dim[e]] = 1;
+                }
+              }
+            }
+      }
+    });
+    // compaction (prefix_sum + compactify_kernel + transform_triangle_id_kernel, :782-813)
+    std::vector<int32_t> vmap(vmask.size());
+    int32_t run = 0;
+    for (size_t i = 0; i < vmask.size(); ++i) {
+      vmap[i] = run;
+      run += vmask[i];
+    }
+    out_v.clear();
+    out_p.clear();
+    out_i.clear();
+    out_v.reserve((size_t)run * 3);
+    for (size_t i = 0; i < vmask.size(); ++i)
+      if (vmask[i]) {
+        out_v.insert(out_v.end(), &verts[i * 3], &verts[i * 3] + 3);
+        out_p.push_back(vprob[i]);
+      }
+    for (size_t t = 0; t < tmask.size(); ++t)
+      if (tmask[t])
+        for (int j = 0; j < 3; ++j) out_i.push_back(vmap[(size_t)tids[t * 3 + j]]);
+  }
+
   template <class Rec, bool Semantic>
   int download(const std::vector<Entry>& blocks, Rec** out, size_t* n) {
     const size_t cnt = blocks.size() * RATSDF_BLOCK_VOLUME;
@@ -905,6 +1038,59 @@ int ratsdf_oracle_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int heig
 int ratsdf_oracle_raycast_device(ratsdf_engine*, const ratsdf_intrinsics*, int, int,
                                  const ratsdf_pose*, float, void*, void*) {
   return RATSDF_ERR_NOT_IMPLEMENTED;
+}
+
+int ratsdf_oracle_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_vertices,
+                                    int32_t** indices, size_t* n_triangles, float** vertex_prob) {
+  if (!e || !vertices || !n_vertices || !indices || !n_triangles || !vertex_prob)
+    return RATSDF_ERR_BAD_ARGUMENT;
+  std::vector<float> v, p;
+  std::vector<int32_t> idx;
+  e->gather_valid_mesh(v, idx, p);
+  float* bv = (float*)malloc(v.size() * 4 + 4);
+  float* bp = (float*)malloc(p.size() * 4 + 4);
+  int32_t* bi = (int32_t*)malloc(idx.size() * 4 + 4);
+  if (!bv || !bp || !bi) return RATSDF_ERR_DEVICE;
+  memcpy(bv, v.data(), v.size() * 4);
+  memcpy(bp, p.data(), p.size() * 4);
+  memcpy(bi, idx.data(), idx.size() * 4);
+  *vertices = bv;
+  *vertex_prob = bp;
+  *indices = bi;
+  *n_vertices = p.size();
+  *n_triangles = idx.size() / 3;
+  return RATSDF_OK;
+}
+
+static int write_mesh_files(const char* vp, const char* ip, const char* pp, const float* v, size_t nv,
+                            const int32_t* idx, size_t nt, const float* pr) {
+  FILE* fv = fopen(vp, "wb");
+  FILE* fp = fopen(pp, "wb");
+  FILE* fi = fopen(ip, "wb");
+  const bool ok = fv && fp && fi;
+  if (ok) {
+    fwrite(v, 12, nv, fv);
+    fwrite(pr, 4, nv, fp);
+    fwrite(idx, 12, nt, fi);
+  }
+  if (fv) fclose(fv);
+  if (fp) fclose(fp);
+  if (fi) fclose(fi);
+  return ok ? RATSDF_OK : RATSDF_ERR_BAD_ARGUMENT;
+}
+
+int ratsdf_oracle_download_all_mesh(ratsdf_engine* e, const char* vp, const char* ip,
+                                    const char* pp) {
+  if (!e || !vp || !ip || !pp) return RATSDF_ERR_BAD_ARGUMENT;
+  float *v = nullptr, *pr = nullptr;
+  int32_t* idx = nullptr;
+  size_t nv = 0, nt = 0;
+  int st = ratsdf_oracle_gather_valid_mesh(e, &v, &nv, &idx, &nt, &pr);
+  if (st == RATSDF_OK) st = write_mesh_files(vp, ip, pp, v, nv, idx, nt, pr);
+  free(v);
+  free(pr);
+  free(idx);
+  return st;
 }
 
 int ratsdf_oracle_export_directory_device(ratsdf_engine*, void*, int32_t, void*) {

@@ -13,7 +13,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "kernels_raycast.h"
+#include "kernels_mesh.h"
 
 using namespace ratsdf;
 
@@ -89,6 +89,7 @@ struct ratsdf_engine {
   uint32_t* dbitmap = nullptr;   // delete bitmap indexed by hash entry (self-cleaning)
   uint32_t* dsummary = nullptr;
   uint32_t* dprefix = nullptr;
+  void* d_mc = nullptr;   // marching-cubes tables (device), built on first use
   uint32_t vis_cap = 0;   // total items of `vis` / `carve_flag`
   uint32_t seg_cap = 0;   // items per work list (vis holds kNumLists + 1 segments)
   uint32_t dwords = 0;
@@ -146,7 +147,7 @@ int ratsdf_engine::free_all() {
                   d_stats, texA, texB, req, req_k, abitmap, asummary, aprefix,
                   slow, xlocks,
                   distinct, masks, wg_count, vis, carve_flag, dbitmap, dsummary, dprefix,
-                  slowdel, d_stage};
+                  slowdel, d_stage, d_mc};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h_stage) (void)hipHostFree(h_stage);
@@ -767,6 +768,123 @@ int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int
     if (err != hipSuccess) st = RATSDF_ERR_DEVICE;
   }
   (void)hipFree(d);
+  return st;
+}
+
+// exclusive positions of the set items of a 0/1 mask; returns the number of set items
+static int mask_positions(ratsdf_engine* e, const uint32_t* mask, size_t n, uint32_t* pos,
+                          uint32_t* scratch_tiles, uint32_t* d_total, uint32_t* h_total) {
+  const uint32_t ntiles = (uint32_t)((n + kScanTile - 1) / kScanTile);
+  hipLaunchKernelGGL(k_mask_tile_sums, dim3(ntiles), dim3(1024), 0, e->stream, mask, n, scratch_tiles);
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, e->stream, scratch_tiles, ntiles,
+                     d_total);
+  hipLaunchKernelGGL(k_mask_positions, dim3(ntiles), dim3(1024), 0, e->stream, mask, n, scratch_tiles,
+                     pos);
+  HIPCHK(hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RATSDF_OK;
+}
+
+int ratsdf_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_vertices,
+                             int32_t** indices, size_t* n_triangles, float** vertex_prob) {
+  if (!e || !vertices || !n_vertices || !indices || !n_triangles || !vertex_prob)
+    return RATSDF_ERR_BAD_ARGUMENT;
+  int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);  // check_valid_kernel + GatherBlock
+  if (st != RATSDF_OK) return st;
+  uint32_t nb = 0;
+  HIPCHK(hipMemcpyAsync(&nb, &e->ctl->n_sel, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *vertices = (float*)malloc(4);
+  *vertex_prob = (float*)malloc(4);
+  *indices = (int32_t*)malloc(4);
+  *n_vertices = 0;
+  *n_triangles = 0;
+  if (nb == 0) return RATSDF_OK;
+  const size_t nvs = (size_t)nb * kVertVolume * 3;  // candidate vertices
+  const size_t nts = (size_t)nb * 512 * 5;          // candidate triangles
+  if (!e->d_mc) {
+    const McTables h = make_mc_tables();
+    HIPCHK(hipMalloc(&e->d_mc, sizeof(McTables)));
+    HIPCHK(hipMemcpy(e->d_mc, &h, sizeof(McTables), hipMemcpyHostToDevice));
+  }
+  // one scratch allocation: verts | vprob | vmask | vpos | tids | tmask | tpos | tile sums | total
+  const size_t ntile_max = (nts > nvs ? nts : nvs) / kScanTile + 2;
+  const size_t bytes = nvs * 12 + nvs * 4 * 3 + nts * 12 + nts * 4 * 2 + ntile_max * 4 + 64;
+  uint8_t* d = nullptr;
+  HIPCHK(hipMalloc(&d, bytes));
+  float* verts = (float*)d;
+  float* vprob = verts + nvs * 3;
+  uint32_t* vmask = (uint32_t*)(vprob + nvs);
+  uint32_t* vpos = vmask + nvs;
+  int32_t* tids = (int32_t*)(vpos + nvs);
+  uint32_t* tmask = (uint32_t*)(tids + nts * 3);
+  uint32_t* tpos = tmask + nts;
+  uint32_t* tiles = tpos + nts;
+  uint32_t* d_total = tiles + ntile_max;
+  hipLaunchKernelGGL(k_marching_cubes, dim3(nb), dim3(512), 0, e->stream, e->tab, e->pool, e->vis,
+                     (const McTables*)e->d_mc, e->vs, verts, vprob, vmask, tids, tmask);
+  uint32_t nv = 0, nt = 0;
+  st = mask_positions(e, vmask, nvs, vpos, tiles, d_total, &nv);
+  if (st == RATSDF_OK) st = mask_positions(e, tmask, nts, tpos, tiles, d_total, &nt);
+  if (st != RATSDF_OK) {
+    (void)hipFree(d);
+    return st;
+  }
+  free(*vertices);
+  free(*vertex_prob);
+  free(*indices);
+  *vertices = (float*)malloc((size_t)nv * 12 + 4);
+  *vertex_prob = (float*)malloc((size_t)nv * 4 + 4);
+  *indices = (int32_t*)malloc((size_t)nt * 12 + 4);
+  uint8_t* o = nullptr;
+  hipError_t err = hipMalloc(&o, (size_t)nv * 16 + (size_t)nt * 12 + 64);
+  if (err == hipSuccess) {
+    float* ov = (float*)o;
+    float* op = ov + (size_t)nv * 3;
+    int32_t* oi = (int32_t*)(op + nv);
+    hipLaunchKernelGGL(k_compact_vertices, dim3(2048), dim3(256), 0, e->stream, verts, vprob, vmask,
+                       vpos, nvs, ov, op);
+    hipLaunchKernelGGL(k_compact_triangles, dim3(2048), dim3(256), 0, e->stream, tids, tmask, tpos,
+                       vpos, nts, oi);
+    if (nv) err = hipMemcpyAsync(*vertices, ov, (size_t)nv * 12, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess && nv)
+      err = hipMemcpyAsync(*vertex_prob, op, (size_t)nv * 4, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess && nt)
+      err = hipMemcpyAsync(*indices, oi, (size_t)nt * 12, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(o);
+  }
+  (void)hipFree(d);
+  if (err != hipSuccess) return RATSDF_ERR_DEVICE;
+  *n_vertices = nv;
+  *n_triangles = nt;
+  return RATSDF_OK;
+}
+
+int ratsdf_download_all_mesh(ratsdf_engine* e, const char* vp, const char* ip, const char* pp) {
+  if (!e || !vp || !ip || !pp) return RATSDF_ERR_BAD_ARGUMENT;
+  float *v = nullptr, *pr = nullptr;
+  int32_t* idx = nullptr;
+  size_t nv = 0, nt = 0;
+  int st = ratsdf_gather_valid_mesh(e, &v, &nv, &idx, &nt, &pr);
+  if (st == RATSDF_OK) {  // modules/tsdf_module.cc:66-86
+    FILE* fv = fopen(vp, "wb");
+    FILE* fp = fopen(pp, "wb");
+    FILE* fi = fopen(ip, "wb");
+    if (fv && fp && fi) {
+      fwrite(v, 12, nv, fv);
+      fwrite(pr, 4, nv, fp);
+      fwrite(idx, 12, nt, fi);
+    } else {
+      st = RATSDF_ERR_BAD_ARGUMENT;
+    }
+    if (fv) fclose(fv);
+    if (fp) fclose(fp);
+    if (fi) fclose(fi);
+  }
+  free(v);
+  free(pr);
+  free(idx);
   return st;
 }
 

@@ -21,6 +21,8 @@ struct Api {
   int (*download_all)(ratsdf_engine*, const char*) = nullptr;
   int (*raycast)(ratsdf_engine*, const ratsdf_intrinsics*, int, int, const ratsdf_pose*, float,
                  uint8_t*, uint8_t*) = nullptr;
+  int (*gather_valid_mesh)(ratsdf_engine*, float**, size_t*, int32_t**, size_t*, float**) = nullptr;
+  int (*download_all_mesh)(ratsdf_engine*, const char*, const char*, const char*) = nullptr;
   int (*free_buffer)(void*) = nullptr;
   int (*num_active_blocks)(ratsdf_engine*, int32_t*) = nullptr;
   const char* (*status_string)(int) = nullptr;
@@ -50,7 +52,12 @@ class TSDFGrid {
   std::vector<VoxelSpatialTSDF> GatherValid();                                   // :86
   std::vector<VoxelSpatialTSDFSEGM> GatherValidSemantic();                       // :93
   std::vector<VoxelSpatialTSDF> GatherVoxels(const BoundingCube<float>& volumn);  // :102
+  // voxel_tsdf.cuh:104-106 (Vector3f / Vector3i buffers become flat float / int arrays, 3 per item)
+  void GatherValidMesh(std::vector<float>* vertex_buffer, std::vector<int32_t>* index_buffer,
+                       std::vector<float>* vertex_prob_buffer);
   void DownloadAll(const std::string& file_path);  // the write of tsdf_module.cc:57-64
+  void DownloadAllMesh(const std::string& vertices_path, const std::string& indices_path,
+                       const std::string& prob_path);  // tsdf_module.cc:66-86
   int NumActiveBlock();                            // voxel_hash.cu:225
   int last_status() const { return status_; }
   ratsdf_engine* handle() { return engine_; }

@@ -11,8 +11,7 @@
 //     the reference (tsdf_module.cc:91-94,119-125).  Knowingly fixed: terminate() is idempotent
 //     (the reference's destructor joins a second time and would throw), and Flush() is added so a
 //     harness can wait for the queue to drain first.
-//   * Render writes into host buffers instead of OpenGL textures; DownloadAllMesh (marching cubes)
-//     is outside this build's scope.
+//   * Render writes into host buffers instead of OpenGL textures.
 #pragma once
 #include <condition_variable>
 #include <memory>
@@ -50,6 +49,8 @@ class TSDFSystem {
   void Render(const CameraParams& virtual_cam, const SE3<float> cam_T_world, uint8_t* img_rgba,
               uint8_t* img_normal, float max_depth);
   void DownloadAll(const std::string& file_path);
+  void DownloadAllMesh(const std::string& vertices_path, const std::string& indices_path,
+                       const std::string& prob_path);  // tsdf_module.h:119-120
   bool is_terminated();
   void terminate();
   void SetPause(bool pause);

@@ -58,6 +58,10 @@ const Api& Api::Load(const char* path, const char* prefix) {
       reinterpret_cast<decltype(api.gather_valid_semantic)>(sym("gather_valid_semantic"));
   api.download_all = reinterpret_cast<decltype(api.download_all)>(sym("download_all"));
   api.raycast = reinterpret_cast<decltype(api.raycast)>(sym("raycast"));
+  api.gather_valid_mesh =
+      reinterpret_cast<decltype(api.gather_valid_mesh)>(sym("gather_valid_mesh"));
+  api.download_all_mesh =
+      reinterpret_cast<decltype(api.download_all_mesh)>(sym("download_all_mesh"));
   api.free_buffer = reinterpret_cast<decltype(api.free_buffer)>(sym("free_buffer"));
   api.num_active_blocks = reinterpret_cast<decltype(api.num_active_blocks)>(sym("num_active_blocks"));
   api.status_string = reinterpret_cast<decltype(api.status_string)>(sym("status_string"));
@@ -147,6 +151,27 @@ std::vector<VoxelSpatialTSDF> TSDFGrid::GatherVoxels(const BoundingCube<float>& 
   return out;
 }
 
+void TSDFGrid::GatherValidMesh(std::vector<float>* vb, std::vector<int32_t>* ib,
+                               std::vector<float>* pb) {
+  if (!engine_ || !vb || !ib || !pb) return;
+  float *v = nullptr, *p = nullptr;
+  int32_t* idx = nullptr;
+  size_t nv = 0, nt = 0;
+  note(api_->gather_valid_mesh(engine_, &v, &nv, &idx, &nt, &p), "GatherValidMesh");
+  if (status_ == RATSDF_OK) {
+    vb->assign(v, v + nv * 3);
+    pb->assign(p, p + nv);
+    ib->assign(idx, idx + nt * 3);
+  }
+  if (v) api_->free_buffer(v);
+  if (p) api_->free_buffer(p);
+  if (idx) api_->free_buffer(idx);
+}
+
+void TSDFGrid::DownloadAllMesh(const std::string& vp, const std::string& ip, const std::string& pp) {
+  if (engine_) note(api_->download_all_mesh(engine_, vp.c_str(), ip.c_str(), pp.c_str()), "DownloadAllMesh");
+}
+
 void TSDFGrid::DownloadAll(const std::string& path) {
   if (engine_) note(api_->download_all(engine_, path.c_str()), "DownloadAll");
 }
@@ -218,6 +243,12 @@ void TSDFSystem::Render(const CameraParams& virtual_cam, const SE3<float> cam_T_
 void TSDFSystem::DownloadAll(const std::string& file_path) {
   std::lock_guard<std::mutex> lock(mtx_read_);
   tsdf_.DownloadAll(file_path);
+}
+
+void TSDFSystem::DownloadAllMesh(const std::string& vertices_path, const std::string& indices_path,
+                                 const std::string& prob_path) {
+  std::lock_guard<std::mutex> lock(mtx_read_);
+  tsdf_.DownloadAllMesh(vertices_path, indices_path, prob_path);
 }
 
 void TSDFSystem::Run() {

@@ -69,7 +69,8 @@ SYMBOLS = [
     "synchronize", "stream",
     "profile_enable", "profile_read", "totals",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
-    "download_all", "free_buffer", "raycast", "raycast_device", "export_directory_device", "test_allocate", "test_delete",
+    "download_all", "free_buffer", "raycast", "raycast_device", "gather_valid_mesh", "download_all_mesh",
+    "export_directory_device", "test_allocate", "test_delete",
     "test_retrieve", "test_assign_rgbw", "dump_directory", "dump_voxels", "dump_heap",
     "status_string", "backend",
 ]
@@ -117,6 +118,9 @@ class Library:
         self.fn["raycast"].argtypes = [vp, C.POINTER(Intrinsics), C.c_int, C.c_int, C.POINTER(Pose),
                                        C.c_float, vp, vp]
         self.fn["raycast_device"].argtypes = self.fn["raycast"].argtypes
+        self.fn["gather_valid_mesh"].argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                                 C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
+        self.fn["download_all_mesh"].argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p]
         self.fn["export_directory_device"].argtypes = [vp, vp, C.c_int32, vp]
         self.fn["test_allocate"].argtypes = [vp, vp, C.c_int32]
         self.fn["test_delete"].argtypes = [vp, vp, C.c_int32]
@@ -316,6 +320,23 @@ class Engine:
                                       float(max_depth), rgba.ctypes.data, normal.ctypes.data),
                "raycast")
         return rgba, normal
+
+    def gather_valid_mesh(self):
+        """TSDFGrid::GatherValidMesh (voxel_tsdf.cu:736-845): (vertices [n,3] f32 metres,
+        triangles [m,3] i32, per-vertex probability [n] f32)."""
+        pv, pi, pp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nv, nt = C.c_size_t(), C.c_size_t()
+        _check(self.lib.fn["gather_valid_mesh"](self._h, C.byref(pv), C.byref(nv), C.byref(pi),
+                                                C.byref(nt), C.byref(pp)), "gather_valid_mesh")
+        v = self._take(pv, nv.value * 3, np.dtype("<f4")).reshape(-1, 3)
+        i = self._take(pi, nt.value * 3, np.dtype("<i4")).reshape(-1, 3)
+        p = self._take(pp, nv.value, np.dtype("<f4"))
+        return v, i, p
+
+    def download_all_mesh(self, vertices_path, indices_path, prob_path):
+        _check(self.lib.fn["download_all_mesh"](self._h, str(vertices_path).encode(),
+                                                str(indices_path).encode(),
+                                                str(prob_path).encode()), "download_all_mesh")
 
     def export_directory_device(self, d_blocks, capacity, d_count):
         _check(self.lib.fn["export_directory_device"](self._h, d_blocks, capacity, d_count),

@@ -107,6 +107,22 @@ int main(int argc, char** argv) {
       size_t hit = 0;
       for (size_t i = 3; i < a.size(); i += 4) hit += a[i] == 255;
       CHECK(hit > (size_t)W * H / 4);
+      // mesh export through the system == through the grid (DownloadAllMesh, tsdf_module.cc:66-86)
+      std::vector<float> mv, mp;
+      std::vector<int32_t> mi;
+      grid.GatherValidMesh(&mv, &mi, &mp);
+      CHECK(mv.size() > 300 && mi.size() > 300 && mp.size() * 3 == mv.size());
+      sys.DownloadAllMesh("/tmp/ratsdf_host_v.bin", "/tmp/ratsdf_host_i.bin", "/tmp/ratsdf_host_p.bin");
+      FILE* fi = fopen("/tmp/ratsdf_host_i.bin", "rb");
+      CHECK(fi != nullptr);
+      std::vector<int32_t> fi_data(mi.size());
+      CHECK(fread(fi_data.data(), 4, mi.size(), fi) == mi.size());
+      CHECK(fgetc(fi) == EOF);
+      fclose(fi);
+      CHECK(fi_data == mi);
+      remove("/tmp/ratsdf_host_v.bin");
+      remove("/tmp/ratsdf_host_i.bin");
+      remove("/tmp/ratsdf_host_p.bin");
       sys.Render(cam, frames[0].pose, a.data(), nullptr, 0.5f);  // too short to reach the surface
       hit = 0;
       for (size_t i = 3; i < a.size(); i += 4) hit += a[i] == 255;
