@@ -63,6 +63,34 @@ __device__ inline int f2i(float f) {
   return r;
 }
 
+// IEEE-exact division with a shared divisor.  hipcc expands `a / b` (correctly rounded, no fast-math)
+// into: r0 = rcp(b); e = fma(-b, r0, 1); r1 = fma(e, r0, r0); q0 = a * r1; e2 = fma(-b, q0, a);
+// q1 = fma(e2, r1, q0); e3 = fma(-b, q1, a); q = fma(e3, r1, q1), wrapped in v_div_scale /
+// v_div_fixup for operands near the ends of the exponent range and for inf / NaN / 0.  When several
+// numerators share one divisor the refined reciprocal r1 is computed once and every quotient costs
+// five instructions instead of ten -- the same FMA sequence, hence the same correctly rounded result,
+// for finite operands away from the exponent limits (|b| in [2^-60, 2^60], quotient not subnormal),
+// which is what the callers guarantee or guard.
+struct Recip {
+  float d, r1;
+};
+__device__ inline Recip make_recip(float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e = fmaf(-d, r0, 1.f);
+  return Recip{d, fmaf(e, r0, r0)};
+}
+__device__ inline float div_shared(float a, const Recip& b) {
+  const float q0 = a * b.r1;
+  const float e2 = fmaf(-b.d, q0, a);
+  const float q1 = fmaf(e2, b.r1, q0);
+  const float e3 = fmaf(-b.d, q1, a);
+  return fmaf(e3, b.r1, q1);
+}
+__device__ inline bool recip_safe(float d) {  // divisor range in which div_shared equals IEEE `/`
+  const float ad = fabsf(d);
+  return ad > 1e-18f && ad < 1e18f;
+}
+
 // Hash(), utils/tsdf/voxel_hash.cu:19-23
 __host__ __device__ inline uint32_t block_hash(int x, int y, int z, uint32_t mask) {
   return (((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349669u) ^ ((uint32_t)z * 83492791u)) & mask;

@@ -204,16 +204,32 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
 
   const V3 pcd{pc.x * d, pc.y * d, pc.z * d};
   const V3 pw = se3_apply(P.Ti, pcd);                                   // :146
-  const V3 dc{pc.x / r, pc.y / r, pc.z / r};                            // :148
+  // shared-divisor divisions (device_math.h): r in [1, ~3], voxel size a frame constant
+  const Recip rr = make_recip(r), rvs = make_recip(P.vs);
+  const bool vs_ok = recip_safe(P.vs);  // uniform
+  const V3 dc{div_shared(pc.x, rr), div_shared(pc.y, rr), div_shared(pc.z, rr)};     // :148
   const V3 dw = quat_rotate(P.Ti.q, dc);                                // :150
   const V3 sw{pw.x - dw.x * P.trunc, pw.y - dw.y * P.trunc, pw.z - dw.z * P.trunc};  // :151
-  const V3 dg{dw.x / P.vs, dw.y / P.vs, dw.z / P.vs};                   // :153
-  const V3 sg{sw.x / P.vs, sw.y / P.vs, sw.z / P.vs};                   // :154
+  V3 dg, sg;
+  if (vs_ok && fabsf(sw.x) < 1e18f && fabsf(sw.y) < 1e18f && fabsf(sw.z) < 1e18f) {
+    dg = V3{div_shared(dw.x, rvs), div_shared(dw.y, rvs), div_shared(dw.z, rvs)};     // :153
+    sg = V3{div_shared(sw.x, rvs), div_shared(sw.y, rvs), div_shared(sw.z, rvs)};     // :154
+  } else {
+    dg = V3{dw.x / P.vs, dw.y / P.vs, dw.z / P.vs};
+    sg = V3{sw.x / P.vs, sw.y / P.vs, sw.z / P.vs};
+  }
   const float two_tr = 2 * P.trunc;
   const V3 rg{two_tr * dg.x, two_tr * dg.y, two_tr * dg.z};             // :155
   int steps = f2i(ceilf(fmaxf(fmaxf(fabsf(rg.x), fabsf(rg.y)), fabsf(rg.z)) / RATSDF_BLOCK_LEN));
   const float den = fmaxf((float)steps, 1);
-  const V3 st{rg.x / den, rg.y / den, rg.z / den};                      // :159
+  // :159 -- dividing by 1, 2, 4, ... is an exact scaling, so multiply by the exact reciprocal then
+  V3 st;
+  if (steps <= 2 || (steps & (steps - 1)) == 0) {
+    const float inv = 1.f / den;  // exact for powers of two
+    st = V3{rg.x * inv, rg.y * inv, rg.z * inv};
+  } else {
+    st = V3{rg.x / den, rg.y / den, rg.z / den};
+  }
   if (valid && steps >= P.S) {  // cannot happen for |dir| <= 1; keep ranks unique regardless
     set_error(ctl, RATSDF_ERR_CAPACITY);
     steps = P.S - 1;

@@ -155,11 +155,15 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
       const uint32_t cn = tb[j].x;
       const float r_new = (float)(cn & 0xFFu), g_new = (float)((cn >> 8) & 0xFFu),
                   b_new = (float)((cn >> 16) & 0xFFu);
-      const float rc = (r_old * wo + r_new * wn) / wc;                  // :234-235
-      const float gc = (g_old * wo + g_new * wn) / wc;
-      const float bc = (b_old * wo + b_new * wn) / wc;
+      // wc = weight (1..40) + w_new (0..4): six quotients share it (division, :234-247)
+      const Recip rwc = make_recip(wc);
+      const float rc = div_shared(r_old * wo + r_new * wn, rwc);        // :234-235
+      const float gc = div_shared(g_old * wo + g_new * wn, rwc);
+      const float bc = div_shared(b_old * wo + b_new * wn, rwc);
       const float t_old = __uint_as_float(tv[j]);
-      tv[j] = __float_as_uint((t_old * wo + ts * wn) / wc);             // :236
+      const float t_num = t_old * wo + ts * wn;
+      // a NaN / inf tsdf can only come from NaN / inf inputs; keep IEEE semantics for them
+      tv[j] = __float_as_uint(fabsf(t_num) < 1e18f ? div_shared(t_num, rwc) : t_num / wc);  // :236
       const uint32_t wq = (uint32_t)f2i(fminf(roundf(wc), 40)) & 0xFFu; // :238
       cv[j] = ((uint32_t)f2i(roundf(rc)) & 0xFFu) | (((uint32_t)f2i(roundf(gc)) & 0xFFu) << 8) |
               (((uint32_t)f2i(roundf(bc)) & 0xFFu) << 16) | (wq << 24); // :239-240
@@ -167,8 +171,10 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
       if (P.debug != 6) {  // diagnostic 6: no transcendental part
       // hardware exp2/log2 based exp/log (v_exp_f32 / v_log_f32, ~1e-7 relative): the only
       // functions of the path whose last bits differ between any two libms anyway
-      const float pos = __expf((wo * __logf(pr) + wn * ta[j].z) / wc);      // :242-244
-      const float neg = __expf((wo * __logf(1 - pr) + wn * ta[j].w) / wc);  // :245-247
+      // log(0) = -inf is a legal input here (ht = 0, :242-247): guard the shared-divisor form
+      const float lp = wo * __logf(pr) + wn * ta[j].z, ln = wo * __logf(1 - pr) + wn * ta[j].w;
+      const float pos = __expf(fabsf(lp) < 1e18f ? div_shared(lp, rwc) : lp / wc);  // :242-244
+      const float neg = __expf(fabsf(ln) < 1e18f ? div_shared(ln, rwc) : ln / wc);  // :245-247
       sv[j] = __float_as_uint(pos / (pos + neg));                       // :248
       }
       ++nupd;
@@ -295,17 +301,20 @@ __device__ inline void stage_finish(Stage<VPL>& s, const Pool& pool, const Frame
       const uint32_t cn = s.tb[j].x;
       const float r_new = (float)(cn & 0xFFu), g_new = (float)((cn >> 8) & 0xFFu),
                   b_new = (float)((cn >> 16) & 0xFFu);
-      const float rc = (r_old * wo + r_new * wn) / wc;                  // :234-235
-      const float gc = (g_old * wo + g_new * wn) / wc;
-      const float bc = (b_old * wo + b_new * wn) / wc;
+      const Recip rwc = make_recip(wc);
+      const float rc = div_shared(r_old * wo + r_new * wn, rwc);        // :234-235
+      const float gc = div_shared(g_old * wo + g_new * wn, rwc);
+      const float bc = div_shared(b_old * wo + b_new * wn, rwc);
       const float t_old = __uint_as_float(s.tv[j]);
-      s.tv[j] = __float_as_uint((t_old * wo + ts * wn) / wc);           // :236
+      const float t_num = t_old * wo + ts * wn;
+      s.tv[j] = __float_as_uint(fabsf(t_num) < 1e18f ? div_shared(t_num, rwc) : t_num / wc);  // :236
       const uint32_t wq = (uint32_t)f2i(fminf(roundf(wc), 40)) & 0xFFu; // :238
       s.cv[j] = ((uint32_t)f2i(roundf(rc)) & 0xFFu) | (((uint32_t)f2i(roundf(gc)) & 0xFFu) << 8) |
                 (((uint32_t)f2i(roundf(bc)) & 0xFFu) << 16) | (wq << 24);  // :239-240
       const float pr = __uint_as_float(s.sv[j]);
-      const float pos = __expf((wo * __logf(pr) + wn * s.ta[j].z) / wc);      // :242-244
-      const float neg = __expf((wo * __logf(1 - pr) + wn * s.ta[j].w) / wc);  // :245-247
+      const float lp = wo * __logf(pr) + wn * s.ta[j].z, ln = wo * __logf(1 - pr) + wn * s.ta[j].w;
+      const float pos = __expf(fabsf(lp) < 1e18f ? div_shared(lp, rwc) : lp / wc);  // :242-244
+      const float neg = __expf(fabsf(ln) < 1e18f ? div_shared(ln, rwc) : ln / wc);  // :245-247
       s.sv[j] = __float_as_uint(pos / (pos + neg));                     // :248
       ++nupd;
     }
