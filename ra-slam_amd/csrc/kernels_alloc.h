@@ -285,16 +285,56 @@ __device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P,
     if (ws) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     PSTAMP(3);
+    // lookup first (cheap, usually a hit); the 8-corner frustum test only for absent blocks (both are
+    // pure predicates; the reference tests visibility first, :165-166)
+    bool absent[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (!need[i]) continue;
-      const uint32_t e0 = block_hash(bxs[i], bys[i], bzs[i], tab.bucket_mask) << 1;
-      // lookup first (cheap, usually a hit), the 8-corner frustum test only for absent blocks
-      // (both are pure predicates; the reference tests visibility first, :165-166)
-      if (block_present_pre(tab, key0(bxs[i], bys[i]), key1(bzs[i]), e0, ea[i], eb[i])) continue;
-      if (!block_visible<true>(bxs[i], bys[i], bzs[i], P)) continue;
-      alloc_request_absent(tab, bxs[i], bys[i], bzs[i], (uint32_t)pix * (uint32_t)P.S + (uint32_t)i,
-                           ea[i], eb[i], req, req_cap, slow, slow_cap, ctl);
+      absent[i] = false;
+      if (need[i]) {
+        const uint32_t e0 = block_hash(bxs[i], bys[i], bzs[i], tab.bucket_mask) << 1;
+        absent[i] = !block_present_pre(tab, key0(bxs[i], bys[i]), key1(bzs[i]), e0, ea[i], eb[i]);
+      }
+    }
+    // Frustum test of the wave's absent candidates, spread over the lanes: 8 candidates x 8 corners
+    // per step (is_block_visible<true>, voxel_tsdf.cu:75-96).  A lane that owns an absent candidate
+    // would otherwise walk its 8 corners alone while the other 63 lanes idle -- those waves (image
+    // border, freshly carved blocks) were the tail of this kernel.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i >= P.S) break;  // uniform
+      unsigned long long todo = __ballot(absent[i]);
+      unsigned long long ok = 0;
+      while (todo) {  // uniform
+        unsigned long long packed = 0;  // up to 8 owner lanes, one byte each, 0xFF = none
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          unsigned long long o = 0xFFull;
+          if (todo) {
+            o = (unsigned long long)(__ffsll((long long)todo) - 1);
+            todo &= todo - 1;
+          }
+          packed |= o << (8 * k);
+        }
+        const uint32_t own = (uint32_t)(packed >> (8 * (lane >> 3))) & 0xFFu;
+        const int src = own == 0xFFu ? 0 : (int)own;
+        const int cbx = __shfl(bxs[i], src), cby = __shfl(bys[i], src), cbz = __shfl(bzs[i], src);
+        const int c = lane & 7;
+        const int cx = (int16_t)((int16_t)(cbx << 3) + ((c >> 0) & 1) * 7);
+        const int cy = (int16_t)((int16_t)(cby << 3) + ((c >> 1) & 1) * 7);
+        const int cz = (int16_t)((int16_t)(cbz << 3) + ((c >> 2) & 1) * 7);
+        const bool v = own == 0xFFu || voxel_visible(cx, cy, cz, P);
+        const unsigned long long b = __ballot(v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned long long o = (packed >> (8 * k)) & 0xFFull;
+          if (o != 0xFFull && ((b >> (8 * k)) & 0xFFull) == 0xFFull) ok |= 1ull << o;
+        }
+      }
+      if (absent[i] && ((ok >> lane) & 1ull)) {
+        alloc_request_absent(tab, bxs[i], bys[i], bzs[i], (uint32_t)pix * (uint32_t)P.S + (uint32_t)i,
+                             ea[i], eb[i], req, req_cap, slow, slow_cap, ctl);
+      }
     }
 #ifdef RATSDF_STAMPS
     if (ws && (threadIdx.x & 63) == 0) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }

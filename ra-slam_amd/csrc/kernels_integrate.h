@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_in
     float m = 3.0e38f;
     uint32_t nupd = 0;
 #ifdef RATSDF_STAMPS
-    unsigned long long* ws = (ctl->debug_buf && P.debug != 8) ? ctl->debug_buf + (size_t)((blockIdx.x * 4 + wv) & 16383) * 8 : nullptr;
+    unsigned long long* ws = (ctl->debug_buf && P.debug != 8 && P.debug != 10) ? ctl->debug_buf + (size_t)((blockIdx.x * 4 + wv) & 16383) * 8 : nullptr;
     if (ws && lane == 0 && it == wg_in_list) { ws[0] = (unsigned long long)clock64(); ws[5] = wall_clock64(); }
 #else
     unsigned long long* ws = nullptr;

@@ -79,6 +79,13 @@ __device__ inline void select_flags_role(const Table& tab, const FrameParams& P,
 __device__ inline void visible_append_role(const Table& tab, const FrameParams& P, uint32_t wg,
                                            VisItem* vis, uint32_t seg_cap, Ctl* ctl) {
   __shared__ uint32_t cnt[kNumLists], base[kNumLists], cnt2[kNumLists];
+#ifdef RATSDF_STAMPS
+  unsigned long long* ws = (ctl->debug_buf && P.debug == 10) ? ctl->debug_buf + (size_t)((wg * 4 + (threadIdx.x >> 6)) & 16383) * 8 : nullptr;
+  if (ws && (threadIdx.x & 63) == 0) { ws[0] = (unsigned long long)clock64(); ws[5] = wall_clock64(); }
+#define VSTAMP(i) do { if (ws && (threadIdx.x & 63) == 0) ws[i] = (unsigned long long)clock64(); } while (0)
+#else
+#define VSTAMP(i) do { } while (0)
+#endif
   const uint32_t nwords = tab.num_entry >> 6;
   const uint32_t w = wg * kVisWG + threadIdx.x;
   if (threadIdx.x < kNumLists) {
@@ -87,6 +94,7 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
   }
   __syncthreads();
   unsigned long long occ = w < nwords ? tab.occ[w] : 0ull;
+  VSTAMP(1);
   unsigned long long sel = 0, l0 = 0, l1 = 0, l2 = 0;  // selection mask + 3 bit planes of the list id
   while (occ) {
     const int b = __ffsll((long long)occ) - 1;
@@ -103,12 +111,14 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
       atomicAdd(&cnt[l], 1u);
     }
   }
+  VSTAMP(2);
   __syncthreads();
   if (threadIdx.x < kNumLists) {
     const uint32_t c = cnt[threadIdx.x];
     base[threadIdx.x] = c ? atomicAdd(&ctl->n_list[threadIdx.x], c) : 0u;
   }
   __syncthreads();
+  VSTAMP(3);
   while (sel) {
     const int b = __ffsll((long long)sel) - 1;
     sel &= sel - 1;
@@ -125,6 +135,9 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
       reinterpret_cast<uint4*>(vis)[(size_t)l * seg_cap + pos] = v;
     }
   }
+#ifdef RATSDF_STAMPS
+  if (ws && (threadIdx.x & 63) == 0) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }
+#endif
 }
 
 // k_front: the two directory-read-only jobs of a frame in one launch.
