@@ -8,9 +8,12 @@
 // outcome is made a pure function of the input: every candidate carries its raster rank
 // (pixel * S + sample) and the pass computes exactly what a sequential, rank-ordered execution of
 // the reference code would:
-//   alloc_pixels_role  per pixel: candidates, directory lookup, atomicMin(claim[bucket], rank) for
-//                      ordinary buckets ("first requester in raster order wins the bucket lock"),
-//                      append to a small slow list for chained / full buckets (part of k_front)
+//   cand_pixels_role   per pixel: candidate blocks -> the frame's candidate set {block, smallest
+//                      rank}; no directory access (kernels_cand.h; runs ahead of the frame)
+//   cand_consume_role  per distinct candidate: directory lookup, frustum test,
+//                      atomicMin(claim[bucket], rank) for ordinary buckets ("first requester in
+//                      raster order wins the bucket lock"), append to a small slow list for chained
+//                      / full buckets (part of k_front)
 //   k_alloc_rank       one workgroup: (a) replays the slow list in rank order against the claim
 //                      table (time-dependent lock / fill queries), so chain appends lock, link and
 //                      defeat later claims exactly as the sequential code would; (b) winners
@@ -156,219 +159,11 @@ __device__ inline void alloc_request_absent(const Table& t, int x, int y, int z,
   }
 }
 
+}  // namespace ratsdf
+#include "kernels_cand.h"  // the per-pixel candidate pass and its consumer (uses the helpers above)
+namespace ratsdf {
+
 // ---------------------------------------------------------------------------------------------
-// alloc_pixels_role: block_allocate_kernel, voxel_tsdf.cu:120-168.  One lane per pixel, 64 consecutive
-// pixels of a row per wave (coalesced depth / ht / lt reads).  Also writes the packed per-pixel
-// texels the integration kernel gathers from: texA = {depth, range, log ht, log lt},
-// texB = {rgb, w_new}.  log(ht), log(lt) and w_new = (1 - d/max_depth)*4 are functions of the pixel
-// only (voxel_tsdf.cu:226,243,246), so evaluating them once per pixel instead of once per voxel is
-// value-identical.
-// ---------------------------------------------------------------------------------------------
-__device__ inline void alloc_pixels_role(const Table& tab, const FrameParams& P, uint32_t wg,
-                                         const float* depth, const uint8_t* rgb, const float* ht,
-                                         const float* lt, float4* texA, uint2* texB, Request* req,
-                                         uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap,
-                                         Ctl* ctl) {
-#ifdef RATSDF_STAMPS
-  unsigned long long* ws = (ctl->debug_buf && P.debug == 8) ? ctl->debug_buf + (size_t)((wg * 4 + (threadIdx.x >> 6)) & 16383) * 8 : nullptr;
-  if (ws && (threadIdx.x & 63) == 0) { ws[0] = (unsigned long long)clock64(); ws[5] = wall_clock64(); }
-#define PSTAMP(i) do { if (ws && (threadIdx.x & 63) == 0) ws[i] = (unsigned long long)clock64(); } while (0)
-#else
-#define PSTAMP(i) do { } while (0)
-#endif
-  const int npix = P.W * P.H;
-  const int pix = (int)wg * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const bool inb = pix < npix;
-  const int px = inb ? pix % P.W : 0;
-  const int py = inb ? pix / P.W : 0;
-  const float d = inb ? depth[pix] : 0.f;
-
-  const V3 pimg{(float)px, (float)py, 1.f};
-  const V3 pc = intr_mul(P.Ki, pimg);                                   // :137
-  const float r = sqrtf(pc.x * pc.x + (pc.y * pc.y + pc.z * pc.z));     // :140 (Eigen norm order)
-  if (inb) {
-    float lh = 0.f, ll = 0.f;
-    if (P.has_sem) {
-      lh = __logf(ht[pix]);  // same function as the per-voxel log in k_integrate
-      ll = __logf(lt[pix]);
-    }
-    const float wn = (1 - d / P.md) * 4;
-    const uint32_t c = (uint32_t)rgb[3 * pix] | ((uint32_t)rgb[3 * pix + 1] << 8) |
-                       ((uint32_t)rgb[3 * pix + 2] << 16);
-    texA[pix] = make_float4(d, r, lh, ll);
-    texB[pix] = make_uint2(c, __float_as_uint(wn));
-  }
-  const bool valid = inb && !(d == 0 || d > P.md);                      // :141
-  PSTAMP(1);
-
-  const V3 pcd{pc.x * d, pc.y * d, pc.z * d};
-  const V3 pw = se3_apply(P.Ti, pcd);                                   // :146
-  // shared-divisor divisions (device_math.h): r in [1, ~3], voxel size a frame constant
-  const Recip rr = make_recip(r), rvs = make_recip(P.vs);
-  const bool vs_ok = recip_safe(P.vs);  // uniform
-  const V3 dc{div_shared(pc.x, rr), div_shared(pc.y, rr), div_shared(pc.z, rr)};     // :148
-  const V3 dw = quat_rotate(P.Ti.q, dc);                                // :150
-  const V3 sw{pw.x - dw.x * P.trunc, pw.y - dw.y * P.trunc, pw.z - dw.z * P.trunc};  // :151
-  V3 dg, sg;
-  if (vs_ok && fabsf(sw.x) < 1e18f && fabsf(sw.y) < 1e18f && fabsf(sw.z) < 1e18f) {
-    dg = V3{div_shared(dw.x, rvs), div_shared(dw.y, rvs), div_shared(dw.z, rvs)};     // :153
-    sg = V3{div_shared(sw.x, rvs), div_shared(sw.y, rvs), div_shared(sw.z, rvs)};     // :154
-  } else {
-    dg = V3{dw.x / P.vs, dw.y / P.vs, dw.z / P.vs};
-    sg = V3{sw.x / P.vs, sw.y / P.vs, sw.z / P.vs};
-  }
-  const float two_tr = 2 * P.trunc;
-  const V3 rg{two_tr * dg.x, two_tr * dg.y, two_tr * dg.z};             // :155
-  int steps = f2i(ceilf(fmaxf(fmaxf(fabsf(rg.x), fabsf(rg.y)), fabsf(rg.z)) / RATSDF_BLOCK_LEN));
-  const float den = fmaxf((float)steps, 1);
-  // :159 -- dividing by 1, 2, 4, ... is an exact scaling, so multiply by the exact reciprocal then
-  V3 st;
-  if (steps <= 2 || (steps & (steps - 1)) == 0) {
-    const float inv = 1.f / den;  // exact for powers of two
-    st = V3{rg.x * inv, rg.y * inv, rg.z * inv};
-  } else {
-    st = V3{rg.x / den, rg.y / den, rg.z / den};
-  }
-  if (valid && steps >= P.S) {  // cannot happen for |dir| <= 1; keep ranks unique regardless
-    set_error(ctl, RATSDF_ERR_CAPACITY);
-    steps = P.S - 1;
-  }
-  V3 p = sg;
-  uint32_t prev0 = kInf, prev1 = kInf;  // this lane's previous sample
-  if (P.debug == 1) return;
-  if (P.S <= 4) {
-    // Batched form (S = 3 for truncation = 6 voxels): derive all candidate blocks first, then put
-    // every directory lookup of the lane in flight at once, then evaluate.  Same requests, same
-    // ranks as the sequential form below; only the memory latency overlaps.
-    int bxs[4], bys[4], bzs[4];
-    bool need[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      need[i] = false;
-      bxs[i] = bys[i] = bzs[i] = 0;
-      if (i < P.S) {  // uniform
-        const bool act = valid && i <= steps;
-        const int gx = (int16_t)f2i(roundf(p.x)), gy = (int16_t)f2i(roundf(p.y)),
-                  gz = (int16_t)f2i(roundf(p.z));                         // :163-164
-        const int bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
-        const uint32_t k0 = act ? key0(bx, by) : kInf;
-        const uint32_t k1 = act ? key1(bz) : kInf;
-        const uint32_t n0 = __shfl_up(k0, 1), n1 = __shfl_up(k1, 1);
-        const bool dup = (k0 == prev0 && k1 == prev1) || (lane > 0 && k0 == n0 && k1 == n1);
-        need[i] = act && !dup && shard_owned(bx, P) && P.debug != 2;
-        bxs[i] = bx;
-        bys[i] = by;
-        bzs[i] = bz;
-        if (act) {
-          prev0 = k0;
-          prev1 = k1;
-        }
-        p.x += st.x;
-        p.y += st.y;
-        p.z += st.z;
-      }
-    }
-    PSTAMP(2);
-    EntryWords ea[4], eb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ea[i] = EntryWords{0, 0, -1};
-      eb[i] = EntryWords{0, 0, -1};
-      if (need[i]) {
-        const uint32_t e0 = block_hash(bxs[i], bys[i], bzs[i], tab.bucket_mask) << 1;
-        ea[i] = load_entry(tab.entries, e0);
-        eb[i] = load_entry(tab.entries, e0 + 1);
-      }
-    }
-#ifdef RATSDF_STAMPS
-    if (ws) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    PSTAMP(3);
-    // lookup first (cheap, usually a hit); the 8-corner frustum test only for absent blocks (both are
-    // pure predicates; the reference tests visibility first, :165-166)
-    bool absent[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      absent[i] = false;
-      if (need[i]) {
-        const uint32_t e0 = block_hash(bxs[i], bys[i], bzs[i], tab.bucket_mask) << 1;
-        absent[i] = !block_present_pre(tab, key0(bxs[i], bys[i]), key1(bzs[i]), e0, ea[i], eb[i]);
-      }
-    }
-    // Frustum test of the wave's absent candidates, spread over the lanes: 8 candidates x 8 corners
-    // per step (is_block_visible<true>, voxel_tsdf.cu:75-96).  A lane that owns an absent candidate
-    // would otherwise walk its 8 corners alone while the other 63 lanes idle -- those waves (image
-    // border, freshly carved blocks) were the tail of this kernel.
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i >= P.S) break;  // uniform
-      unsigned long long todo = __ballot(absent[i]);
-      unsigned long long ok = 0;
-      while (todo) {  // uniform
-        unsigned long long packed = 0;  // up to 8 owner lanes, one byte each, 0xFF = none
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          unsigned long long o = 0xFFull;
-          if (todo) {
-            o = (unsigned long long)(__ffsll((long long)todo) - 1);
-            todo &= todo - 1;
-          }
-          packed |= o << (8 * k);
-        }
-        const uint32_t own = (uint32_t)(packed >> (8 * (lane >> 3))) & 0xFFu;
-        const int src = own == 0xFFu ? 0 : (int)own;
-        const int cbx = __shfl(bxs[i], src), cby = __shfl(bys[i], src), cbz = __shfl(bzs[i], src);
-        const int c = lane & 7;
-        const int cx = (int16_t)((int16_t)(cbx << 3) + ((c >> 0) & 1) * 7);
-        const int cy = (int16_t)((int16_t)(cby << 3) + ((c >> 1) & 1) * 7);
-        const int cz = (int16_t)((int16_t)(cbz << 3) + ((c >> 2) & 1) * 7);
-        const bool v = own == 0xFFu || voxel_visible(cx, cy, cz, P);
-        const unsigned long long b = __ballot(v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const unsigned long long o = (packed >> (8 * k)) & 0xFFull;
-          if (o != 0xFFull && ((b >> (8 * k)) & 0xFFull) == 0xFFull) ok |= 1ull << o;
-        }
-      }
-      if (absent[i] && ((ok >> lane) & 1ull)) {
-        alloc_request_absent(tab, bxs[i], bys[i], bzs[i], (uint32_t)pix * (uint32_t)P.S + (uint32_t)i,
-                             ea[i], eb[i], req, req_cap, slow, slow_cap, ctl);
-      }
-    }
-#ifdef RATSDF_STAMPS
-    if (ws && (threadIdx.x & 63) == 0) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }
-#endif
-    return;
-  }
-  for (int i = 0; i < P.S; ++i) {       // uniform trip count: the shuffles below need every lane
-    const bool act = valid && i <= steps;
-    const int gx = (int16_t)f2i(roundf(p.x)), gy = (int16_t)f2i(roundf(p.y)),
-              gz = (int16_t)f2i(roundf(p.z));                           // :163-164
-    const int bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
-    const uint32_t k0 = act ? key0(bx, by) : kInf;
-    const uint32_t k1 = act ? key1(bz) : kInf;
-    // A later request for the same block never matters (the earlier one either inserts it or fails
-    // on a lock that stays taken), so drop repeats of the previous sample / the previous pixel.
-    const uint32_t n0 = __shfl_up(k0, 1), n1 = __shfl_up(k1, 1);
-    const bool dup = (k0 == prev0 && k1 == prev1) || (lane > 0 && k0 == n0 && k1 == n1);
-    if (act && !dup && shard_owned(bx, P) && P.debug != 2) {
-      EntryWords w;
-      if (find_block(tab, bx, by, bz, &w) == kInf && block_visible<true>(bx, by, bz, P)) {
-        alloc_request(tab, bx, by, bz, (uint32_t)pix * (uint32_t)P.S + (uint32_t)i, req, req_cap,
-                      slow, slow_cap, ctl);
-      }
-    }
-    if (act) {
-      prev0 = k0;
-      prev1 = k1;
-    }
-    p.x += st.x;
-    p.y += st.y;
-    p.z += st.z;
-  }
-}
-
 // test hook: explicit request list, rank = list index (utils/tests/voxel_hash_test.cu:36-39)
 __global__ void k_alloc_list(Table tab, FrameParams P, const int16_t* pos, int n, Request* req,
                              uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap, Ctl* ctl) {
@@ -642,7 +437,11 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, ui
                                                      uint32_t slow_cap, XLock* xlocks,
                                                      SlowRequest* distinct, uint32_t* bitmap,
                                                      uint32_t* summary, uint32_t* prefix,
-                                                     uint32_t nwords, Ctl* ctl) {
+                                                     uint32_t nwords, Ctl* ctl, CandJob next) {
+  if (blockIdx.x != 0) {  // extra workgroups: a share of the NEXT frame's candidate pass
+    cand_pixels_role(next, blockIdx.x - 1, ctl);
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
   uint32_t* lds = reinterpret_cast<uint32_t*>(skeys);  // [0,32): scan scratch, [32]: counter
   uint32_t* lds_rank = lds + 64;                       // kSmallRank words

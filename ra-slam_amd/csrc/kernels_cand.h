@@ -1,0 +1,315 @@
+// kernels_cand.h -- the directory-independent half of block_allocate_kernel
+// (utils/tsdf/voxel_tsdf.cu:120-168) for gfx950.
+//
+// Which blocks a frame asks for depends only on its depth image and pose: the ray samples of every
+// valid pixel, rounded to voxels and shifted to blocks (:137-164).  Whether a request then inserts
+// anything depends on the directory (:165-166).  The first part is ~700 VALU instructions per pixel
+// wave and touches no map state, so it does not have to sit on the frame's critical path: when the
+// caller hands over a batch of frames (ratsdf_integrate_device_batch = the queue of
+// TSDFSystem::Run, modules/tsdf_module.cc:88-115), the candidate pass of frame f+1 runs as extra
+// workgroups inside the two single-workgroup kernels of frame f (k_alloc_rank, k_carve), which leave
+// 255 of the 256 CUs idle.  A single frame (ratsdf_integrate_device) runs it as its own launch.
+//
+// Output of the pass = the frame's candidate set: every distinct requested block with the SMALLEST
+// raster rank (pixel * S + sample) that asked for it.  Only that request matters: under the
+// canonical raster-order execution a later request for the same block finds it either inserted by
+// the first one or blocked by a bucket lock that stays taken until the end of the pass
+// (voxel_hash.cu:46-108), so it can never change the directory.  A 640x480 frame has ~0.9 M samples
+// but only a few thousand distinct blocks; the directory-dependent half (cand_consume_role, in
+// k_front) then does a few thousand lookups instead of ~100 k.
+//
+// The set is an open-addressing table keyed by block position {keys: 48-bit position, ranks:
+// atomicMin of the rank}; the lane that inserts a key also appends its slot to one of 64 slot lists
+// (64 counters on separate cache lines: a single-address atomic sustains only ~90 ops/us on this
+// part).  The consumer empties every slot it reads, so the table is clean for the frame after next
+// (two sets, used alternately).  Also written here: the packed per-pixel texels k_integrate gathers
+// from (texA = {depth, range, log ht, log lt}, texB = {rgb, w_new}); log(ht), log(lt) and
+// w_new = (1 - d / max_depth) * 4 are functions of the pixel only (voxel_tsdf.cu:226,243,246).
+#pragma once
+// included from the middle of kernels_alloc.h (needs its request helpers, is needed by k_alloc_rank)
+#include "device_math.h"
+
+namespace ratsdf {
+
+constexpr int kCandSegs = 64;           // slot lists (and consumer workgroups) per candidate set
+constexpr int kCandCountStride = 32;    // words between list counters (one 128-byte line each)
+constexpr unsigned long long kCandEmpty = ~0ull;
+
+struct CandSet {
+  unsigned long long* keys;  // [slot_mask + 1], kCandEmpty = free
+  uint32_t* ranks;           // [slot_mask + 1], kInf = none
+  uint4* list;               // [kCandSegs][seg_cap] {key lo, key hi, slot, -}, list = slot & 63
+  uint32_t* count;           // [kCandSegs * kCandCountStride]
+  uint32_t slot_mask;
+  uint32_t seg_cap;          // (slot_mask + 1) / kCandSegs: a list can never overflow
+};
+
+// one candidate pass (or a share of it): pixels [first_pixel, first_pixel + n_pixels) of the frame
+struct CandJob {
+  FrameParams P;
+  const float* depth;
+  const uint8_t* rgb;
+  const float* ht;
+  const float* lt;
+  float4* texA;
+  uint2* texB;
+  CandSet set;
+  uint32_t first_pixel, n_pixels;
+  uint32_t pixels_per_wg;  // <= blockDim.x; the remaining threads of a workgroup only join barriers
+};
+
+__device__ inline unsigned long long ld_agent_u64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// record "block (k0,k1) was requested with raster rank `rank`".  One returning atomic (the CAS) on
+// the common path; the rank update is a fire-and-forget atomicMin.
+__device__ inline void cand_insert(const CandSet& cs, uint32_t k0, uint32_t k1, int bx, int by, int bz,
+                                   uint32_t rank, Ctl* ctl) {
+  const unsigned long long key = (unsigned long long)k0 | ((unsigned long long)k1 << 32);
+  uint32_t s = block_hash(bx, by, bz, cs.slot_mask);
+  for (uint32_t guard = 0; guard <= cs.slot_mask; ++guard) {
+    const unsigned long long k = atomicCAS(&cs.keys[s], kCandEmpty, key);
+    if (k == kCandEmpty || k == key) {
+      atomicMin(&cs.ranks[s], rank);
+      if (k == kCandEmpty) {  // this lane inserted the key: publish the slot
+        const uint32_t l = s & (kCandSegs - 1);
+        const uint32_t pos = atomicAdd(&cs.count[l * kCandCountStride], 1u);
+        cs.list[(size_t)l * cs.seg_cap + pos] = make_uint4(k0, k1, s, 0u);
+      }
+      return;
+    }
+    s = (s + 1) & cs.slot_mask;
+  }
+  set_error(ctl, RATSDF_ERR_CAPACITY);
+}
+
+// Workgroup-level pre-aggregation: the pixels of one workgroup ask for the same few dozen blocks over
+// and over (a 640x480 / 5 mm frame: ~100 k lane-distinct requests, ~5 k distinct blocks), and a
+// global insert is two dependent L2 round trips plus atomics.  Requests first meet in a small LDS
+// set of the same shape; after a barrier every occupied LDS slot is flushed by one lane.  A request
+// that finds the LDS set full goes to the global set directly.
+constexpr uint32_t kCandLdsSlots = 512;
+
+struct CandLds {
+  unsigned long long keys[kCandLdsSlots];
+  uint32_t ranks[kCandLdsSlots];
+};
+
+__device__ inline bool cand_lds_insert(CandLds& L, unsigned long long key, uint32_t h, uint32_t rank) {
+  uint32_t s = h & (kCandLdsSlots - 1);
+  for (uint32_t guard = 0; guard < 32; ++guard) {
+    unsigned long long k = L.keys[s];
+    if (k == kCandEmpty) k = atomicCAS(&L.keys[s], kCandEmpty, key);
+    if (k == kCandEmpty || k == key) {
+      atomicMin(&L.ranks[s], rank);
+      return true;
+    }
+    s = (s + 1) & (kCandLdsSlots - 1);
+  }
+  return false;
+}
+
+// block_allocate_kernel up to (not including) the directory lookup, one lane per pixel, 64
+// consecutive pixels of a row per wave.  `wg` counts workgroups of blockDim.x pixels inside the job.
+__device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg, Ctl* ctl) {
+  const FrameParams& P = J.P;
+  const uint32_t rel = wg * J.pixels_per_wg + threadIdx.x;
+  const int pix = (int)(J.first_pixel + rel);
+  const int lane = threadIdx.x & 63;
+  const bool inb = threadIdx.x < J.pixels_per_wg && rel < J.n_pixels && pix < P.W * P.H;
+  const int px = inb ? pix % P.W : 0;
+  const int py = inb ? pix / P.W : 0;
+  const float d = inb ? J.depth[pix] : 0.f;
+
+  const V3 pimg{(float)px, (float)py, 1.f};
+  const V3 pc = intr_mul(P.Ki, pimg);                                   // :137
+  const float r = sqrtf(pc.x * pc.x + (pc.y * pc.y + pc.z * pc.z));     // :140 (Eigen norm order)
+  if (inb) {
+    float lh = 0.f, ll = 0.f;
+    if (P.has_sem) {
+      lh = __logf(J.ht[pix]);  // same function as the per-voxel log of the reference's update
+      ll = __logf(J.lt[pix]);
+    }
+    const float wn = (1 - d / P.md) * 4;
+    const uint32_t c = (uint32_t)J.rgb[3 * pix] | ((uint32_t)J.rgb[3 * pix + 1] << 8) |
+                       ((uint32_t)J.rgb[3 * pix + 2] << 16);
+    J.texA[pix] = make_float4(d, r, lh, ll);
+    J.texB[pix] = make_uint2(c, __float_as_uint(wn));
+  }
+  const bool valid = inb && !(d == 0 || d > P.md);                      // :141
+  if (P.debug == 1) return;  // uniform
+
+  const V3 pcd{pc.x * d, pc.y * d, pc.z * d};
+  const V3 pw = se3_apply(P.Ti, pcd);                                   // :146
+  // shared-divisor divisions (device_math.h): r in [1, ~3], voxel size a frame constant
+  const Recip rr = make_recip(r), rvs = make_recip(P.vs);
+  const bool vs_ok = recip_safe(P.vs);  // uniform
+  const V3 dc{div_shared(pc.x, rr), div_shared(pc.y, rr), div_shared(pc.z, rr)};     // :148
+  const V3 dw = quat_rotate(P.Ti.q, dc);                                // :150
+  const V3 sw{pw.x - dw.x * P.trunc, pw.y - dw.y * P.trunc, pw.z - dw.z * P.trunc};  // :151
+  V3 dg, sg;
+  if (vs_ok && fabsf(sw.x) < 1e18f && fabsf(sw.y) < 1e18f && fabsf(sw.z) < 1e18f) {
+    dg = V3{div_shared(dw.x, rvs), div_shared(dw.y, rvs), div_shared(dw.z, rvs)};     // :153
+    sg = V3{div_shared(sw.x, rvs), div_shared(sw.y, rvs), div_shared(sw.z, rvs)};     // :154
+  } else {
+    dg = V3{dw.x / P.vs, dw.y / P.vs, dw.z / P.vs};
+    sg = V3{sw.x / P.vs, sw.y / P.vs, sw.z / P.vs};
+  }
+  const float two_tr = 2 * P.trunc;
+  const V3 rg{two_tr * dg.x, two_tr * dg.y, two_tr * dg.z};             // :155
+  int steps = f2i(ceilf(fmaxf(fmaxf(fabsf(rg.x), fabsf(rg.y)), fabsf(rg.z)) / RATSDF_BLOCK_LEN));
+  const float den = fmaxf((float)steps, 1);
+  // :159 -- dividing by 1, 2, 4, ... is an exact scaling, so multiply by the exact reciprocal then
+  V3 st;
+  if (steps <= 2 || (steps & (steps - 1)) == 0) {
+    const float inv = 1.f / den;  // exact for powers of two
+    st = V3{rg.x * inv, rg.y * inv, rg.z * inv};
+  } else {
+    st = V3{rg.x / den, rg.y / den, rg.z / den};
+  }
+  if (valid && steps >= P.S) {  // cannot happen for |dir| <= 1; keep ranks unique regardless
+    set_error(ctl, RATSDF_ERR_CAPACITY);
+    steps = P.S - 1;
+  }
+  V3 p = sg;
+  uint32_t prev0 = kInf, prev1 = kInf;  // this lane's previous sample
+  for (int i = 0; i < P.S; ++i) {       // uniform trip count: the shuffles below need every lane
+    const bool act = valid && i <= steps;
+    const int gx = (int16_t)f2i(roundf(p.x)), gy = (int16_t)f2i(roundf(p.y)),
+              gz = (int16_t)f2i(roundf(p.z));                           // :163-164
+    const int bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
+    const uint32_t k0 = act ? key0(bx, by) : kInf;
+    const uint32_t k1 = act ? key1(bz) : kInf;
+    // repeats of the previous sample / the previous pixel carry a larger rank for the same block
+    const uint32_t n0 = __shfl_up(k0, 1), n1 = __shfl_up(k1, 1);
+    const bool dup = (k0 == prev0 && k1 == prev1) || (lane > 0 && k0 == n0 && k1 == n1);
+    if (act && !dup && shard_owned(bx, P) && P.debug != 2) {
+      const uint32_t rank = (uint32_t)pix * (uint32_t)P.S + (uint32_t)i;
+      const unsigned long long key = (unsigned long long)k0 | ((unsigned long long)k1 << 32);
+      if (!cand_lds_insert(L, key, block_hash(bx, by, bz, 0xFFFFFFFFu), rank))
+        cand_insert(J.set, k0, k1, bx, by, bz, rank, ctl);
+    }
+    if (act) {
+      prev0 = k0;
+      prev1 = k1;
+    }
+    p.x += st.x;
+    p.y += st.y;
+    p.z += st.z;
+  }
+}
+
+__device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl) {
+  __shared__ CandLds L;
+  for (uint32_t i = threadIdx.x; i < kCandLdsSlots; i += blockDim.x) {
+    L.keys[i] = kCandEmpty;
+    L.ranks[i] = kInf;
+  }
+  __syncthreads();
+  // whole waves are either in or out (pixels_per_wg is a multiple of 64)
+  if ((threadIdx.x & ~63u) < J.pixels_per_wg) cand_pixel_work(J, L, wg, ctl);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kCandLdsSlots; i += blockDim.x) {
+    const unsigned long long key = L.keys[i];
+    if (key != kCandEmpty) {
+      const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+      cand_insert(J.set, k0, k1, (int16_t)(k0 & 0xFFFFu), (int16_t)(k0 >> 16), (int16_t)(k1 & 0xFFFFu),
+                  L.ranks[i], ctl);
+    }
+  }
+}
+
+// is_block_visible<true> (voxel_tsdf.cu:75-96) for the lanes of a wave that hold an absent
+// candidate, spread over the lanes: 8 candidates x 8 corners per step.  Every lane of the wave must
+// call it; returns the answer for the calling lane's own candidate.
+__device__ inline bool wave_block_visible_full(bool want, int bx, int by, int bz,
+                                               const FrameParams& P) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(want);
+  unsigned long long ok = 0;
+  while (todo) {  // uniform
+    unsigned long long packed = 0;  // up to 8 owner lanes, one byte each, 0xFF = none
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      unsigned long long o = 0xFFull;
+      if (todo) {
+        o = (unsigned long long)(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+      }
+      packed |= o << (8 * k);
+    }
+    const uint32_t own = (uint32_t)(packed >> (8 * (lane >> 3))) & 0xFFu;
+    const int src = own == 0xFFu ? 0 : (int)own;
+    const int cbx = __shfl(bx, src), cby = __shfl(by, src), cbz = __shfl(bz, src);
+    const int c = lane & 7;
+    const int cx = (int16_t)((int16_t)(cbx << 3) + ((c >> 0) & 1) * 7);
+    const int cy = (int16_t)((int16_t)(cby << 3) + ((c >> 1) & 1) * 7);
+    const int cz = (int16_t)((int16_t)(cbz << 3) + ((c >> 2) & 1) * 7);
+    const bool v = own == 0xFFu || voxel_visible(cx, cy, cz, P);
+    const unsigned long long b = __ballot(v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long o = (packed >> (8 * k)) & 0xFFull;
+      if (o != 0xFFull && ((b >> (8 * k)) & 0xFFull) == 0xFFull) ok |= 1ull << o;
+    }
+  }
+  return want && ((ok >> lane) & 1ull);
+}
+
+// The directory-dependent half (voxel_tsdf.cu:165-166 + VoxelHashTable::Allocate): workgroup `seg`
+// takes slot list `seg` of the frame's candidate set; one lane per candidate looks the block up,
+// absent blocks take the full-frustum test and file their allocation request with the rank the set
+// recorded.  Every slot read is emptied again.
+__device__ inline void cand_consume_role(const Table& tab, const FrameParams& P, const CandSet& cs,
+                                         uint32_t seg, Request* req, uint32_t req_cap,
+                                         SlowRequest* slow, uint32_t slow_cap, Ctl* ctl) {
+  const uint4* list = cs.list + (size_t)seg * cs.seg_cap;
+  // the count and the first batch of items are fetched together (list memory is always readable)
+  uint4 item = list[threadIdx.x < cs.seg_cap ? threadIdx.x : 0];
+  uint32_t n = cs.count[seg * kCandCountStride];
+  if (n > cs.seg_cap) n = cs.seg_cap;
+  __syncthreads();
+  if (threadIdx.x == 0) cs.count[seg * kCandCountStride] = 0;
+  for (uint32_t base = 0; base < n; base += blockDim.x) {  // uniform
+    const uint32_t i = base + threadIdx.x;
+    const bool have = i < n;
+    if (base && have) item = list[i];
+    int bx = 0, by = 0, bz = 0;
+    uint32_t rank = kInf;
+    EntryWords ea{0, 0, -1}, eb{0, 0, -1};
+    bool absent = false;
+    if (have) {
+      const uint32_t k0 = item.x, k1 = item.y, s = item.z;
+      bx = (int16_t)(k0 & 0xFFFFu);
+      by = (int16_t)(k0 >> 16);
+      bz = (int16_t)(k1 & 0xFFFFu);
+      const uint32_t e0 = block_hash(bx, by, bz, tab.bucket_mask) << 1;
+      rank = cs.ranks[s];
+      ea = load_entry(tab.entries, e0);
+      eb = load_entry(tab.entries, e0 + 1);
+      cs.keys[s] = kCandEmpty;
+      cs.ranks[s] = kInf;
+      absent = !block_present_pre(tab, k0, k1, e0, ea, eb);
+    }
+    if (wave_block_visible_full(absent, bx, by, bz, P)) {
+      alloc_request_absent(tab, bx, by, bz, rank, ea, eb, req, req_cap, slow, slow_cap, ctl);
+    }
+  }
+}
+
+// stand-alone candidate pass (single frames, first frame of a batch)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cand(CandJob job,
+                                                                                   Ctl* ctl) {
+  cand_pixels_role(job, blockIdx.x, ctl);
+}
+
+__global__ void k_init_cand(unsigned long long* keys, uint32_t* ranks, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    keys[i] = kCandEmpty;
+    ranks[i] = kInf;
+  }
+}
+
+}  // namespace ratsdf

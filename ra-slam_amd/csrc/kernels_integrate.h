@@ -549,7 +549,11 @@ __global__ __launch_bounds__(1024) void k_carve(Table tab, Pool pool, const VisI
                                                 uint32_t* bitmap, uint32_t* summary,
                                                 uint32_t* prefix, SlowDelete* slow,
                                                 uint32_t slow_cap, Ctl* ctl,
-                                                ratsdf_frame_stats* stats) {
+                                                ratsdf_frame_stats* stats, CandJob next) {
+  if (blockIdx.x != 0) {  // extra workgroups: a share of the NEXT frame's candidate pass
+    cand_pixels_role(next, blockIdx.x - 1, ctl);
+    return;
+  }
   __shared__ uint32_t lds[32];
   __shared__ uint32_t n_list;                 // deletes recorded in the LDS list (may exceed cap)
   __shared__ uint32_t del_entry[kSmallCarve];

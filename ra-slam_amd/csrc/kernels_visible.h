@@ -141,19 +141,16 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
 }
 
 // k_front: the two directory-read-only jobs of a frame in one launch.
-//   workgroups [0, n_vis_wg)          visible list of the blocks that exist before this frame
-//                                     (longest dependency chain, so it is dispatched first)
-//   workgroups [n_vis_wg, gridDim.x)  allocation candidates + packed texels (alloc_pixels_role)
+//   workgroups [0, n_vis_wg)              visible list of the blocks that exist before this frame
+//                                         (longest dependency chain, so it is dispatched first)
+//   workgroups [n_vis_wg, +kCandSegs)     allocation requests from the frame's candidate set
+//                                         (cand_consume_role, kernels_cand.h)
 // Blocks inserted by this frame join the list in k_integrate (they are visible by construction).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(Table tab, FrameParams P, uint32_t n_vis_wg,
-                                               const float* depth, const uint8_t* rgb,
-                                               const float* ht, const float* lt, float4* texA,
-                                               uint2* texB, Request* req, uint32_t req_cap,
-                                               SlowRequest* slow, uint32_t slow_cap, VisItem* vis,
-                                               uint32_t seg_cap, Ctl* ctl) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(
+    Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, Request* req, uint32_t req_cap,
+    SlowRequest* slow, uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Ctl* ctl) {
   if (blockIdx.x >= n_vis_wg) {
-    alloc_pixels_role(tab, P, blockIdx.x - n_vis_wg, depth, rgb, ht, lt, texA, texB, req, req_cap,
-                      slow, slow_cap, ctl);
+    cand_consume_role(tab, P, cand, blockIdx.x - n_vis_wg, req, req_cap, slow, slow_cap, ctl);
   } else if (P.debug != 3) {
     visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl);
   }

@@ -66,8 +66,14 @@ struct ratsdf_engine {
 
   // image-sized scratch
   size_t pix_cap = 0, rank_cap = 0, cur_nranks = 0;
-  float4* texA = nullptr;
-  uint2* texB = nullptr;
+  float4* texA[2] = {nullptr, nullptr};  // packed per-pixel texels, double-buffered: the candidate
+  uint2* texB[2] = {nullptr, nullptr};   // pass of frame f+1 writes while k_integrate(f) reads
+  CandSet cand[2] = {};                  // candidate sets, used alternately (kernels_cand.h)
+  uint32_t* cand_count = nullptr;        // both sets' list counters
+  unsigned parity = 0;                   // which texel buffer / candidate set the NEXT frame uses
+  bool cand_ready = false;               // that frame's candidate pass has already been enqueued
+  unsigned cand_split = 15;              // percent of the look-ahead pass placed in k_alloc_rank
+  unsigned cand_wgs = 248;               // look-ahead workgroups per host kernel (about one per CU)
   Request* req = nullptr;
   uint32_t req_cap = 0;
   uint32_t* abitmap = nullptr;   // rank bitmap, many-request path only (whole 32-word groups)
@@ -111,11 +117,17 @@ struct ratsdf_engine {
   int free_all();
   int ensure_image(size_t npix, size_t nranks);
   int ensure_stage(size_t npix);
-  int alloc_rank(uint32_t nranks);
-  int carve_tail(bool is_frame);
+  int alloc_rank(uint32_t nranks, const CandJob* next = nullptr);
+  int carve_tail(bool is_frame, const CandJob* next = nullptr);
   int select(int mode, const GridBounds& gb, uint32_t* count_slot);
-  int frame(const void* d_rgb, const void* d_depth, const void* d_ht, const void* d_lt, int H, int W,
-            float md, const ratsdf_intrinsics* K, const ratsdf_pose* T);
+  struct FrameIn {
+    const void *rgb, *depth, *ht, *lt;
+    const ratsdf_intrinsics* K;
+    const ratsdf_pose* T;
+  };
+  FrameParams frame_params(const FrameIn& in, int H, int W, float md) const;
+  CandJob cand_job(const FrameIn& in, const FrameParams& P, unsigned par) const;
+  int frame(const FrameIn& cur, const FrameIn* next, int H, int W, float md);
   int sticky();
   int drain_profile();
   FrameParams base_params() const;
@@ -144,7 +156,9 @@ FrameParams ratsdf_engine::base_params() const {
 int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
   void* ptrs[] = {tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
-                  d_stats, texA, texB, req, req_k, abitmap, asummary, aprefix,
+                  d_stats, texA[0], texA[1], texB[0], texB[1], cand[0].keys, cand[1].keys,
+                  cand[0].ranks, cand[1].ranks, cand[0].list, cand[1].list, cand_count,
+                  req, req_k, abitmap, asummary, aprefix,
                   slow, xlocks,
                   distinct, masks, wg_count, vis, carve_flag, dbitmap, dsummary, dprefix,
                   slowdel, d_stage, d_mc};
@@ -163,10 +177,14 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
   if (npix <= pix_cap && nranks == cur_nranks) return RATSDF_OK;
   HIPCHK(hipStreamSynchronize(stream));
   if (npix > pix_cap) {
-    if (texA) (void)hipFree(texA);
-    if (texB) (void)hipFree(texB);
-    HIPCHK(hipMalloc(&texA, npix * sizeof(float4)));
-    HIPCHK(hipMalloc(&texB, npix * sizeof(uint2)));
+    for (int i = 0; i < 2; ++i) {
+      if (texA[i]) (void)hipFree(texA[i]);
+      if (texB[i]) (void)hipFree(texB[i]);
+      texA[i] = nullptr;
+      texB[i] = nullptr;
+      HIPCHK(hipMalloc(&texA[i], npix * sizeof(float4)));
+      HIPCHK(hipMalloc(&texB[i], npix * sizeof(uint2)));
+    }
     pix_cap = npix;
   }
   if (nranks > rank_cap) {
@@ -211,19 +229,27 @@ int ratsdf_engine::ensure_stage(size_t npix) {
 
 // rank kernel (resolve + mark + scan) on a rank space of `nranks`; the commit itself happens inside
 // k_integrate for frames and in k_commit_only for the stand-alone test hook
-int ratsdf_engine::alloc_rank(uint32_t nranks) {
+int ratsdf_engine::alloc_rank(uint32_t nranks, const CandJob* next) {
   const uint32_t nwords = (nranks + 31) / 32;
-  hipLaunchKernelGGL(k_alloc_rank, dim3(1), dim3(1024), kSlowSortCap * sizeof(unsigned long long),
-                     stream, tab, req, req_cap, req_k, slow, kSlowCap, xlocks, distinct, abitmap,
-                     asummary, aprefix, nwords, ctl);
+  CandJob none;
+  memset(&none, 0, sizeof(none));
+  const CandJob& job = next ? *next : none;
+  const unsigned extra = job.n_pixels ? (job.n_pixels + job.pixels_per_wg - 1) / job.pixels_per_wg : 0;
+  hipLaunchKernelGGL(k_alloc_rank, dim3(1 + extra), dim3(1024),
+                     kSlowSortCap * sizeof(unsigned long long), stream, tab, req, req_cap, req_k, slow,
+                     kSlowCap, xlocks, distinct, abitmap, asummary, aprefix, nwords, ctl, job);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
 
-int ratsdf_engine::carve_tail(bool is_frame) {
-  hipLaunchKernelGGL(k_carve, dim3(1), dim3(1024), 0, stream, tab, pool, vis, seg_cap, carve_flag,
-                     dbitmap, dsummary, dprefix, slowdel, kSlowDelCap, ctl,
-                     is_frame ? d_stats : (ratsdf_frame_stats*)nullptr);
+int ratsdf_engine::carve_tail(bool is_frame, const CandJob* next) {
+  CandJob none;
+  memset(&none, 0, sizeof(none));
+  const CandJob& job = next ? *next : none;
+  const unsigned extra = job.n_pixels ? (job.n_pixels + job.pixels_per_wg - 1) / job.pixels_per_wg : 0;
+  hipLaunchKernelGGL(k_carve, dim3(1 + extra), dim3(1024), 0, stream, tab, pool, vis, seg_cap,
+                     carve_flag, dbitmap, dsummary, dprefix, slowdel, kSlowDelCap, ctl,
+                     is_frame ? d_stats : (ratsdf_frame_stats*)nullptr, job);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
@@ -243,13 +269,10 @@ int ratsdf_engine::select(int mode, const GridBounds& gb, uint32_t* count_slot) 
   return RATSDF_OK;
 }
 
-int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_ht, const void* d_lt,
-                         int H, int W, float md, const ratsdf_intrinsics* K, const ratsdf_pose* T) {
-  const size_t npix = (size_t)H * W;
-  if (npix * (size_t)S >= 0xFFFFFFFFull) return RATSDF_ERR_BAD_ARGUMENT;
-  int st = ensure_image(npix, npix * (size_t)S);
-  if (st != RATSDF_OK) return st;
+FrameParams ratsdf_engine::frame_params(const FrameIn& in, int H, int W, float md) const {
   FrameParams P = base_params();
+  const ratsdf_pose* T = in.T;
+  const ratsdf_intrinsics* K = in.K;
   P.T = Se3{Quat{T->qx, T->qy, T->qz, T->qw}, V3{T->tx, T->ty, T->tz}};
   P.Ti = se3_inverse(P.T);                       // voxel_tsdf.cu:459
   P.K = Intr{K->fx, K->fy, K->cx, K->cy};
@@ -258,14 +281,67 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
   P.W = W;
   P.H = H;
   P.S = S;
-  P.has_sem = (d_ht && d_lt) ? 1 : 0;
+  P.has_sem = (in.ht && in.lt) ? 1 : 0;
+  return P;
+}
+
+CandJob ratsdf_engine::cand_job(const FrameIn& in, const FrameParams& P, unsigned par) const {
+  CandJob j;
+  memset(&j, 0, sizeof(j));
+  j.P = P;
+  j.depth = (const float*)in.depth;
+  j.rgb = (const uint8_t*)in.rgb;
+  j.ht = (const float*)in.ht;
+  j.lt = (const float*)in.lt;
+  j.texA = texA[par];
+  j.texB = texB[par];
+  j.set = cand[par];
+  j.first_pixel = 0;
+  j.n_pixels = (uint32_t)((size_t)P.W * P.H);
+  j.pixels_per_wg = 256;
+  return j;
+}
+
+// One frame.  `next` (same image size) is the frame the caller will integrate right after this one,
+// if it already knows it: its candidate pass then rides in this frame's single-workgroup kernels.
+int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, float md) {
+  const size_t npix = (size_t)H * W;
+  if (npix * (size_t)S >= 0xFFFFFFFFull) return RATSDF_ERR_BAD_ARGUMENT;
+  int st = ensure_image(npix, npix * (size_t)S);
+  if (st != RATSDF_OK) return st;
+  const FrameParams P = frame_params(cur, H, W, md);
+  const unsigned par = parity;
+
+  if (!cand_ready) {  // nobody looked ahead: this frame's candidate pass runs in line
+    const CandJob job = cand_job(cur, P, par);
+    hipLaunchKernelGGL(k_cand, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, job, ctl);
+  }
+  CandJob ahead_a, ahead_b;
+  if (next) {
+    const FrameParams Pn = frame_params(*next, H, W, md);
+    ahead_a = cand_job(*next, Pn, par ^ 1u);
+    ahead_b = ahead_a;
+    // split in whole 64-pixel wave spans; each share is spread over ~one workgroup per CU (the
+    // single-workgroup kernels run 1024 threads, of which a look-ahead workgroup uses as many as it
+    // needs to cover its pixels)
+    const uint32_t spans = (uint32_t)((npix + 63) / 64);
+    const uint32_t spans_a = (uint32_t)((uint64_t)spans * cand_split / 100);
+    ahead_a.n_pixels = (uint32_t)std::min<size_t>((size_t)spans_a * 64, npix);
+    ahead_b.first_pixel = ahead_a.n_pixels;
+    ahead_b.n_pixels = (uint32_t)npix - ahead_a.n_pixels;
+    for (CandJob* j : {&ahead_a, &ahead_b}) {
+      uint32_t ppw = (j->n_pixels + cand_wgs - 1) / cand_wgs;
+      ppw = (ppw + 63) / 64 * 64;
+      j->pixels_per_wg = std::min<uint32_t>(std::max<uint32_t>(ppw, 64u), 1024u);
+    }
+  }
+  parity = par ^ 1u;
+  cand_ready = next != nullptr;
 
   // the control block was zeroed by the previous pass's last kernel (k_carve) or at creation
-  const unsigned n_pix_wg = (unsigned)((npix + 255) / 256);
-  hipLaunchKernelGGL(k_front, dim3(nwg + n_pix_wg), dim3(256), 0, stream, tab, P, nwg,
-                     (const float*)d_depth, (const uint8_t*)d_rgb, (const float*)d_ht,
-                     (const float*)d_lt, texA, texB, req, req_cap, slow, kSlowCap, vis, seg_cap, ctl);
-  st = alloc_rank((uint32_t)(npix * (size_t)S));
+  hipLaunchKernelGGL(k_front, dim3(nwg + kCandSegs), dim3(256), 0, stream, tab, P, nwg, cand[par], req,
+                     req_cap, slow, kSlowCap, vis, seg_cap, ctl);
+  st = alloc_rank((uint32_t)(npix * (size_t)S), next ? &ahead_a : nullptr);
   if (st != RATSDF_OK) return st;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -285,27 +361,27 @@ int ratsdf_engine::frame(const void* d_rgb, const void* d_depth, const void* d_h
   if (pipe_grid) {
     if (vpl == 4)
       hipLaunchKernelGGL(k_integrate_pipe<4>, dim3(pipe_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
     else
       hipLaunchKernelGGL(k_integrate_pipe<2>, dim3(pipe_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
   } else
   switch (vpl) {
     case 8:
       hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
       break;
     case 4:
       hipLaunchKernelGGL(k_integrate<4>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
       break;
     default:
       hipLaunchKernelGGL(k_integrate<2>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA, texB, carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
   }
   if (timed) HIPCHK(hipEventRecord(ev1, stream));
 
-  st = carve_tail(true);
+  st = carve_tail(true, next ? &ahead_b : nullptr);
   if (st != RATSDF_OK) return st;
   if (profiling && prof_used >= 4096) return drain_profile();
   return RATSDF_OK;
@@ -366,6 +442,14 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     const int x = atoi(v);
     if (x >= 8 && x <= 8192 && x % 8 == 0) e->pipe_grid = (unsigned)x;
   }
+  if (const char* v = getenv("RATSDF_CAND_SPLIT")) {
+    const int x = atoi(v);
+    if (x >= 0 && x <= 100) e->cand_split = (unsigned)x;
+  }
+  if (const char* v = getenv("RATSDF_CAND_WGS")) {
+    const int x = atoi(v);
+    if (x >= 1 && x <= 4096) e->cand_wgs = (unsigned)x;
+  }
   if (const char* v = getenv("RATSDF_GRID")) {
     const int x = atoi(v);
     if (x >= 64 && x <= 65536) e->integrate_grid = (unsigned)x;
@@ -416,6 +500,23 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->dsummary, (size_t)dsum_words * 4));
   CREATE_CHK(hipMalloc(&e->dprefix, (size_t)e->dwords * 4));
   CREATE_CHK(hipMalloc(&e->slowdel, (size_t)kSlowDelCap * sizeof(SlowDelete)));
+  // candidate sets: twice as many slots as the pool has blocks (more distinct requests than that
+  // cannot be served anyway), at least 2^16
+  uint32_t cand_slots = 1u << 16;
+  while (cand_slots < 2u * (uint32_t)t.num_block) cand_slots <<= 1;
+  CREATE_CHK(hipMalloc(&e->cand_count, 2 * kCandSegs * kCandCountStride * 4));
+  CREATE_CHK(hipMemsetAsync(e->cand_count, 0, 2 * kCandSegs * kCandCountStride * 4, e->stream));
+  for (int i = 0; i < 2; ++i) {
+    CandSet& c = e->cand[i];
+    c.slot_mask = cand_slots - 1;
+    c.seg_cap = cand_slots / kCandSegs;
+    c.count = e->cand_count + i * kCandSegs * kCandCountStride;
+    CREATE_CHK(hipMalloc(&c.keys, (size_t)cand_slots * 8));
+    CREATE_CHK(hipMalloc(&c.ranks, (size_t)cand_slots * 4));
+    CREATE_CHK(hipMalloc(&c.list, (size_t)cand_slots * sizeof(uint4)));
+    hipLaunchKernelGGL(k_init_cand, dim3((cand_slots + 255) / 256), dim3(256), 0, e->stream, c.keys,
+                       c.ranks, cand_slots);
+  }
   // voxel memory starts zeroed (defined value for the reference's uninitialised rgb)
   CREATE_CHK(hipMemsetAsync(e->pool.rgbw, 0, nvox * 4, e->stream));
   CREATE_CHK(hipMemsetAsync(e->pool.tsdf, 0, nvox * 4, e->stream));
@@ -463,7 +564,8 @@ int ratsdf_integrate_device(ratsdf_engine* e, const void* d_rgb, const void* d_d
   if (!e || !d_rgb || !d_depth || !K || !T || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   if (!d_ht || !d_lt) d_ht = d_lt = nullptr;
-  return e->frame(d_rgb, d_depth, d_ht, d_lt, height, width, max_depth, K, T);
+  const ratsdf_engine::FrameIn in{d_rgb, d_depth, d_ht, d_lt, K, T};
+  return e->frame(in, nullptr, height, width, max_depth);
 }
 
 int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_rgb,
@@ -472,12 +574,19 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
                                   const ratsdf_intrinsics* K, const ratsdf_pose* T) {
   if (!e || n < 0 || (n > 0 && (!d_rgb || !d_depth || !K || !T)) || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n; ++i)
+    if (!d_rgb[i] || !d_depth[i]) return RATSDF_ERR_BAD_ARGUMENT;
+  auto input = [&](int i) {
     const void* ht = (d_ht && d_lt) ? d_ht[i] : nullptr;
     const void* lt = (d_ht && d_lt) ? d_lt[i] : nullptr;
-    if (!d_rgb[i] || !d_depth[i]) return RATSDF_ERR_BAD_ARGUMENT;
     if (!ht || !lt) ht = lt = nullptr;
-    const int st = e->frame(d_rgb[i], d_depth[i], ht, lt, height, width, max_depth, &K[i], &T[i]);
+    return ratsdf_engine::FrameIn{d_rgb[i], d_depth[i], ht, lt, &K[i], &T[i]};
+  };
+  for (int i = 0; i < n; ++i) {
+    const ratsdf_engine::FrameIn cur = input(i);
+    ratsdf_engine::FrameIn nxt{};
+    if (i + 1 < n) nxt = input(i + 1);
+    const int st = e->frame(cur, i + 1 < n ? &nxt : nullptr, height, width, max_depth);
     if (st != RATSDF_OK) return st;
   }
   return RATSDF_OK;
@@ -502,8 +611,9 @@ int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, c
   memcpy(h + npix * 12, rgb, npix * 3);
   HIPCHK(hipMemcpyAsync(e->d_stage, h, npix * 16, hipMemcpyHostToDevice, e->stream));
   uint8_t* d = e->d_stage;
-  st = e->frame(d + npix * 12, d, ht ? d + npix * 4 : nullptr, ht ? d + npix * 8 : nullptr, height,
-                width, max_depth, K, T);
+  const ratsdf_engine::FrameIn in{d + npix * 12, d, ht ? d + npix * 4 : nullptr,
+                                  ht ? d + npix * 8 : nullptr, K, T};
+  st = e->frame(in, nullptr, height, width, max_depth);
   if (st != RATSDF_OK) return st;
   return e->sticky();  // cudaStreamSynchronize(stream_), voxel_tsdf.cu:450
 }

@@ -7,7 +7,7 @@ import json,sys
 kv,out=sys.argv[1],sys.argv[2]
 try:
     j=json.loads(out); r=j.get("roofline") or {}
-    print(f"{kv:40s} fps={j['value']:9.1f} ms/step={j['ms_per_step']:8.3f} k_integrate_us={r.get('avg_launch_us')} frac={r.get('frac')}")
+    print(f"{kv:40s} fps={j['value']:9.1f} ms/step={j['ms_per_step']:8.3f} k_integrate_us={r.get('avg_launch_us')} frac={r.get('frac')} host_enq={j.get('host_enqueue_frac')}")
 except Exception as e:
     print(kv, "FAILED", out[-200:])
 PY
