@@ -52,30 +52,45 @@ struct SlowDelete {
   int32_t freed;   // pool index released
 };
 
-// Device-resident control block.  Words [0, kCtlFrameWords) are zeroed at the start of every frame.
+// one successful or pending simple delete of the carve pass: where the block sat, what it held
+struct DelItem {
+  uint32_t entry;
+  int32_t idx;
+};
+
+// Per-frame counters.  Two copies, used alternately: frame f works in fr[f & 1] while the end of
+// frame f-1 (pool releases, statistics; carve_finalize) is still being settled from fr[(f-1) & 1].
+// carve_finalize zeroes the copy it has consumed.
+struct FrameCtl {
+  uint32_t n_req;          // requests appended this pass
+  uint32_t n_slow;         // slow (chained-bucket) requests appended this pass
+  uint32_t n_win;          // winners of the allocation pass
+  uint32_t alloc_base;     // num_free at the start of the allocation pass
+  uint32_t n_delcand;      // slot-0 deletes done by k_integrate (pool release pending)
+  uint32_t n_slow_del;     // head / chain deletes waiting for carve_resolve_slow
+  uint32_t pending;        // this frame's carve pass has not been finalised yet
+  uint32_t slow_resolved;  // carve_resolve_slow has run for this frame
+  uint32_t n_list[8];      // visible blocks per XCD list (image-tile buckets)
+  uint32_t n_winlist;      // > 0: the winners' raster ranks are listed in win_ranks[0, n_winlist) and
+                           // k_integrate derives each winner's order from the list (few winners);
+                           // 0: req_k holds the order (many winners, rank bitmap path)
+  uint32_t pad[15];
+};
+static_assert(sizeof(FrameCtl) == 128, "frame counters are one 128-byte line");
+
+// Device-resident control block.
 struct Ctl {
-  // --- per-frame (zeroed by a memset node) ---
-  uint32_t n_req;         // requests appended this pass
-  uint32_t n_slow;        // slow (chained-bucket) requests appended this pass
-  uint32_t n_win;         // winners of the allocation pass
-  uint32_t n_vis;         // V (total, filled in by k_carve / the test hook)
-  uint32_t n_updated;     // U
-  uint32_t n_slow_del;    // slow deletes appended
-  uint32_t n_del;         // successful deletes
-  uint32_t alloc_base;    // num_free at the start of the allocation pass
-  uint32_t free_base;     // num_free at the start of the carve pass
-  uint32_t n_sel;         // selected blocks of a query / export
-  uint32_t n_list[8];     // visible blocks per XCD list (image-tile buckets)
-  uint32_t pad0[14];
+  FrameCtl fr[2];
   // --- persistent ---
   int32_t num_free;       // VoxelMemPool::num_free_blocks_
   uint32_t error;         // sticky ratsdf_status
+  uint32_t n_sel;         // selected blocks of a query / export
+  uint32_t pad0;
   unsigned long long totals[5];  // frames, sum V, sum U, sum allocated, sum deleted
   uint32_t pad1[4];
   unsigned long long stamps[32];  // diagnostic build only
   unsigned long long* debug_buf;  // diagnostic build only: per-wave stamps of k_integrate
 };
-constexpr int kCtlFrameBytes = 128;
 constexpr int kNumLists = 8;  // one block list per XCD; list 8 (the 9th segment) holds this frame's new blocks
 
 // Diagnostic build only (-DRATSDF_STAMPS): thread 0 of the single-workgroup kernels accumulates
@@ -121,7 +136,9 @@ struct FrameParams {
 
 struct Table {
   Entry* entries;
-  uint32_t* claim;
+  uint32_t* claim;          // per-bucket claim of the allocation pass (kInf = free)
+  uint32_t* dclaim;         // per-bucket claim of the carve pass (its own table: k_integrate both
+                            // releases allocation claims and places carve claims)
   unsigned long long* occ;  // occupancy bitmap of the directory: bit e set <=> entries[e].idx >= 0
   uint32_t num_bucket, num_entry, bucket_mask, entry_mask;
   int32_t num_block;

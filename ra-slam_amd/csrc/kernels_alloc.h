@@ -77,7 +77,7 @@ __device__ inline uint32_t find_block(const Table& t, int x, int y, int z, Entry
 // One allocation request with raster rank `rank` for block (x,y,z), against the pre-pass directory.
 __device__ inline void alloc_request(const Table& t, int x, int y, int z, uint32_t rank, Request* req,
                                      uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap,
-                                     Ctl* ctl) {
+                                     Ctl* ctl, FrameCtl* F) {
   const uint32_t k0 = key0(x, y), k1 = key1(z);
   const uint32_t bucket = block_hash(x, y, z, t.bucket_mask);
   const uint32_t e0 = bucket << 1;
@@ -99,15 +99,18 @@ __device__ inline void alloc_request(const Table& t, int x, int y, int z, uint32
   if (!special) {
     const uint32_t old = atomicMin(&t.claim[bucket], rank);
     if (rank < old) {
-      const uint32_t slot = atomicAdd(&ctl->n_req, 1u);
+      // the leader of an ordinary bucket fills its first empty home entry (voxel_hash.cu:67-78);
+      // nothing else can take that slot during the pass, so it is fixed here
+      const uint32_t e = (bucket << 1) + (a.idx < 0 ? 0u : 1u);
+      const uint32_t slot = atomicAdd(&F->n_req, 1u);
       if (slot < req_cap) {
-        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, 0};
+        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, e};
       } else {
         set_error(ctl, RATSDF_ERR_CAPACITY);
       }
     }
   } else {
-    const uint32_t slot = atomicAdd(&ctl->n_slow, 1u);
+    const uint32_t slot = atomicAdd(&F->n_slow, 1u);
     if (slot < slow_cap) {
       slow[slot] = SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank};
     } else {
@@ -136,21 +139,24 @@ __device__ inline bool block_present_pre(const Table& t, uint32_t k0, uint32_t k
 __device__ inline void alloc_request_absent(const Table& t, int x, int y, int z, uint32_t rank,
                                             const EntryWords& a, const EntryWords& b, Request* req,
                                             uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap,
-                                            Ctl* ctl) {
+                                            Ctl* ctl, FrameCtl* F) {
   const uint32_t bucket = block_hash(x, y, z, t.bucket_mask);
   const bool special = (a.idx >= 0 && b.idx >= 0) || entry_offset(b) != 0;
   if (!special) {
     const uint32_t old = atomicMin(&t.claim[bucket], rank);
     if (rank < old) {
-      const uint32_t slot = atomicAdd(&ctl->n_req, 1u);
+      // the leader of an ordinary bucket fills its first empty home entry (voxel_hash.cu:67-78);
+      // nothing else can take that slot during the pass, so it is fixed here
+      const uint32_t e = (bucket << 1) + (a.idx < 0 ? 0u : 1u);
+      const uint32_t slot = atomicAdd(&F->n_req, 1u);
       if (slot < req_cap) {
-        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, 0};
+        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, e};
       } else {
         set_error(ctl, RATSDF_ERR_CAPACITY);
       }
     }
   } else {
-    const uint32_t slot = atomicAdd(&ctl->n_slow, 1u);
+    const uint32_t slot = atomicAdd(&F->n_slow, 1u);
     if (slot < slow_cap) {
       slow[slot] = SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank};
     } else {
@@ -159,19 +165,58 @@ __device__ inline void alloc_request_absent(const Table& t, int x, int y, int z,
   }
 }
 
-}  // namespace ratsdf
-#include "kernels_cand.h"  // the per-pixel candidate pass and its consumer (uses the helpers above)
-namespace ratsdf {
+// alloc_request_absent for a whole wave (every lane calls it; `want` selects the lanes that have an
+// absent, visible block).  Same effect, but the lanes of a wave share ONE returning atomic on the
+// request counter: a per-lane atomicAdd on that single address (~90 ops/us) was the longest step of
+// k_front once workgroup-level duplicates raised the number of requests.
+__device__ inline void alloc_request_absent_wave(bool want, const Table& t, int x, int y, int z,
+                                                 uint32_t rank, const EntryWords& a,
+                                                 const EntryWords& b, Request* req, uint32_t req_cap,
+                                                 SlowRequest* slow, uint32_t slow_cap, Ctl* ctl,
+                                                 FrameCtl* F) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t bucket = block_hash(x, y, z, t.bucket_mask);
+  const bool special = (a.idx >= 0 && b.idx >= 0) || entry_offset(b) != 0;
+  bool app = false;
+  if (want && !special) app = rank < atomicMin(&t.claim[bucket], rank);
+  const unsigned long long m = __ballot(app);
+  if (m) {  // uniform
+    uint32_t base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if ((int)lane == leader) base = atomicAdd(&F->n_req, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (app) {
+      const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      // the leader of an ordinary bucket fills its first empty home entry (voxel_hash.cu:67-78);
+      // nothing else can take that slot during the pass, so it is fixed here
+      const uint32_t e = (bucket << 1) + (a.idx < 0 ? 0u : 1u);
+      if (slot < req_cap) {
+        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, e};
+      } else {
+        set_error(ctl, RATSDF_ERR_CAPACITY);
+      }
+    }
+  }
+  if (want && special) {
+    const uint32_t slot = atomicAdd(&F->n_slow, 1u);
+    if (slot < slow_cap) {
+      slow[slot] = SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank};
+    } else {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // test hook: explicit request list, rank = list index (utils/tests/voxel_hash_test.cu:36-39)
 __global__ void k_alloc_list(Table tab, FrameParams P, const int16_t* pos, int n, Request* req,
-                             uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap, Ctl* ctl) {
+                             uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap, Ctl* ctl,
+                             uint32_t par) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
   if (!shard_owned(x, P)) return;
-  alloc_request(tab, x, y, z, (uint32_t)i, req, req_cap, slow, slow_cap, ctl);
+  alloc_request(tab, x, y, z, (uint32_t)i, req, req_cap, slow, slow_cap, ctl, &ctl->fr[par]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -192,8 +237,8 @@ struct XLock {
 __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uint32_t req_cap,
                                              const SlowRequest* slow, uint32_t slow_cap,
                                              XLock* xlocks, SlowRequest* distinct, Ctl* ctl,
-                                             unsigned long long* skeys) {
-  uint32_t n = ctl->n_slow;
+                                             FrameCtl* F, unsigned long long* skeys) {
+  uint32_t n = F->n_slow;
   if (n > slow_cap) n = slow_cap;
   if (n > (uint32_t)kSlowSortCap) {
     if (threadIdx.x == 0) set_error(ctl, RATSDF_ERR_CAPACITY);
@@ -244,7 +289,7 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
     p[0] = key0(s.x, s.y);
     p[1] = key1(s.z);  // offset 0
     p[2] = (uint32_t)kPlaceholderIdx;
-    const uint32_t slot = atomicAdd(&ctl->n_req, 1u);
+    const uint32_t slot = atomicAdd(&F->n_req, 1u);
     if (slot < req_cap) {
       req[slot] = Request{s.x, s.y, s.z, (uint16_t)(kReqWinner | kReqPlaced), s.rank, e};
     } else {
@@ -430,35 +475,59 @@ __device__ inline uint32_t bitmap_rank(const uint32_t* bitmap, const uint32_t* p
 //     winner counts the smaller ones -- no global atomics, no bitmap
 //   * many requests (first frames of a scene): rank-indexed bitmap + popcount prefix (self-cleaning)
 // ---------------------------------------------------------------------------------------------
+// Rank of every key of an LDS list among the list's (distinct) keys = number of smaller keys,
+// handed to emit(position, rank).  Four lanes share a key and each scans a quarter of the list with
+// 16-byte LDS reads (a scalar loop over a few hundred keys per thread is a chain of LDS latencies and
+// was most of the serial kernels' time).  keys[] must have room for 16 entries of padding.
+// All threads of the workgroup; two barriers.
+template <typename Emit>
+__device__ inline void lds_rank_all(uint32_t* keys, uint32_t n, Emit emit) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t n16 = (n + 15u) & ~15u;
+  __syncthreads();
+  if (tid < n16 - n) keys[n + tid] = kInf;
+  __syncthreads();
+  const uint4* v = reinterpret_cast<const uint4*>(keys);
+  const uint32_t nchunks = n16 >> 2, sub = tid & 3u;
+  for (uint32_t base = 0; base < n; base += nt >> 2) {  // uniform
+    const uint32_t item = base + (tid >> 2);
+    const uint32_t mine = item < n ? keys[item] : 0u;
+    uint32_t k = 0;
+#pragma unroll 4
+    for (uint32_t c = sub; c < nchunks; c += 4) {
+      const uint4 x = v[c];
+      k += (x.x < mine) + (x.y < mine) + (x.z < mine) + (x.w < mine);
+    }
+    k += __shfl_xor(k, 1);
+    k += __shfl_xor(k, 2);
+    if (sub == 0 && item < n) emit(item, k);
+  }
+}
+
 constexpr uint32_t kSmallRank = 4096;  // LDS list capacity (16 KiB of the resolver's sort buffer)
 
-__global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, uint32_t req_cap,
-                                                     uint32_t* req_k, const SlowRequest* slow,
-                                                     uint32_t slow_cap, XLock* xlocks,
-                                                     SlowRequest* distinct, uint32_t* bitmap,
-                                                     uint32_t* summary, uint32_t* prefix,
-                                                     uint32_t nwords, Ctl* ctl, CandJob next) {
-  if (blockIdx.x != 0) {  // extra workgroups: a share of the NEXT frame's candidate pass
-    cand_pixels_role(next, blockIdx.x - 1, ctl);
-    return;
-  }
-  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+// All threads of one workgroup; `skeys` = the workgroup's dynamic LDS (kSlowSortCap keys), `nf` = the
+// pool's free count at the start of this pass.
+__device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t req_cap,
+                                       uint32_t* req_k, const SlowRequest* slow, uint32_t slow_cap,
+                                       XLock* xlocks, SlowRequest* distinct, uint32_t* bitmap,
+                                       uint32_t* summary, uint32_t* prefix, uint32_t nwords, Ctl* ctl,
+                                       FrameCtl* F, int32_t nf, unsigned long long* skeys) {
   uint32_t* lds = reinterpret_cast<uint32_t*>(skeys);  // [0,32): scan scratch, [32]: counter
   uint32_t* lds_rank = lds + 64;                       // kSmallRank words
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   RATSDF_STAMP(ctl->stamps, 8);
-  const uint32_t n_slow = ctl->n_slow;
-  const int32_t nf = ctl->num_free;
+  const uint32_t n_slow = F->n_slow;
   if (n_slow != 0) {  // uniform
-    resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, distinct, ctl, skeys);
+    resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, distinct, ctl, F, skeys);
     __syncthreads();
   }
-  uint32_t n = n_slow ? ld_agent_u32(&ctl->n_req) : ctl->n_req;  // the resolver appends requests
+  uint32_t n = n_slow ? ld_agent_u32(&F->n_req) : F->n_req;  // the resolver appends requests
   if (n > req_cap) n = req_cap;
   RATSDF_STAMP(ctl->stamps, 12);
   uint32_t total = 0;
   if (n <= kSmallRank) {
-    uint32_t* lds_req = lds_rank + kSmallRank;  // request index of each listed winner
+    uint32_t* lds_req = lds_rank + kSmallRank + 16;  // request index of each listed winner
     if (tid == 0) lds[32] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += nt) {
@@ -478,13 +547,8 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, ui
     __syncthreads();
     RATSDF_STAMP(ctl->stamps, 9);
     total = lds[32];
-    for (uint32_t w = tid; w < total; w += nt) {  // winner w: count the winners with smaller rank
-      const uint32_t mine = lds_rank[w];
-      uint32_t k = 0;
-#pragma unroll 4
-      for (uint32_t j = 0; j < total; ++j) k += lds_rank[j] < mine;
-      req_k[lds_req[w]] = k;
-    }
+    // winner w: count the winners with smaller rank
+    lds_rank_all(lds_rank, total, [&](uint32_t w, uint32_t k) { req_k[lds_req[w]] = k; });
     RATSDF_STAMP(ctl->stamps, 10);
   } else {
     for (uint32_t i = tid; i < n; i += nt) {
@@ -518,8 +582,9 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Request* req, ui
       set_error(ctl, RATSDF_ERR_POOL_EXHAUSTED);
       take = (uint32_t)nf;
     }
-    ctl->alloc_base = (uint32_t)nf;
-    ctl->n_win = take;
+    F->alloc_base = (uint32_t)nf;
+    F->n_win = take;
+    F->pending = 1;  // the frame (or test pass) now owes a carve_finalize
     ctl->num_free = nf - (int32_t)take;
   }
   RATSDF_STAMP(ctl->stamps, 11);
@@ -539,11 +604,7 @@ __device__ inline bool commit_request(const Table& tab, const Pool& pool, const 
     if (writer && !placed) tab.claim[bucket] = kInf;
     return false;
   }
-  uint32_t e = r.entry;
-  if (writer && !placed) {
-    const uint32_t e0 = bucket << 1;
-    e = (load_entry(tab.entries, e0).idx < 0) ? e0 : e0 + 1;
-  }
+  const uint32_t e = r.entry;  // chosen when the request was filed / placed
   uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + e);
   if (k >= n_win) {  // pool exhausted (voxel_mem.cu:39): this insertion does not happen
     if (writer) {
@@ -571,18 +632,29 @@ __device__ inline bool commit_request(const Table& tab, const Pool& pool, const 
 // initialised to weight 1 / tsdf -1 / probability .5 with rgb left untouched (voxel_mem.cu:43-51).
 __global__ __launch_bounds__(256) void k_commit_only(Table tab, Pool pool, const Request* req,
                                                      uint32_t req_cap, const uint32_t* req_k,
-                                                     Ctl* ctl) {
-  uint32_t n = ctl->n_req;
+                                                     const uint32_t* win_ranks, Ctl* ctl,
+                                                     uint32_t par) {
+  const FrameCtl* F = &ctl->fr[par];
+  uint32_t n = F->n_req;
   if (n > req_cap) n = req_cap;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t base = ctl->alloc_base, n_win = ctl->n_win;
+  const uint32_t base = F->alloc_base, n_win = F->n_win, n_winlist = F->n_winlist;
   for (uint32_t i = wave; i < n; i += nwaves) {
     const Request r = req[i];
     uint32_t e;
     int32_t idx;
-    const uint32_t k = (r.flags & kReqWinner) ? req_k[i] : 0u;
+    uint32_t k = 0;
+    if (r.flags & kReqWinner) {
+      if (n_winlist) {  // few winners: position in raster order = winners with a smaller rank
+        for (uint32_t j = lane; j < n_winlist; j += 64) k += win_ranks[j] < r.rank;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o);
+      } else {
+        k = req_k[i];
+      }
+    }
     if (!commit_request(tab, pool, r, k, base, n_win, lane == 0, &idx, &e)) continue;
     const size_t v = ((size_t)idx << 9) + lane * 8;
     float4* pt = reinterpret_cast<float4*>(pool.tsdf + v);

@@ -10,41 +10,43 @@
 // workgroups inside the two single-workgroup kernels of frame f (k_alloc_rank, k_carve), which leave
 // 255 of the 256 CUs idle.  A single frame (ratsdf_integrate_device) runs it as its own launch.
 //
-// Output of the pass = the frame's candidate set: every distinct requested block with the SMALLEST
-// raster rank (pixel * S + sample) that asked for it.  Only that request matters: under the
-// canonical raster-order execution a later request for the same block finds it either inserted by
-// the first one or blocked by a bucket lock that stays taken until the end of the pass
-// (voxel_hash.cu:46-108), so it can never change the directory.  A 640x480 frame has ~0.9 M samples
-// but only a few thousand distinct blocks; the directory-dependent half (cand_consume_role, in
-// k_front) then does a few thousand lookups instead of ~100 k.
+// Output of the pass = the frame's candidate list: (block, raster rank = pixel * S + sample) pairs,
+// deduplicated per workgroup with the SMALLEST rank kept.  Only the first request for a block
+// matters: under the canonical raster-order execution a later request for the same block finds it
+// either inserted by the first one or blocked by a bucket lock that stays taken until the end of the
+// pass (voxel_hash.cu:46-108), so it can never change the directory.  A 640x480 frame has ~0.9 M
+// samples, ~100 k lane-distinct requests, but only ~15 k workgroup-distinct ones (~5 k distinct
+// blocks); the directory-dependent half (cand_consume_role, in k_front) then does ~15 k lookups.
+// Duplicates between workgroups are harmless: the per-bucket claim (atomicMin of the rank) picks
+// the smallest rank exactly as it did when every lane filed its own request.
 //
-// The set is an open-addressing table keyed by block position {keys: 48-bit position, ranks:
-// atomicMin of the rank}; the lane that inserts a key also appends its slot to one of 64 slot lists
-// (64 counters on separate cache lines: a single-address atomic sustains only ~90 ops/us on this
-// part).  The consumer empties every slot it reads, so the table is clean for the frame after next
-// (two sets, used alternately).  Also written here: the packed per-pixel texels k_integrate gathers
-// from (texA = {depth, range, log ht, log lt}, texB = {rgb, w_new}); log(ht), log(lt) and
-// w_new = (1 - d / max_depth) * 4 are functions of the pixel only (voxel_tsdf.cu:226,243,246).
+// Requests of a workgroup meet in a small LDS hash set {block, min rank}; after a barrier the
+// occupied slots are compacted and appended to one of 64 global lists with ONE returning atomic per
+// workgroup (64 counters on separate cache lines: a single-address atomic sustains only ~90 ops/us
+// on this part).  The consumer resets the counters.  Two lists are used alternately (frame parity).
+// Also written here: the packed per-pixel texels k_integrate gathers from (texA = {depth, range,
+// log ht, log lt}, texB = {rgb, w_new}); log(ht), log(lt) and w_new = (1 - d / max_depth) * 4 are
+// functions of the pixel only (voxel_tsdf.cu:226,243,246).
 #pragma once
-// included from the middle of kernels_alloc.h (needs its request helpers, is needed by k_alloc_rank)
-#include "device_math.h"
+#include "kernels_alloc.h"
 
 namespace ratsdf {
 
-constexpr int kCandSegs = 64;           // slot lists (and consumer workgroups) per candidate set
+constexpr int kCandSegs = 64;           // candidate lists (and consumer workgroups) per frame
 constexpr int kCandCountStride = 32;    // words between list counters (one 128-byte line each)
 constexpr unsigned long long kCandEmpty = ~0ull;
 
 struct CandSet {
-  unsigned long long* keys;  // [slot_mask + 1], kCandEmpty = free
-  uint32_t* ranks;           // [slot_mask + 1], kInf = none
-  uint4* list;               // [kCandSegs][seg_cap] {key lo, key hi, slot, -}, list = slot & 63
+  uint4* list;               // [kCandSegs][seg_cap] {x | y << 16, z, rank, -}
   uint32_t* count;           // [kCandSegs * kCandCountStride]
-  uint32_t slot_mask;
-  uint32_t seg_cap;          // (slot_mask + 1) / kCandSegs: a list can never overflow
+  uint32_t seg_cap;
 };
 
-// one candidate pass (or a share of it): pixels [first_pixel, first_pixel + n_pixels) of the frame
+// One candidate pass (or a share of it).  The image is cut into 16x4-pixel tiles, one per wave; four
+// vertically stacked tiles form a 16x16 super-tile and tiles are numbered super-tile by super-tile,
+// so that the waves of a workgroup cover a compact patch of the image: neighbouring pixels ask for
+// the same blocks, and the per-workgroup deduplication is what keeps the candidate list short
+// (row-segment workgroups produced ~120 k candidates per 640x480 frame, patches ~20 k).
 struct CandJob {
   FrameParams P;
   const float* depth;
@@ -54,47 +56,31 @@ struct CandJob {
   float4* texA;
   uint2* texB;
   CandSet set;
-  uint32_t first_pixel, n_pixels;
-  uint32_t pixels_per_wg;  // <= blockDim.x; the remaining threads of a workgroup only join barriers
+  uint32_t first_tile, n_tiles;  // this share: tiles [first_tile, first_tile + n_tiles)
+  uint32_t tiles_per_wg;         // waves of a workgroup that take a tile; the others only join barriers
+  uint32_t tiles_x;              // super-tiles per image row = ceil(W / 16)
 };
 
-__device__ inline unsigned long long ld_agent_u64(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// record "block (k0,k1) was requested with raster rank `rank`".  One returning atomic (the CAS) on
-// the common path; the rank update is a fire-and-forget atomicMin.
-__device__ inline void cand_insert(const CandSet& cs, uint32_t k0, uint32_t k1, int bx, int by, int bz,
-                                   uint32_t rank, Ctl* ctl) {
-  const unsigned long long key = (unsigned long long)k0 | ((unsigned long long)k1 << 32);
-  uint32_t s = block_hash(bx, by, bz, cs.slot_mask);
-  for (uint32_t guard = 0; guard <= cs.slot_mask; ++guard) {
-    const unsigned long long k = atomicCAS(&cs.keys[s], kCandEmpty, key);
-    if (k == kCandEmpty || k == key) {
-      atomicMin(&cs.ranks[s], rank);
-      if (k == kCandEmpty) {  // this lane inserted the key: publish the slot
-        const uint32_t l = s & (kCandSegs - 1);
-        const uint32_t pos = atomicAdd(&cs.count[l * kCandCountStride], 1u);
-        cs.list[(size_t)l * cs.seg_cap + pos] = make_uint4(k0, k1, s, 0u);
-      }
-      return;
-    }
-    s = (s + 1) & cs.slot_mask;
-  }
-  set_error(ctl, RATSDF_ERR_CAPACITY);
-}
-
-// Workgroup-level pre-aggregation: the pixels of one workgroup ask for the same few dozen blocks over
-// and over (a 640x480 / 5 mm frame: ~100 k lane-distinct requests, ~5 k distinct blocks), and a
-// global insert is two dependent L2 round trips plus atomics.  Requests first meet in a small LDS
-// set of the same shape; after a barrier every occupied LDS slot is flushed by one lane.  A request
-// that finds the LDS set full goes to the global set directly.
+// Workgroup-level aggregation: the pixels of one workgroup ask for the same few dozen blocks over
+// and over.  A request that finds the LDS set full goes to the global list directly.
 constexpr uint32_t kCandLdsSlots = 512;
 
 struct CandLds {
   unsigned long long keys[kCandLdsSlots];
   uint32_t ranks[kCandLdsSlots];
+  uint32_t n, base;
 };
+
+// append one candidate straight to a global list (LDS set overflow only)
+__device__ inline void cand_append(const CandSet& cs, uint32_t seg, uint32_t k0, uint32_t k1,
+                                   uint32_t rank, Ctl* ctl) {
+  const uint32_t pos = atomicAdd(&cs.count[seg * kCandCountStride], 1u);
+  if (pos < cs.seg_cap) {
+    cs.list[(size_t)seg * cs.seg_cap + pos] = make_uint4(k0, k1, rank, 0u);
+  } else {
+    set_error(ctl, RATSDF_ERR_CAPACITY);
+  }
+}
 
 __device__ inline bool cand_lds_insert(CandLds& L, unsigned long long key, uint32_t h, uint32_t rank) {
   uint32_t s = h & (kCandLdsSlots - 1);
@@ -110,16 +96,19 @@ __device__ inline bool cand_lds_insert(CandLds& L, unsigned long long key, uint3
   return false;
 }
 
-// block_allocate_kernel up to (not including) the directory lookup, one lane per pixel, 64
-// consecutive pixels of a row per wave.  `wg` counts workgroups of blockDim.x pixels inside the job.
+// block_allocate_kernel up to (not including) the directory lookup, one lane per pixel, one 16x4
+// tile per wave.  `wg` counts workgroups inside the job.
 __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg, Ctl* ctl) {
   const FrameParams& P = J.P;
-  const uint32_t rel = wg * J.pixels_per_wg + threadIdx.x;
-  const int pix = (int)(J.first_pixel + rel);
+  const uint32_t wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  const bool inb = threadIdx.x < J.pixels_per_wg && rel < J.n_pixels && pix < P.W * P.H;
-  const int px = inb ? pix % P.W : 0;
-  const int py = inb ? pix / P.W : 0;
+  const uint32_t rel = wg * J.tiles_per_wg + wave;       // tile within the share
+  const uint32_t tile = J.first_tile + rel;
+  const uint32_t sup = tile >> 2, sub = tile & 3u;
+  const int px = (int)(sup % J.tiles_x) * 16 + (lane & 15);
+  const int py = (int)(sup / J.tiles_x) * 16 + (int)sub * 4 + (lane >> 4);
+  const bool inb = wave < J.tiles_per_wg && rel < J.n_tiles && px < P.W && py < P.H;
+  const int pix = inb ? py * P.W + px : 0;
   const float d = inb ? J.depth[pix] : 0.f;
 
   const V3 pimg{(float)px, (float)py, 1.f};
@@ -188,7 +177,7 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
       const uint32_t rank = (uint32_t)pix * (uint32_t)P.S + (uint32_t)i;
       const unsigned long long key = (unsigned long long)k0 | ((unsigned long long)k1 << 32);
       if (!cand_lds_insert(L, key, block_hash(bx, by, bz, 0xFFFFFFFFu), rank))
-        cand_insert(J.set, k0, k1, bx, by, bz, rank, ctl);
+        cand_append(J.set, (J.first_tile + wg) & (kCandSegs - 1), k0, k1, rank, ctl);
     }
     if (act) {
       prev0 = k0;
@@ -206,16 +195,37 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl)
     L.keys[i] = kCandEmpty;
     L.ranks[i] = kInf;
   }
+  if (threadIdx.x == 0) L.n = 0;
   __syncthreads();
-  // whole waves are either in or out (pixels_per_wg is a multiple of 64)
-  if ((threadIdx.x & ~63u) < J.pixels_per_wg) cand_pixel_work(J, L, wg, ctl);
+  if ((threadIdx.x >> 6) < J.tiles_per_wg) cand_pixel_work(J, L, wg, ctl);  // whole waves in or out
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < kCandLdsSlots; i += blockDim.x) {
-    const unsigned long long key = L.keys[i];
-    if (key != kCandEmpty) {
-      const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-      cand_insert(J.set, k0, k1, (int16_t)(k0 & 0xFFFFu), (int16_t)(k0 >> 16), (int16_t)(k1 & 0xFFFFu),
-                  L.ranks[i], ctl);
+  // compact the occupied slots and append them to one global list: one returning atomic per workgroup
+  constexpr uint32_t kMaxPerThread = kCandLdsSlots / 64;  // blockDim.x >= 64
+  uint32_t pos[kMaxPerThread];
+#pragma unroll
+  for (uint32_t k = 0; k < kMaxPerThread; ++k) {
+    const uint32_t i = threadIdx.x + k * blockDim.x;
+    pos[k] = kInf;
+    if (i < kCandLdsSlots && L.keys[i] != kCandEmpty) pos[k] = atomicAdd(&L.n, 1u);
+  }
+  __syncthreads();
+  const uint32_t seg = (J.first_tile + wg) & (kCandSegs - 1);
+  const uint32_t n = L.n;
+  if (n == 0) return;  // uniform
+  if (threadIdx.x == 0) L.base = atomicAdd(&J.set.count[seg * kCandCountStride], n);
+  __syncthreads();
+  const uint32_t base = L.base;
+  if (base + n > J.set.seg_cap) {  // uniform
+    if (threadIdx.x == 0) set_error(ctl, RATSDF_ERR_CAPACITY);
+    return;
+  }
+  uint4* out = J.set.list + (size_t)seg * J.set.seg_cap + base;
+#pragma unroll
+  for (uint32_t k = 0; k < kMaxPerThread; ++k) {
+    const uint32_t i = threadIdx.x + k * blockDim.x;
+    if (pos[k] != kInf) {
+      const unsigned long long key = L.keys[i];
+      out[pos[k]] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), L.ranks[i], 0u);
     }
   }
 }
@@ -263,7 +273,8 @@ __device__ inline bool wave_block_visible_full(bool want, int bx, int by, int bz
 // recorded.  Every slot read is emptied again.
 __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P, const CandSet& cs,
                                          uint32_t seg, Request* req, uint32_t req_cap,
-                                         SlowRequest* slow, uint32_t slow_cap, Ctl* ctl) {
+                                         SlowRequest* slow, uint32_t slow_cap, Ctl* ctl,
+                                         FrameCtl* F) {
   const uint4* list = cs.list + (size_t)seg * cs.seg_cap;
   // the count and the first batch of items are fetched together (list memory is always readable)
   uint4 item = list[threadIdx.x < cs.seg_cap ? threadIdx.x : 0];
@@ -276,25 +287,21 @@ __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P,
     const bool have = i < n;
     if (base && have) item = list[i];
     int bx = 0, by = 0, bz = 0;
-    uint32_t rank = kInf;
     EntryWords ea{0, 0, -1}, eb{0, 0, -1};
     bool absent = false;
     if (have) {
-      const uint32_t k0 = item.x, k1 = item.y, s = item.z;
+      const uint32_t k0 = item.x, k1 = item.y;
       bx = (int16_t)(k0 & 0xFFFFu);
       by = (int16_t)(k0 >> 16);
       bz = (int16_t)(k1 & 0xFFFFu);
       const uint32_t e0 = block_hash(bx, by, bz, tab.bucket_mask) << 1;
-      rank = cs.ranks[s];
       ea = load_entry(tab.entries, e0);
       eb = load_entry(tab.entries, e0 + 1);
-      cs.keys[s] = kCandEmpty;
-      cs.ranks[s] = kInf;
       absent = !block_present_pre(tab, k0, k1, e0, ea, eb);
     }
-    if (wave_block_visible_full(absent, bx, by, bz, P)) {
-      alloc_request_absent(tab, bx, by, bz, rank, ea, eb, req, req_cap, slow, slow_cap, ctl);
-    }
+    const bool want = wave_block_visible_full(absent, bx, by, bz, P);
+    alloc_request_absent_wave(want, tab, bx, by, bz, item.z, ea, eb, req, req_cap, slow, slow_cap, ctl,
+                              F);
   }
 }
 
@@ -302,14 +309,6 @@ __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P,
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cand(CandJob job,
                                                                                    Ctl* ctl) {
   cand_pixels_role(job, blockIdx.x, ctl);
-}
-
-__global__ void k_init_cand(unsigned long long* keys, uint32_t* ranks, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    keys[i] = kCandEmpty;
-    ranks[i] = kInf;
-  }
 }
 
 }  // namespace ratsdf

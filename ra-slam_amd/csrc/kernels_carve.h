@@ -1,0 +1,366 @@
+// kernels_carve.h -- the carve pass (space_carving_kernel's Delete calls, utils/tsdf/voxel_tsdf.cu:
+// 253-276,878-883; VoxelHashTable::Delete, voxel_hash.cu:110-159; ReleaseBlock, voxel_mem.cu:56-61)
+// without a launch of its own.
+//
+// The pass is made deterministic the same way as allocation: deletions happen in ascending
+// hash-entry order (the order of the reference's visible list).  It has three parts with different
+// dependencies, and each lives where its inputs become available:
+//   carve_candidate      (inside k_integrate, by the thread that holds a block's min |tsdf|)
+//                        a block in slot 0 of its home bucket is deleted on the spot -- that path
+//                        takes no lock and touches nothing else (voxel_hash.cu:114-123); a list-head
+//                        or chain block claims its home bucket with atomicMin(entry index) in the
+//                        carve claim table and is queued
+//   carve_resolve_slow   (first workgroup of the NEXT k_front, only when something is queued; the
+//                        other directory readers of that launch wait for it)
+//                        one winner per home bucket = the first in entry order (the bucket lock of
+//                        voxel_hash.cu:125-158); winners unlink; claims are released (ResetLocks)
+//   carve_finalize       (in the next k_alloc_rank, before its own pass; or k_settle when no frame
+//                        follows) ReleaseBlock in ascending entry order of the deleted blocks:
+//                          few deletes (the steady state): entries in an LDS list, every delete
+//                          counts the smaller ones; many deletes: entry-indexed bitmap + popcount
+//                          prefix (self-cleaning);
+//                        free-list bookkeeping, frame statistics, and the consumed FrameCtl is
+//                        zeroed for the frame after next.
+// Nothing between k_integrate and the next allocation pass needs the free list, and the next
+// k_front only needs the directory, so the order above is equivalent to the reference's
+// "integrate, then carve" with the carve's serial part off the frame's critical path.
+#pragma once
+#include "kernels_visible.h"
+
+namespace ratsdf {
+
+constexpr uint32_t kSmallCarve = 2048;
+
+struct CarveBufs {
+  DelItem* del;        // slot-0 deletes of the frame
+  uint32_t del_cap;
+  SlowDelete* slow;    // head / chain deletes of the frame
+  uint32_t slow_cap;
+  uint32_t* upd_wg;    // voxels updated, one counter per k_integrate workgroup
+  uint32_t upd_n;
+  uint32_t* bitmap;    // delete bitmap indexed by hash entry (many-deletes path)
+  uint32_t* summary;
+  uint32_t* prefix;
+};
+
+__device__ inline void occ_clear(const Table& tab, uint32_t e) {
+  atomicAnd(&tab.occ[e >> 6], ~(1ull << (e & 63)));
+}
+__device__ inline uint32_t ld_agent(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A block whose min |tsdf| >= 0.9 after the update (voxel_tsdf.cu:253-276).  One thread.
+__device__ inline void carve_candidate(const Table& tab, const CarveBufs& cb, Ctl* ctl, FrameCtl* F,
+                                       const VisItem& it) {
+  const uint32_t bucket = block_hash(it.x, it.y, it.z, tab.bucket_mask);
+  if (it.entry == (bucket << 1)) {                                       // voxel_hash.cu:114-123
+    uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + it.entry);
+    pe[1] = key1(it.z);  // offset = 0
+    pe[2] = (uint32_t)-1;
+    occ_clear(tab, it.entry);
+    const uint32_t slot = atomicAdd(&F->n_delcand, 1u);
+    if (slot < cb.del_cap) {
+      cb.del[slot] = DelItem{it.entry, it.idx};
+    } else {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+    }
+  } else {
+    atomicMin(&tab.dclaim[bucket], it.entry);
+    const uint32_t slot = atomicAdd(&F->n_slow_del, 1u);
+    if (slot < cb.slow_cap) {
+      cb.slow[slot] = SlowDelete{it.x, it.y, it.z, 0, it.entry, -1};
+    } else {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+    }
+  }
+}
+
+// Head / chain deletes.  All threads of one workgroup; every claim of the pass has been placed (the
+// kernel that placed them has finished).
+__device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb, Ctl* ctl, FrameCtl* F) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  SlowDelete* slow = cb.slow;
+  uint32_t ns = F->n_slow_del;
+  if (ns > cb.slow_cap) ns = cb.slow_cap;
+  // decide every winner before any claim is released (the state is parked in the item itself and
+  // re-read by the same thread)
+  for (uint32_t j = tid; j < ns; j += nt) {
+    const SlowDelete s = slow[j];
+    const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
+    slow[j].state = (ld_agent(&tab.dclaim[bucket]) == s.entry) ? 1 : 0;
+  }
+  __syncthreads();
+  for (uint32_t j = tid; j < ns; j += nt) {
+    const SlowDelete s = slow[j];
+    const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
+    tab.dclaim[bucket] = kInf;  // ResetLocks
+    if (!s.state) continue;
+    const uint32_t k0 = key0(s.x, s.y), k1 = key1(s.z);
+    uint32_t last = (bucket << 1) + 1;
+    uint32_t* ph = reinterpret_cast<uint32_t*>(tab.entries + last);
+    const EntryWords h = load_entry(tab.entries, last);
+    int32_t freed = -1;
+    if (entry_matches(h, k0, k1)) {                                     // voxel_hash.cu:125-140
+      const uint32_t nxt = (last + (uint32_t)entry_offset(h)) & tab.entry_mask;
+      uint32_t* pn = reinterpret_cast<uint32_t*>(tab.entries + nxt);
+      const EntryWords nw = load_entry(tab.entries, nxt);
+      freed = h.idx;
+      const int noff = entry_offset(nw);
+      const int16_t hoff = noff ? (int16_t)(entry_offset(h) + noff) : (int16_t)0;
+      ph[0] = nw.w0;
+      ph[1] = (nw.w1 & 0xFFFFu) | ((uint32_t)(uint16_t)hoff << 16);
+      ph[2] = (uint32_t)nw.idx;
+      pn[1] = pn[1] & 0xFFFFu;
+      pn[2] = (uint32_t)-1;
+      occ_clear(tab, nxt);  // the head keeps its bit unless it was its own successor
+    } else {                                                            // voxel_hash.cu:142-158
+      for (uint32_t g = 0; g < tab.num_entry; ++g) {
+        const EntryWords lw = load_entry(tab.entries, last);
+        const int loff = entry_offset(lw);
+        if (!loff) break;
+        const uint32_t cur = (last + (uint32_t)loff) & tab.entry_mask;
+        const EntryWords cw = load_entry(tab.entries, cur);
+        if (entry_matches(cw, k0, k1)) {
+          const int coff = entry_offset(cw);
+          const int16_t link = coff ? (int16_t)(loff + coff) : (int16_t)0;
+          uint32_t* pl = reinterpret_cast<uint32_t*>(tab.entries + last);
+          uint32_t* pcur = reinterpret_cast<uint32_t*>(tab.entries + cur);
+          pl[1] = (pl[1] & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16);
+          freed = cw.idx;
+          pcur[1] = pcur[1] & 0xFFFFu;
+          pcur[2] = (uint32_t)-1;
+          occ_clear(tab, cur);
+          break;
+        }
+        last = cur;
+      }
+    }
+    if (freed >= 0) {
+      slow[j].state = 2;
+      slow[j].freed = freed;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) F->slow_resolved = 1;
+}
+
+// Directory readers of the next launch: make sure the queued head / chain deletes of the previous
+// frame have happened.  Workgroup 0 of the launch does them; the others wait (the launch is small
+// enough to be fully resident and workgroup 0 is dispatched first).  Uniform per workgroup.
+__device__ inline void carve_resolve_gate(const Table& tab, const CarveBufs& cb, Ctl* ctl,
+                                          FrameCtl* Fprev) {
+  if (Fprev->n_slow_del == 0) return;  // the steady state
+  if (blockIdx.x == 0) {
+    if (ld_agent(&Fprev->slow_resolved) == 0) carve_resolve_slow(tab, cb, ctl, Fprev);  // uniform
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(&Fprev->slow_resolved, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (threadIdx.x == 0) {
+      while (__hip_atomic_load(&Fprev->slow_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 2u)
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+}
+
+// Pool releases of a finished frame with few deletes (the steady state), spread over kReleaseWGs
+// workgroups of the next k_front: ReleaseBlock in ascending entry order (voxel_mem.cu:56-60) means
+// delete w goes to heap[num_free + (number of deleted entries below its own)].  Every workgroup
+// holds the whole list of deleted entries in LDS; 16 lanes share a delete and each scans a 16th of
+// the list.  num_free is the value the frame's own allocation pass left (nothing changes it until
+// the next k_alloc_rank, which adds the number of releases).  The slow (head / chain) deletes of the
+// frame have been resolved before this runs (carve_resolve_gate).
+constexpr uint32_t kReleaseWGs = 16;
+
+__device__ inline void carve_release_role(const Pool& pool, const CarveBufs& cb, Ctl* ctl,
+                                          FrameCtl* Fp, uint32_t wg) {
+  __shared__ __attribute__((aligned(16))) uint32_t del_entry[kSmallCarve];
+  __shared__ int32_t del_pool[kSmallCarve];
+  __shared__ uint32_t n_extra;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  // one round of loads: counters, free count and (speculatively) the head of the delete list
+  const uint32_t pend = Fp->pending;
+  uint32_t nd = Fp->n_delcand, ns = Fp->n_slow_del;
+  const int32_t nf = ctl->num_free;
+  DelItem first = cb.del[tid < cb.del_cap ? tid : 0];
+  if (!pend) return;  // uniform
+  if (nd > cb.del_cap) nd = cb.del_cap;
+  if (ns > cb.slow_cap) ns = cb.slow_cap;
+  if (nd + ns > kSmallCarve || nd + ns == 0) return;  // many deletes: carve_finalize does them
+  if (tid == 0) n_extra = 0;
+  __syncthreads();
+  if (tid < nd) {
+    del_entry[tid] = first.entry;
+    del_pool[tid] = first.idx;
+  }
+  for (uint32_t i = tid + nt; i < nd; i += nt) {
+    const DelItem d = cb.del[i];
+    del_entry[i] = d.entry;
+    del_pool[i] = d.idx;
+  }
+  for (uint32_t j = tid; j < ns; j += nt) {  // head / chain deletes that happened: rare
+    const SlowDelete sd = cb.slow[j];
+    if (sd.state == 2) {
+      const uint32_t slot = nd + atomicAdd(&n_extra, 1u);
+      del_entry[slot] = sd.entry;
+      del_pool[slot] = sd.freed;
+    }
+  }
+  __syncthreads();
+  const uint32_t n = nd + n_extra;
+  const uint32_t n64 = (n + 63u) & ~63u;
+  if (tid < n64 - n) del_entry[n + tid] = kInf;  // n64 <= kSmallCarve (a multiple of 64)
+  __syncthreads();
+  const uint4* v = reinterpret_cast<const uint4*>(del_entry);
+  const uint32_t nchunks = n64 >> 2, sub = tid & 15u;
+  const uint32_t per_pass = (nt >> 4) * kReleaseWGs;
+  for (uint32_t base = 0; base < n; base += per_pass) {  // uniform
+    const uint32_t item = base + wg * (nt >> 4) + (tid >> 4);
+    const uint32_t mine = item < n ? del_entry[item] : 0u;
+    uint32_t k = 0;
+    for (uint32_t c = sub; c < nchunks; c += 16) {
+      const uint4 x = v[c];
+      k += (x.x < mine) + (x.y < mine) + (x.z < mine) + (x.w < mine);
+    }
+    k += __shfl_xor(k, 1);
+    k += __shfl_xor(k, 2);
+    k += __shfl_xor(k, 4);
+    k += __shfl_xor(k, 8);
+    if (sub == 0 && item < n) pool.heap[(uint32_t)nf + k] = del_pool[item];
+  }
+}
+
+// ReleaseBlock calls of a finished frame in ascending entry order + bookkeeping.  All threads of one
+// workgroup.  `scratch`: 2 * kSmallCarve + 80 words of LDS (16-byte aligned).  `nf` = free blocks before the releases.
+// Returns the number of blocks released (uniform).
+__device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, const CarveBufs& cb,
+                                          Ctl* ctl, FrameCtl* F, ratsdf_frame_stats* stats, int32_t nf,
+                                          uint32_t* scratch) {
+  if (F->pending == 0) return 0;  // uniform
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  uint32_t* lds = scratch;                    // [0,32): scan scratch, [32]: counter, [33]: result
+  uint32_t* del_entry = scratch + 64;
+  int32_t* del_pool = reinterpret_cast<int32_t*>(scratch + 64 + kSmallCarve + 16);
+  uint32_t nd = F->n_delcand, ns = F->n_slow_del;
+  if (nd > cb.del_cap) nd = cb.del_cap;
+  if (ns > cb.slow_cap) ns = cb.slow_cap;
+  const uint32_t n_win = F->n_win, n_slow_req = F->n_slow;
+  uint32_t nv = n_win;
+#pragma unroll
+  for (int l = 0; l < kNumLists; ++l) nv += F->n_list[l];
+  // voxels updated: per-workgroup counters of k_integrate (consumed here)
+  uint32_t upd_part = 0;
+  for (uint32_t i = tid; i < cb.upd_n; i += nt) {
+    const uint32_t u = cb.upd_wg[i];
+    if (u) {
+      upd_part += u;
+      cb.upd_wg[i] = 0;
+    }
+  }
+  if (tid == 0) lds[32] = 0;
+  __syncthreads();
+  uint32_t n_del = 0;
+  if (nd + ns <= kSmallCarve) {
+    for (uint32_t i = tid; i < nd; i += nt) {
+      const DelItem d = cb.del[i];
+      del_entry[i] = d.entry;
+      del_pool[i] = d.idx;
+    }
+    for (uint32_t j = tid; j < ns; j += nt) {
+      const SlowDelete s = cb.slow[j];
+      if (s.state == 2) {
+        const uint32_t slot = nd + atomicAdd(&lds[32], 1u);
+        del_entry[slot] = s.entry;
+        del_pool[slot] = s.freed;
+      }
+    }
+    __syncthreads();
+    n_del = nd + lds[32];
+    // rank of a delete = number of deleted entries below its own (all in LDS)
+    lds_rank_all(del_entry, n_del, [&](uint32_t w, uint32_t k) {
+      pool.heap[(uint32_t)nf + k] = del_pool[w];                          // voxel_mem.cu:56-60
+    });
+  } else {
+    for (uint32_t i = tid; i < nd; i += nt) bitmap_set(cb.bitmap, cb.summary, cb.del[i].entry);
+    for (uint32_t j = tid; j < ns; j += nt)
+      if (cb.slow[j].state == 2) bitmap_set(cb.bitmap, cb.summary, cb.slow[j].entry);
+    __syncthreads();
+    const uint32_t nwords = tab.num_entry >> 5;
+    const uint32_t chunk = bitmap_chunk(nwords, nt);
+    const uint32_t sum = chunk_popcount(cb.bitmap, cb.summary, nwords, chunk);
+    uint32_t total = 0;
+    const uint32_t excl = block_exclusive_scan(sum, lds, &total);
+    bitmap_write_prefix(cb.bitmap, cb.summary, cb.prefix, nwords, chunk, sum, excl);
+    __syncthreads();
+    n_del = total;
+    for (uint32_t i = tid; i < nd; i += nt) {
+      const DelItem d = cb.del[i];
+      pool.heap[(uint32_t)nf + bitmap_rank(cb.bitmap, cb.prefix, d.entry)] = d.idx;
+    }
+    for (uint32_t j = tid; j < ns; j += nt) {
+      const SlowDelete s = cb.slow[j];
+      if (s.state == 2) pool.heap[(uint32_t)nf + bitmap_rank(cb.bitmap, cb.prefix, s.entry)] = s.freed;
+    }
+    __syncthreads();  // every reader of the delete bitmap is done: leave it clean for the next pass
+    bitmap_clean(cb.bitmap, cb.summary, nwords);
+  }
+  uint32_t upd = 0;
+  (void)block_exclusive_scan(upd_part, lds, &upd);
+  if (tid == 0) {
+    if (stats) {
+      stats->visible_blocks = (int32_t)nv;
+      stats->updated_voxels = (int32_t)upd;
+      stats->allocated_blocks = (int32_t)n_win;
+      stats->deleted_blocks = (int32_t)n_del;
+      stats->active_blocks = tab.num_block - (nf + (int32_t)n_del);
+      stats->slow_requests = (int32_t)n_slow_req;
+      ctl->totals[0] += 1;
+      ctl->totals[1] += nv;
+      ctl->totals[2] += upd;
+      ctl->totals[3] += n_win;
+      ctl->totals[4] += n_del;
+    }
+    // counters ready for the frame after next
+    uint32_t* z = reinterpret_cast<uint32_t*>(F);
+    for (int i = 0; i < (int)(sizeof(FrameCtl) / 4); ++i) z[i] = 0;
+  }
+  __syncthreads();
+  return n_del;
+}
+
+// explicit delete list (test hook, utils/tests/voxel_mem_test.cu:56-78): every listed block that
+// exists becomes a carve candidate; k_settle then deletes them in entry order
+__global__ void k_delete_list(Table tab, const int16_t* pos, int n, CarveBufs cb, Ctl* ctl,
+                              uint32_t par) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  FrameCtl* F = &ctl->fr[par];
+  if (i == 0) F->pending = 1;
+  if (i >= n) return;
+  EntryWords w;
+  const int x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+  const uint32_t e = find_block(tab, x, y, z, &w);
+  if (e == kInf) return;
+  carve_candidate(tab, cb, ctl, F, VisItem{(int16_t)x, (int16_t)y, (int16_t)z, 0, w.idx, e});
+}
+
+// The tail of the last frame when no other frame follows it (queries, statistics, test hooks and
+// ratsdf_synchronize call this first): queued head / chain deletes + carve_finalize.
+__global__ __launch_bounds__(1024) void k_settle(Table tab, Pool pool, CarveBufs cb, Ctl* ctl,
+                                                 uint32_t par, ratsdf_frame_stats* stats) {
+  __shared__ __attribute__((aligned(16))) uint32_t scratch[2 * kSmallCarve + 80];
+  FrameCtl* F = &ctl->fr[par];
+  if (F->n_slow_del != 0 && ld_agent(&F->slow_resolved) == 0) {  // uniform
+    carve_resolve_slow(tab, cb, ctl, F);
+    __threadfence();
+    __syncthreads();
+  }
+  const int32_t nf = ctl->num_free;
+  const uint32_t n_del = carve_finalize(tab, pool, cb, ctl, F, stats, nf, scratch);
+  if (threadIdx.x == 0 && n_del) ctl->num_free = nf + (int32_t)n_del;
+}
+
+}  // namespace ratsdf

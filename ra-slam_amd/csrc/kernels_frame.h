@@ -1,0 +1,226 @@
+// kernels_frame.h -- the launches of a frame besides k_integrate.  A frame is three launches:
+//
+//   k_front(f)       reads the directory: visible list (visible_append_role) + allocation requests
+//                    from the frame's candidate set (cand_consume_role); first makes sure the queued
+//                    head / chain deletes of frame f-1 have happened (carve_resolve_gate)
+//   k_alloc_rank(f)  ONE workgroup does the serial bookkeeping: pool releases and statistics of frame
+//                    f-1 (carve_finalize), then this frame's allocation order (alloc_rank_role)
+//   k_integrate(f)   commit of the winners + voxel update + start of the carve pass
+//
+// Both k_front and k_alloc_rank leave most of the chip idle, so when the caller has already handed
+// over frame f+1 (ratsdf_integrate_device_batch) its directory-independent candidate pass
+// (cand_pixels_role) rides along as extra workgroups: `ahead` describes the share each launch takes.
+#pragma once
+#include "kernels_integrate.h"
+
+namespace ratsdf {
+
+// workgroups [0, n_vis_wg)               visible list of the blocks that exist before this frame
+//                                        (longest dependency chain, so it is dispatched first)
+// workgroups [n_vis_wg, +kCandSegs)      allocation requests from the frame's candidate set
+// workgroups [.., +kReleaseWGs)          pool releases of the previous frame (carve_release_role)
+// workgroups beyond                      look-ahead candidate pass of the next frame
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(
+    Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, Request* req, uint32_t req_cap,
+    SlowRequest* slow, uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Pool pool, CarveBufs cb,
+    Ctl* ctl, uint32_t par, CandJob ahead) {
+  const uint32_t n_dir_wg = n_vis_wg + kCandSegs + kReleaseWGs;
+  if (blockIdx.x >= n_dir_wg) {
+    cand_pixels_role(ahead, blockIdx.x - n_dir_wg, ctl);
+    return;
+  }
+  carve_resolve_gate(tab, cb, ctl, &ctl->fr[par ^ 1u]);
+  FrameCtl* F = &ctl->fr[par];
+  if (blockIdx.x >= n_vis_wg + kCandSegs) {
+    carve_release_role(pool, cb, ctl, &ctl->fr[par ^ 1u], blockIdx.x - n_vis_wg - kCandSegs);
+  } else if (blockIdx.x >= n_vis_wg) {
+    cand_consume_role(tab, P, cand, blockIdx.x - n_vis_wg, req, req_cap, slow, slow_cap, ctl, F);
+  } else if (P.debug != 3) {
+    visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F);
+  }
+}
+
+struct RankBufs {
+  Request* req;
+  uint32_t req_cap;
+  uint32_t* req_k;
+  const SlowRequest* slow;
+  uint32_t slow_cap;
+  XLock* xlocks;
+  SlowRequest* distinct;
+  uint32_t* win_ranks;  // raster ranks of the winners (few-winners path, kSmallRank entries)
+  uint32_t* bitmap;   // rank bitmap (many-requests path)
+  uint32_t* summary;
+  uint32_t* prefix;
+  uint32_t nwords;
+};
+
+// The serial bookkeeping of a frame in its steady-state shape (few deletes, few requests, no chained
+// buckets involved): carve_finalize of the previous frame + alloc_rank_role of this one, fused so that
+// every input is requested in ONE round of loads at the top (a single workgroup that walks
+// "counter -> list -> table -> ..." pays a full memory round trip per arrow, which is what these
+// kernels consist of).  Anything unusual falls back to the general functions.
+// `scratch`: the workgroup's dynamic LDS.  All 1024 threads.
+__device__ inline void serial_frame_role(const Table& tab, const Pool& pool, const RankBufs& rb,
+                                         const CarveBufs& cb, Ctl* ctl, uint32_t par,
+                                         ratsdf_frame_stats* stats, unsigned long long* skeys) {
+#ifdef RATSDF_STAMPS
+  unsigned long long ts[6];
+#define SSTAMP(i) ts[i] = (unsigned long long)clock64()
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+  constexpr uint32_t NT = 1024;
+  constexpr uint32_t RPT = kSmallRank / NT;   // requests per thread held in registers
+  constexpr uint32_t UPT = 4;                 // update counters per thread
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(skeys);
+  uint32_t* lds = scratch;  // [32] slow-delete counter, [33] winner counter, [34] update sum
+  const uint32_t tid = threadIdx.x;
+  FrameCtl* Fp = &ctl->fr[par ^ 1u];
+  FrameCtl* F = &ctl->fr[par];
+
+  SSTAMP(0);
+  // ---- one round of loads ----
+  const int32_t nf0 = ctl->num_free;
+  const uint32_t pend = Fp->pending;
+  uint32_t nd = Fp->n_delcand, ns = Fp->n_slow_del;
+  const uint32_t p_win = Fp->n_win, p_slow = Fp->n_slow;
+  uint32_t nv = p_win;
+#pragma unroll
+  for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l];
+  const uint32_t n_slow = F->n_slow;
+  uint32_t n = F->n_req;
+  uint32_t u[UPT];
+#pragma unroll
+  for (uint32_t k = 0; k < UPT; ++k) {
+    const uint32_t i = tid + k * NT;
+    u[k] = i < cb.upd_n ? cb.upd_wg[i] : 0u;
+  }
+  Request r[RPT];  // the first NT requests ride in the first round; more only if there are more
+  r[0] = rb.req[tid < rb.req_cap ? tid : 0];
+  unsigned long long tot[5] = {0, 0, 0, 0, 0};
+  if (tid == 0 && stats) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) tot[i] = ctl->totals[i];
+  }
+  if (nd > cb.del_cap) nd = cb.del_cap;
+  if (ns > cb.slow_cap) ns = cb.slow_cap;
+  if (n > rb.req_cap) n = rb.req_cap;
+
+  const bool fast = (!pend || nd + ns <= kSmallCarve) && n_slow == 0 && n <= kSmallRank;
+  SSTAMP(1);
+  if (!fast) {  // uniform
+    int32_t nf = nf0;
+    nf += (int32_t)carve_finalize(tab, pool, cb, ctl, Fp, stats, nf, scratch);
+    alloc_rank_role(tab, rb.req, rb.req_cap, rb.req_k, rb.slow, rb.slow_cap, rb.xlocks, rb.distinct,
+                    rb.bitmap, rb.summary, rb.prefix, rb.nwords, ctl, F, nf, skeys);
+    return;
+  }
+
+  // second (and last) dependent round: the claim of every request's bucket
+  uint32_t c[RPT];
+#pragma unroll
+  for (uint32_t k = 0; k < RPT; ++k) {
+    const uint32_t i = tid + k * NT;
+    c[k] = kInf;
+    if (k > 0) {
+      r[k] = Request{0, 0, 0, 0, 0, 0};
+      if (i < n) r[k] = rb.req[i];
+    }
+    if (i < n) c[k] = tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)];
+  }
+  if (tid < 3) lds[32 + tid] = 0;
+  __syncthreads();
+  SSTAMP(2);
+  // ---- previous frame: its pool releases were pushed by the release role of this frame's k_front
+  // (same "few deletes" condition); here only the count and the voxels-updated sum are needed ----
+  if (pend) {
+    for (uint32_t j = tid; j < ns; j += NT)  // head / chain deletes: rare
+      if (cb.slow[j].state == 2) atomicAdd(&lds[32], 1u);
+    uint32_t up = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < UPT; ++k) {
+      up += u[k];
+      if (u[k]) cb.upd_wg[tid + k * NT] = 0;
+    }
+    for (uint32_t i = tid + UPT * NT; i < cb.upd_n; i += NT) {
+      const uint32_t x = cb.upd_wg[i];
+      if (x) {
+        up += x;
+        cb.upd_wg[i] = 0;
+      }
+    }
+    up = wave_sum(up);
+    if ((tid & 63) == 0 && up) atomicAdd(&lds[34], up);
+  }
+  // ---- this frame: the winners' ranks go to a compact list; k_integrate turns a rank into the
+  // winner's position in raster order (= order of the AquireBlock calls) by counting the smaller ones
+#pragma unroll
+  for (uint32_t k = 0; k < RPT; ++k) {
+    const uint32_t i = tid + k * NT;
+    if (i < n && c[k] == r[k].rank) {
+      rb.req[i].flags = kReqWinner;
+      const uint32_t slot = atomicAdd(&lds[33], 1u);
+      rb.win_ranks[slot] = r[k].rank;
+    }
+  }
+  __syncthreads();
+  SSTAMP(3);
+  const uint32_t n_del = pend ? nd + lds[32] : 0u;
+  const uint32_t total = lds[33];
+  const uint32_t upd = lds[34];
+  const int32_t nf = nf0 + (int32_t)n_del;
+  SSTAMP(4);
+#ifdef RATSDF_STAMPS
+  if (tid == 0) { ctl->stamps[16] += n_del; ctl->stamps[17] += total; ctl->stamps[18] += n; }
+#endif
+  if (tid == 0) {
+    if (pend) {
+      if (stats) {
+        stats->visible_blocks = (int32_t)nv;
+        stats->updated_voxels = (int32_t)upd;
+        stats->allocated_blocks = (int32_t)p_win;
+        stats->deleted_blocks = (int32_t)n_del;
+        stats->active_blocks = tab.num_block - nf;
+        stats->slow_requests = (int32_t)p_slow;
+        ctl->totals[0] = tot[0] + 1;
+        ctl->totals[1] = tot[1] + nv;
+        ctl->totals[2] = tot[2] + upd;
+        ctl->totals[3] = tot[3] + p_win;
+        ctl->totals[4] = tot[4] + n_del;
+      }
+      uint32_t* z = reinterpret_cast<uint32_t*>(Fp);  // counters ready for the frame after next
+      for (int i = 0; i < (int)(sizeof(FrameCtl) / 4); ++i) z[i] = 0;
+    }
+    uint32_t take = total;
+    if ((int64_t)total > (int64_t)nf) {  // voxel_mem.cu:39 assert(idx >= 1)
+      set_error(ctl, RATSDF_ERR_POOL_EXHAUSTED);
+      take = (uint32_t)nf;
+    }
+    F->alloc_base = (uint32_t)nf;
+    F->n_win = take;
+    F->n_winlist = total;
+    F->pending = 1;  // this frame now owes a carve_finalize
+    ctl->num_free = nf - (int32_t)take;
+  }
+  SSTAMP(5);
+#ifdef RATSDF_STAMPS
+  if (tid == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&ctl->stamps[8 + i], ts[i]);
+#endif
+}
+
+// workgroup 0: carve_finalize of the previous frame, then this frame's allocation order
+// workgroups beyond: look-ahead candidate pass of the next frame
+__global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Pool pool, RankBufs rb, CarveBufs cb,
+                                                     Ctl* ctl, uint32_t par,
+                                                     ratsdf_frame_stats* stats, CandJob ahead) {
+  if (blockIdx.x != 0) {
+    cand_pixels_role(ahead, blockIdx.x - 1, ctl);
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  serial_frame_role(tab, pool, rb, cb, ctl, par, stats, skeys);
+}
+
+}  // namespace ratsdf

@@ -10,9 +10,9 @@
 //   * queries / exports: k_select_flags + k_select_scatter build a list ordered by ascending
 //     hash-entry index exactly like the reference's scan + gather (one lane per 64-entry word
 //     produces a selection mask, the scatter kernel turns per-workgroup counts into offsets).
-// Counts stay on the device (Ctl::n_vis / n_sel); consumers are persistent grids that read them.
+// Counts stay on the device (FrameCtl::n_list / Ctl::n_sel); consumers are persistent grids that read them.
 #pragma once
-#include "kernels_alloc.h"
+#include "kernels_cand.h"
 
 namespace ratsdf {
 
@@ -77,7 +77,7 @@ __device__ inline void select_flags_role(const Table& tab, const FrameParams& P,
 // non-empty list.  The lists are unordered; nothing in a frame depends on their order (blocks are
 // independent; the carve pass orders its pool releases by hash entry).
 __device__ inline void visible_append_role(const Table& tab, const FrameParams& P, uint32_t wg,
-                                           VisItem* vis, uint32_t seg_cap, Ctl* ctl) {
+                                           VisItem* vis, uint32_t seg_cap, Ctl* ctl, FrameCtl* F) {
   __shared__ uint32_t cnt[kNumLists], base[kNumLists], cnt2[kNumLists];
 #ifdef RATSDF_STAMPS
   unsigned long long* ws = (ctl->debug_buf && P.debug == 10) ? ctl->debug_buf + (size_t)((wg * 4 + (threadIdx.x >> 6)) & 16383) * 8 : nullptr;
@@ -115,7 +115,7 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
   __syncthreads();
   if (threadIdx.x < kNumLists) {
     const uint32_t c = cnt[threadIdx.x];
-    base[threadIdx.x] = c ? atomicAdd(&ctl->n_list[threadIdx.x], c) : 0u;
+    base[threadIdx.x] = c ? atomicAdd(&F->n_list[threadIdx.x], c) : 0u;
   }
   __syncthreads();
   VSTAMP(3);
@@ -138,22 +138,6 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
 #ifdef RATSDF_STAMPS
   if (ws && (threadIdx.x & 63) == 0) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }
 #endif
-}
-
-// k_front: the two directory-read-only jobs of a frame in one launch.
-//   workgroups [0, n_vis_wg)              visible list of the blocks that exist before this frame
-//                                         (longest dependency chain, so it is dispatched first)
-//   workgroups [n_vis_wg, +kCandSegs)     allocation requests from the frame's candidate set
-//                                         (cand_consume_role, kernels_cand.h)
-// Blocks inserted by this frame join the list in k_integrate (they are visible by construction).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(
-    Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, Request* req, uint32_t req_cap,
-    SlowRequest* slow, uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Ctl* ctl) {
-  if (blockIdx.x >= n_vis_wg) {
-    cand_consume_role(tab, P, cand, blockIdx.x - n_vis_wg, req, req_cap, slow, slow_cap, ctl);
-  } else if (P.debug != 3) {
-    visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl);
-  }
 }
 
 template <int Mode>

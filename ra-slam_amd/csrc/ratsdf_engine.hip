@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "kernels_frame.h"
 #include "kernels_mesh.h"
 
 using namespace ratsdf;
@@ -57,7 +58,6 @@ struct ratsdf_engine {
   int vpl = kDefaultVPL;
   int debug = 0;
   unsigned integrate_grid = 4096;
-  unsigned pipe_grid = 0;  // > 0: persistent software-pipelined k_integrate with this many workgroups
 
   Table tab{};
   Pool pool{};
@@ -72,13 +72,14 @@ struct ratsdf_engine {
   uint32_t* cand_count = nullptr;        // both sets' list counters
   unsigned parity = 0;                   // which texel buffer / candidate set the NEXT frame uses
   bool cand_ready = false;               // that frame's candidate pass has already been enqueued
-  unsigned cand_split = 15;              // percent of the look-ahead pass placed in k_alloc_rank
+  unsigned cand_split = 60;              // percent of the look-ahead pass placed in k_alloc_rank
   unsigned cand_wgs = 248;               // look-ahead workgroups per host kernel (about one per CU)
   Request* req = nullptr;
   uint32_t req_cap = 0;
   uint32_t* abitmap = nullptr;   // rank bitmap, many-request path only (whole 32-word groups)
   uint32_t* asummary = nullptr;  // one bit per group
   uint32_t* req_k = nullptr;     // rank among the winners, per request
+  uint32_t* win_ranks = nullptr; // raster ranks of the winners (few-winners path)
   uint32_t* aprefix = nullptr;       // per-word prefix of the rank bitmap (set groups only)
   uint32_t awords_cap = 0, asum_words = 0;
 
@@ -91,12 +92,14 @@ struct ratsdf_engine {
   uint32_t* wg_count = nullptr;         // selected entries per kVisWG-word workgroup
   uint32_t nwg = 0;
   VisItem* vis = nullptr;
-  uint32_t* carve_flag = nullptr;  // per visible block: bit 31 carve candidate | voxels updated
+  DelItem* del_list = nullptr;     // slot-0 deletes of the last pass (pool release pending)
+  uint32_t* upd_wg = nullptr;      // voxels updated per k_integrate workgroup
+  bool pending = false;            // the last pass still owes its carve_finalize (kernels_carve.h)
   uint32_t* dbitmap = nullptr;   // delete bitmap indexed by hash entry (self-cleaning)
   uint32_t* dsummary = nullptr;
   uint32_t* dprefix = nullptr;
   void* d_mc = nullptr;   // marching-cubes tables (device), built on first use
-  uint32_t vis_cap = 0;   // total items of `vis` / `carve_flag`
+  uint32_t vis_cap = 0;   // total items of `vis`
   uint32_t seg_cap = 0;   // items per work list (vis holds kNumLists + 1 segments)
   uint32_t dwords = 0;
   SlowDelete* slowdel = nullptr;
@@ -117,8 +120,9 @@ struct ratsdf_engine {
   int free_all();
   int ensure_image(size_t npix, size_t nranks);
   int ensure_stage(size_t npix);
-  int alloc_rank(uint32_t nranks, const CandJob* next = nullptr);
-  int carve_tail(bool is_frame, const CandJob* next = nullptr);
+  int alloc_rank(uint32_t nranks, unsigned par, const CandJob* next = nullptr);
+  int settle();
+  CarveBufs carve_bufs() const;
   int select(int mode, const GridBounds& gb, uint32_t* count_slot);
   struct FrameIn {
     const void *rgb, *depth, *ht, *lt;
@@ -156,11 +160,10 @@ FrameParams ratsdf_engine::base_params() const {
 int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
   void* ptrs[] = {tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
-                  d_stats, texA[0], texA[1], texB[0], texB[1], cand[0].keys, cand[1].keys,
-                  cand[0].ranks, cand[1].ranks, cand[0].list, cand[1].list, cand_count,
-                  req, req_k, abitmap, asummary, aprefix,
+                  d_stats, texA[0], texA[1], texB[0], texB[1], cand[0].list, cand[1].list, cand_count,
+                  req, req_k, win_ranks, abitmap, asummary, aprefix,
                   slow, xlocks,
-                  distinct, masks, wg_count, vis, carve_flag, dbitmap, dsummary, dprefix,
+                  distinct, masks, wg_count, vis, del_list, upd_wg, tab.dclaim, dbitmap, dsummary, dprefix,
                   slowdel, d_stage, d_mc};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -188,6 +191,14 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
     pix_cap = npix;
   }
   if (nranks > rank_cap) {
+    // candidate lists: every sample of the image could in principle ask for a different block
+    const uint32_t seg = (uint32_t)((nranks + kCandSegs - 1) / kCandSegs) + 1024;
+    for (int i = 0; i < 2; ++i) {
+      if (cand[i].list) (void)hipFree(cand[i].list);
+      cand[i].list = nullptr;
+      HIPCHK(hipMalloc(&cand[i].list, (size_t)seg * kCandSegs * sizeof(uint4)));
+      cand[i].seg_cap = seg;
+    }
     if (req) (void)hipFree(req);
     if (req_k) (void)hipFree(req_k);
     if (abitmap) (void)hipFree(abitmap);
@@ -229,28 +240,52 @@ int ratsdf_engine::ensure_stage(size_t npix) {
 
 // rank kernel (resolve + mark + scan) on a rank space of `nranks`; the commit itself happens inside
 // k_integrate for frames and in k_commit_only for the stand-alone test hook
-int ratsdf_engine::alloc_rank(uint32_t nranks, const CandJob* next) {
-  const uint32_t nwords = (nranks + 31) / 32;
+CarveBufs ratsdf_engine::carve_bufs() const {
+  CarveBufs cb;
+  cb.del = del_list;
+  cb.del_cap = (uint32_t)tab.num_block;
+  cb.slow = slowdel;
+  cb.slow_cap = kSlowDelCap;
+  cb.upd_wg = upd_wg;
+  cb.upd_n = integrate_grid;
+  cb.bitmap = dbitmap;
+  cb.summary = dsummary;
+  cb.prefix = dprefix;
+  return cb;
+}
+
+int ratsdf_engine::alloc_rank(uint32_t nranks, unsigned par, const CandJob* next) {
   CandJob none;
   memset(&none, 0, sizeof(none));
   const CandJob& job = next ? *next : none;
-  const unsigned extra = job.n_pixels ? (job.n_pixels + job.pixels_per_wg - 1) / job.pixels_per_wg : 0;
+  const unsigned extra = job.n_tiles ? (job.n_tiles + job.tiles_per_wg - 1) / job.tiles_per_wg : 0;
+  RankBufs rb;
+  rb.req = req;
+  rb.req_cap = req_cap;
+  rb.req_k = req_k;
+  rb.win_ranks = win_ranks;
+  rb.slow = slow;
+  rb.slow_cap = kSlowCap;
+  rb.xlocks = xlocks;
+  rb.distinct = distinct;
+  rb.bitmap = abitmap;
+  rb.summary = asummary;
+  rb.prefix = aprefix;
+  rb.nwords = (nranks + 31) / 32;
   hipLaunchKernelGGL(k_alloc_rank, dim3(1 + extra), dim3(1024),
-                     kSlowSortCap * sizeof(unsigned long long), stream, tab, req, req_cap, req_k, slow,
-                     kSlowCap, xlocks, distinct, abitmap, asummary, aprefix, nwords, ctl, job);
+                     kSlowSortCap * sizeof(unsigned long long), stream, tab, pool, rb, carve_bufs(), ctl,
+                     (uint32_t)par, d_stats, job);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
 
-int ratsdf_engine::carve_tail(bool is_frame, const CandJob* next) {
-  CandJob none;
-  memset(&none, 0, sizeof(none));
-  const CandJob& job = next ? *next : none;
-  const unsigned extra = job.n_pixels ? (job.n_pixels + job.pixels_per_wg - 1) / job.pixels_per_wg : 0;
-  hipLaunchKernelGGL(k_carve, dim3(1 + extra), dim3(1024), 0, stream, tab, pool, vis, seg_cap,
-                     carve_flag, dbitmap, dsummary, dprefix, slowdel, kSlowDelCap, ctl,
-                     is_frame ? d_stats : (ratsdf_frame_stats*)nullptr, job);
+// Everything but a following frame needs the last frame's carve pass completed first.
+int ratsdf_engine::settle() {
+  if (!pending) return RATSDF_OK;
+  hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, stream, tab, pool, carve_bufs(), ctl,
+                     (uint32_t)(parity ^ 1u), d_stats);
   HIPCHK(hipGetLastError());
+  pending = false;
   return RATSDF_OK;
 }
 
@@ -296,9 +331,10 @@ CandJob ratsdf_engine::cand_job(const FrameIn& in, const FrameParams& P, unsigne
   j.texA = texA[par];
   j.texB = texB[par];
   j.set = cand[par];
-  j.first_pixel = 0;
-  j.n_pixels = (uint32_t)((size_t)P.W * P.H);
-  j.pixels_per_wg = 256;
+  j.tiles_x = (uint32_t)((P.W + 15) / 16);
+  j.first_tile = 0;
+  j.n_tiles = j.tiles_x * (uint32_t)((P.H + 15) / 16) * 4u;
+  j.tiles_per_wg = 4;
   return j;
 }
 
@@ -314,34 +350,36 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
 
   if (!cand_ready) {  // nobody looked ahead: this frame's candidate pass runs in line
     const CandJob job = cand_job(cur, P, par);
-    hipLaunchKernelGGL(k_cand, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, job, ctl);
+    hipLaunchKernelGGL(k_cand, dim3((job.n_tiles + 3) / 4), dim3(256), 0, stream, job, ctl);
   }
-  CandJob ahead_a, ahead_b;
+  CandJob ahead_a, ahead_b;  // shares of the next frame's candidate pass: k_front, k_alloc_rank
+  memset(&ahead_a, 0, sizeof(ahead_a));
+  memset(&ahead_b, 0, sizeof(ahead_b));
   if (next) {
     const FrameParams Pn = frame_params(*next, H, W, md);
     ahead_a = cand_job(*next, Pn, par ^ 1u);
     ahead_b = ahead_a;
-    // split in whole 64-pixel wave spans; each share is spread over ~one workgroup per CU (the
-    // single-workgroup kernels run 1024 threads, of which a look-ahead workgroup uses as many as it
-    // needs to cover its pixels)
-    const uint32_t spans = (uint32_t)((npix + 63) / 64);
-    const uint32_t spans_a = (uint32_t)((uint64_t)spans * cand_split / 100);
-    ahead_a.n_pixels = (uint32_t)std::min<size_t>((size_t)spans_a * 64, npix);
-    ahead_b.first_pixel = ahead_a.n_pixels;
-    ahead_b.n_pixels = (uint32_t)npix - ahead_a.n_pixels;
-    for (CandJob* j : {&ahead_a, &ahead_b}) {
-      uint32_t ppw = (j->n_pixels + cand_wgs - 1) / cand_wgs;
-      ppw = (ppw + 63) / 64 * 64;
-      j->pixels_per_wg = std::min<uint32_t>(std::max<uint32_t>(ppw, 64u), 1024u);
-    }
+    // k_front takes whole 16x16 super-tiles (4 tiles per 256-thread workgroup)
+    const uint32_t tiles = ahead_a.n_tiles;
+    const uint32_t tiles_a = (uint32_t)((uint64_t)(tiles / 4) * cand_split / 100) * 4;
+    ahead_a.n_tiles = tiles_a;
+    ahead_a.tiles_per_wg = 4;
+    ahead_b.first_tile = tiles_a;
+    ahead_b.n_tiles = tiles - tiles_a;
+    // k_alloc_rank runs 1024-thread workgroups, about one per CU; a look-ahead workgroup uses as
+    // many of its 16 waves as it needs to cover its tiles
+    const uint32_t tpw = (ahead_b.n_tiles + cand_wgs - 1) / cand_wgs;
+    ahead_b.tiles_per_wg = std::min<uint32_t>(std::max<uint32_t>(tpw, 1u), 16u);
   }
   parity = par ^ 1u;
   cand_ready = next != nullptr;
 
-  // the control block was zeroed by the previous pass's last kernel (k_carve) or at creation
-  hipLaunchKernelGGL(k_front, dim3(nwg + kCandSegs), dim3(256), 0, stream, tab, P, nwg, cand[par], req,
-                     req_cap, slow, kSlowCap, vis, seg_cap, ctl);
-  st = alloc_rank((uint32_t)(npix * (size_t)S), next ? &ahead_a : nullptr);
+  // fr[par] was zeroed when the frame before last was finalised (or at creation)
+  const unsigned extra_a = (ahead_a.n_tiles + 3) / 4;
+  hipLaunchKernelGGL(k_front, dim3(nwg + kCandSegs + kReleaseWGs + extra_a), dim3(256), 0, stream, tab,
+                     P, nwg, cand[par], req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(),
+                     ctl, (uint32_t)par, ahead_a);
+  st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr);
   if (st != RATSDF_OK) return st;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -358,31 +396,27 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     ++prof_used;
     HIPCHK(hipEventRecord(ev0, stream));
   }
-  if (pipe_grid) {
-    if (vpl == 4)
-      hipLaunchKernelGGL(k_integrate_pipe<4>, dim3(pipe_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
-    else
-      hipLaunchKernelGGL(k_integrate_pipe<2>, dim3(pipe_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
-  } else
+  const CarveBufs cb = carve_bufs();
   switch (vpl) {
     case 8:
       hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, win_ranks, texA[par], texB[par], cb, ctl,
+                         (uint32_t)par);
       break;
     case 4:
       hipLaunchKernelGGL(k_integrate<4>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, win_ranks, texA[par], texB[par], cb, ctl,
+                         (uint32_t)par);
       break;
     default:
       hipLaunchKernelGGL(k_integrate<2>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, texA[par], texB[par], carve_flag, ctl);
+                         vis, seg_cap, req, req_cap, req_k, win_ranks, texA[par], texB[par], cb, ctl,
+                         (uint32_t)par);
   }
   if (timed) HIPCHK(hipEventRecord(ev1, stream));
 
-  st = carve_tail(true, next ? &ahead_b : nullptr);
-  if (st != RATSDF_OK) return st;
+  HIPCHK(hipGetLastError());
+  pending = true;
   if (profiling && prof_used >= 4096) return drain_profile();
   return RATSDF_OK;
 }
@@ -438,10 +472,6 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     if (x == 2 || x == 4 || x == 8) e->vpl = x;
   }
   if (const char* v = getenv("RATSDF_DEBUG")) e->debug = atoi(v);
-  if (const char* v = getenv("RATSDF_PIPE")) {
-    const int x = atoi(v);
-    if (x >= 8 && x <= 8192 && x % 8 == 0) e->pipe_grid = (unsigned)x;
-  }
   if (const char* v = getenv("RATSDF_CAND_SPLIT")) {
     const int x = atoi(v);
     if (x >= 0 && x <= 100) e->cand_split = (unsigned)x;
@@ -493,30 +523,21 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   e->seg_cap = (uint32_t)t.num_block;              // any list can hold every block
   e->vis_cap = (kNumLists + 1) * e->seg_cap;       // 8 per-XCD lists + this frame's new blocks
   CREATE_CHK(hipMalloc(&e->vis, (size_t)e->vis_cap * sizeof(VisItem)));
-  CREATE_CHK(hipMalloc(&e->carve_flag, (size_t)e->vis_cap * 4));
+  CREATE_CHK(hipMalloc(&e->del_list, (size_t)t.num_block * sizeof(DelItem)));
+  CREATE_CHK(hipMalloc(&e->win_ranks, (size_t)kSmallRank * 4));
+  CREATE_CHK(hipMalloc(&e->upd_wg, 65536 * 4));
+  CREATE_CHK(hipMemsetAsync(e->upd_wg, 0, 65536 * 4, e->stream));
+  CREATE_CHK(hipMalloc(&t.dclaim, (size_t)t.num_bucket * 4));
+  CREATE_CHK(hipMemsetAsync(t.dclaim, 0xFF, (size_t)t.num_bucket * 4, e->stream));
   e->dwords = (e->dwords + kGroupWords - 1) / kGroupWords * kGroupWords;
   const uint32_t dsum_words = (e->dwords / kGroupWords + 31) / 32;
   CREATE_CHK(hipMalloc(&e->dbitmap, (size_t)e->dwords * 4));
   CREATE_CHK(hipMalloc(&e->dsummary, (size_t)dsum_words * 4));
   CREATE_CHK(hipMalloc(&e->dprefix, (size_t)e->dwords * 4));
   CREATE_CHK(hipMalloc(&e->slowdel, (size_t)kSlowDelCap * sizeof(SlowDelete)));
-  // candidate sets: twice as many slots as the pool has blocks (more distinct requests than that
-  // cannot be served anyway), at least 2^16
-  uint32_t cand_slots = 1u << 16;
-  while (cand_slots < 2u * (uint32_t)t.num_block) cand_slots <<= 1;
   CREATE_CHK(hipMalloc(&e->cand_count, 2 * kCandSegs * kCandCountStride * 4));
   CREATE_CHK(hipMemsetAsync(e->cand_count, 0, 2 * kCandSegs * kCandCountStride * 4, e->stream));
-  for (int i = 0; i < 2; ++i) {
-    CandSet& c = e->cand[i];
-    c.slot_mask = cand_slots - 1;
-    c.seg_cap = cand_slots / kCandSegs;
-    c.count = e->cand_count + i * kCandSegs * kCandCountStride;
-    CREATE_CHK(hipMalloc(&c.keys, (size_t)cand_slots * 8));
-    CREATE_CHK(hipMalloc(&c.ranks, (size_t)cand_slots * 4));
-    CREATE_CHK(hipMalloc(&c.list, (size_t)cand_slots * sizeof(uint4)));
-    hipLaunchKernelGGL(k_init_cand, dim3((cand_slots + 255) / 256), dim3(256), 0, e->stream, c.keys,
-                       c.ranks, cand_slots);
-  }
+  for (int i = 0; i < 2; ++i) e->cand[i].count = e->cand_count + i * kCandSegs * kCandCountStride;
   // voxel memory starts zeroed (defined value for the reference's uninitialised rgb)
   CREATE_CHK(hipMemsetAsync(e->pool.rgbw, 0, nvox * 4, e->stream));
   CREATE_CHK(hipMemsetAsync(e->pool.tsdf, 0, nvox * 4, e->stream));
@@ -620,6 +641,7 @@ int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, c
 
 int ratsdf_synchronize(ratsdf_engine* e) {
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   return e->sticky();
 }
 
@@ -648,6 +670,7 @@ int ratsdf_profile_read(ratsdf_engine* e, double* ms, int64_t* launches) {
 
 int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out) {
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int32_t nf = 0;
   HIPCHK(hipMemcpyAsync(&nf, &e->ctl->num_free, 4, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -657,6 +680,7 @@ int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out) {
 
 int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   HIPCHK(hipMemcpyAsync(out, e->d_stats, sizeof(*out), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return RATSDF_OK;
@@ -731,21 +755,17 @@ extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
   HIPCHK(hipMemcpyAsync(tot, e->ctl->totals, sizeof(tot), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   const double n = tot[0] ? (double)tot[0] : 1.0;
-  fprintf(stderr, "[stamps] frames=%llu  carve phases (cycles/frame):", tot[0]);
-  for (int i = 1; i <= 5; ++i) fprintf(stderr, " %d:%.0f", i, (double)(t[i] - t[i - 1]) / n);
-  fprintf(stderr, "\n[stamps] rank phases: read_n:%.0f mark:%.0f scan:%.0f tail:%.0f\n",
-          (double)(t[12] - t[8]) / n, (double)(t[9] - t[12]) / n, (double)(t[10] - t[9]) / n,
-          (double)(t[11] - t[10]) / n);
-  fprintf(stderr, "[stamps] work lists: mean max-list %.1f vs mean per-list %.1f blocks (imbalance %.2fx)\n",
-          (double)t[22] / n, (double)t[23] / n / 8.0, (double)t[22] * 8.0 / (double)(t[23] ? t[23] : 1));
-  fprintf(stderr, "[stamps] k_carve: %.0f shader cycles in %.0f wall ticks (100 MHz) -> %.2f GHz\n",
-          (double)(t[5] - t[0]) / n, (double)(t[21] - t[20]) / n,
-          (double)(t[5] - t[0]) / (double)(t[21] - t[20]) * 0.1);
+  fprintf(stderr, "[stamps] frames=%llu  serial role (shader cycles/frame): loads:%.0f claims+barrier:%.0f lists:%.0f ranks:%.0f tail:%.0f | deletes %.1f winners %.1f requests %.1f per frame\n",
+          tot[0], (double)(t[9] - t[8]) / n, (double)(t[10] - t[9]) / n, (double)(t[11] - t[10]) / n,
+          (double)(t[12] - t[11]) / n, (double)(t[13] - t[12]) / n, (double)t[16] / n, (double)t[17] / n,
+          (double)t[18] / n);
+  fprintf(stderr, "[stamps] ranks phase, first pass (cold code) %.0f cycles of the two\n", (double)t[19] / n);
   return RATSDF_OK;
 }
 
 int ratsdf_totals(ratsdf_engine* e, int64_t* out5, int reset) {
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   unsigned long long t[5] = {0, 0, 0, 0, 0};
   HIPCHK(hipMemcpyAsync(t, e->ctl->totals, sizeof(t), hipMemcpyDeviceToHost, e->stream));
   if (reset) HIPCHK(hipMemsetAsync(e->ctl->totals, 0, sizeof(t), e->stream));
@@ -798,6 +818,7 @@ static inline int16_t host_f2s(float f) {  // static_cast<short>, BoundingCube::
 
 int ratsdf_query(ratsdf_engine* e, const ratsdf_bounds* b, ratsdf_voxel_tsdf** out, size_t* n) {
   if (!e || !b || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   const float scale = (float)(1. / e->vs);  // volumn.Scale<short>(1. / voxel_size_), voxel_tsdf.cu:534
   GridBounds gb{host_f2s(b->xmin * scale), host_f2s(b->xmax * scale), host_f2s(b->ymin * scale),
                 host_f2s(b->ymax * scale), host_f2s(b->zmin * scale), host_f2s(b->zmax * scale)};
@@ -808,6 +829,7 @@ int ratsdf_query(ratsdf_engine* e, const ratsdf_bounds* b, ratsdf_voxel_tsdf** o
 
 int ratsdf_gather_valid(ratsdf_engine* e, ratsdf_voxel_tsdf** out, size_t* n) {
   if (!e || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
   if (st != RATSDF_OK) return st;
   return download_selected(e, false, (void**)out, n);
@@ -815,6 +837,7 @@ int ratsdf_gather_valid(ratsdf_engine* e, ratsdf_voxel_tsdf** out, size_t* n) {
 
 int ratsdf_gather_valid_semantic(ratsdf_engine* e, ratsdf_voxel_segm** out, size_t* n) {
   if (!e || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
   if (st != RATSDF_OK) return st;
   return download_selected(e, true, (void**)out, n);
@@ -822,6 +845,7 @@ int ratsdf_gather_valid_semantic(ratsdf_engine* e, ratsdf_voxel_segm** out, size
 
 int ratsdf_download_all(ratsdf_engine* e, const char* path) {
   if (!e || !path) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   ratsdf_voxel_segm* buf = nullptr;
   size_t n = 0;
   const int st = ratsdf_gather_valid_semantic(e, &buf, &n);
@@ -846,6 +870,7 @@ int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int heig
                           const ratsdf_pose* T, float max_depth, void* d_rgba, void* d_normal) {
   if (!e || !K || !T || height <= 0 || width <= 0 || !(max_depth > 0))
     return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   FrameParams P = e->base_params();
   P.T = Se3{Quat{T->qx, T->qy, T->qz, T->qw}, V3{T->tx, T->ty, T->tz}};
   P.Ti = se3_inverse(P.T);                      // voxel_tsdf.cu:892 cam_T_world.Inverse()
@@ -899,6 +924,7 @@ int ratsdf_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_verti
                              int32_t** indices, size_t* n_triangles, float** vertex_prob) {
   if (!e || !vertices || !n_vertices || !indices || !n_triangles || !vertex_prob)
     return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);  // check_valid_kernel + GatherBlock
   if (st != RATSDF_OK) return st;
   uint32_t nb = 0;
@@ -1001,6 +1027,7 @@ int ratsdf_download_all_mesh(ratsdf_engine* e, const char* vp, const char* ip, c
 int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t capacity,
                                    void* d_count) {
   if (!e || !d_blocks || capacity < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
   if (st != RATSDF_OK) return st;
   hipLaunchKernelGGL(k_export_entries, dim3(256), dim3(256), 0, e->stream, e->vis, &e->ctl->n_sel,
@@ -1020,6 +1047,7 @@ static int upload_s3(ratsdf_engine* e, const int16_t* src, int32_t n, int16_t** 
 
 int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   if (!e || (!bp && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return e->sticky();
   int st = e->ensure_image(0, (size_t)n);
   if (st != RATSDF_OK) return st;
@@ -1027,14 +1055,15 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   st = upload_s3(e, bp, n, &d);
   if (st != RATSDF_OK) return st;
   FrameParams P = e->base_params();
-  HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
+  const uint32_t par = e->parity;  // an allocation pass of its own in the next frame's counters
   hipLaunchKernelGGL(k_alloc_list, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->tab, P, d, n,
-                     e->req, e->req_cap, e->slow, kSlowCap, e->ctl);
-  st = e->alloc_rank((uint32_t)n);
+                     e->req, e->req_cap, e->slow, kSlowCap, e->ctl, par);
+  st = e->alloc_rank((uint32_t)n, par);
   hipLaunchKernelGGL(k_commit_only, dim3(256), dim3(256), 0, e->stream, e->tab, e->pool, e->req,
-                     e->req_cap, e->req_k, e->ctl);
-  // frames expect a clean control block (normally left behind by k_carve)
-  HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
+                     e->req_cap, e->req_k, e->win_ranks, e->ctl, par);
+  // no deletes in this pass; k_settle just zeroes the counters again
+  hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, e->stream, e->tab, e->pool, e->carve_bufs(),
+                     e->ctl, par, (ratsdf_frame_stats*)nullptr);
   const int st2 = e->sticky();
   (void)hipFree(d);
   return st != RATSDF_OK ? st : st2;
@@ -1042,6 +1071,7 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
 
 int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   if (!e || (!bp && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   // keep the first occurrence of every position (a repeated Delete is a no-op in list order)
   std::vector<int16_t> uniq;
   uniq.reserve((size_t)n * 3);
@@ -1057,10 +1087,11 @@ int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   int16_t* d = nullptr;
   int st = upload_s3(e, uniq.data(), m, &d);
   if (st != RATSDF_OK) return st;
-  HIPCHK(hipMemsetAsync(e->ctl, 0, kCtlFrameBytes, e->stream));
-  hipLaunchKernelGGL(k_lookup_list, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->tab, d, m,
-                     e->vis, e->carve_flag, e->ctl);
-  st = e->carve_tail(false);
+  const uint32_t par = e->parity;
+  hipLaunchKernelGGL(k_delete_list, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->tab, d, m,
+                     e->carve_bufs(), e->ctl, par);
+  hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, e->stream, e->tab, e->pool, e->carve_bufs(),
+                     e->ctl, par, (ratsdf_frame_stats*)nullptr);
   const int st2 = e->sticky();
   (void)hipFree(d);
   return st != RATSDF_OK ? st : st2;
@@ -1069,6 +1100,7 @@ int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
 int ratsdf_test_retrieve(ratsdf_engine* e, const int16_t* pts, int32_t n, ratsdf_rgbw* rgbw,
                          float* tsdf, float* prob, ratsdf_block* blocks) {
   if (!e || (!pts && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return RATSDF_OK;
   int16_t* d = nullptr;
   int st = upload_s3(e, pts, n, &d);
@@ -1096,6 +1128,7 @@ int ratsdf_test_retrieve(ratsdf_engine* e, const int16_t* pts, int32_t n, ratsdf
 int ratsdf_test_assign_rgbw(ratsdf_engine* e, const int16_t* pts, const ratsdf_rgbw* vals,
                             int32_t n) {
   if (!e || ((!pts || !vals) && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return RATSDF_OK;
   int16_t* d = nullptr;
   int st = upload_s3(e, pts, n, &d);
@@ -1114,6 +1147,7 @@ int ratsdf_test_assign_rgbw(ratsdf_engine* e, const int16_t* pts, const ratsdf_r
 int ratsdf_dump_directory(ratsdf_engine* e, int32_t** entry_index, ratsdf_block** blocks,
                           size_t* n) {
   if (!e || !entry_index || !blocks || !n) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
   if (st != RATSDF_OK) return st;
   uint32_t cnt = 0;
@@ -1143,6 +1177,7 @@ int ratsdf_dump_directory(ratsdf_engine* e, int32_t** entry_index, ratsdf_block*
 int ratsdf_dump_voxels(ratsdf_engine* e, const int32_t* pool_idx, int32_t n, float* tsdf,
                        ratsdf_rgbw* rgbw, float* prob) {
   if (!e || (!pool_idx && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return RATSDF_OK;
   for (int i = 0; i < n; ++i)
     if (pool_idx[i] < 0 || pool_idx[i] >= e->tab.num_block) return RATSDF_ERR_BAD_ARGUMENT;
@@ -1165,6 +1200,7 @@ int ratsdf_dump_voxels(ratsdf_engine* e, const int32_t* pool_idx, int32_t n, flo
 
 int ratsdf_dump_heap(ratsdf_engine* e, int32_t* num_free, int32_t* heap) {
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (num_free)
     HIPCHK(hipMemcpyAsync(num_free, &e->ctl->num_free, 4, hipMemcpyDeviceToHost, e->stream));
   if (heap)
