@@ -1,0 +1,122 @@
+"""Frames issued back to back (no query in between) take the pipelined path of the HIP engine: the
+carve pass of frame f is finished inside frame f+1's launches and, for batches, the candidate pass of
+frame f+1 rides in frame f's launches.  Results must be those of the frame-at-a-time oracle:
+directory, free list and pool indices bit-exact, voxels within tolerance, totals equal."""
+import numpy as np
+import pytest
+import torch
+
+from parity import assert_maps_equal, assert_stats_equal
+from ratsdf import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def device_frames(frames, semantic=True):
+    dev = torch.device("cuda", 0)
+    out = []
+    for f in frames:
+        t = dict(rgb=torch.from_numpy(f["rgb"]).to(dev), depth=torch.from_numpy(f["depth"]).to(dev))
+        if semantic and f["ht"] is not None:
+            t["ht"] = torch.from_numpy(f["ht"]).to(dev)
+            t["lt"] = torch.from_numpy(f["lt"]).to(dev)
+        out.append(t)
+    torch.cuda.synchronize()
+    return out
+
+
+def make_batch(gpu, frames, dev, lo, hi, md):
+    h, w = frames[0]["depth"].shape
+    sem = "ht" in dev[0]
+    ptr = lambda key: [dev[i][key].data_ptr() for i in range(lo, hi)]
+    return gpu.make_batch(ptr("rgb"), ptr("depth"), ptr("ht") if sem else None,
+                          ptr("lt") if sem else None, h, w, md,
+                          [frames[i]["intrinsics"] for i in range(lo, hi)],
+                          [frames[i]["pose"] for i in range(lo, hi)])
+
+
+def oracle_run(cpu, frames, md):
+    for f in frames:
+        cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+
+
+def check_totals(gpu, cpu):
+    tg, tc = gpu.totals(), cpu.totals()
+    assert tg == tc, (tg, tc)
+
+
+@pytest.mark.parametrize("chunks", [(12,), (1, 2, 3, 6), (5, 7)])
+def test_batches_match_oracle(chunks, make_engine, make_oracle):
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    frames = synthetic.stream("room", sum(chunks), scale=0.25, noise=True, holes=True)
+    dev = device_frames(frames)
+    lo = 0
+    for n in chunks:  # a query between batches, none inside
+        gpu.integrate_device_batch(make_batch(gpu, frames, dev, lo, lo + n, md))
+        oracle_run(cpu, frames[lo:lo + n], md)
+        lo += n
+        assert_maps_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+    assert_stats_equal(gpu, cpu)
+
+
+def test_single_frame_calls_without_queries(make_engine, make_oracle):
+    """ratsdf_integrate_device frame after frame: no look-ahead, but the deferred carve tail."""
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    frames = synthetic.stream("sphere", 10, scale=0.25)
+    dev = device_frames(frames)
+    h, w = frames[0]["depth"].shape
+    for f, d in zip(frames, dev):
+        gpu.integrate_device(d["rgb"].data_ptr(), d["depth"].data_ptr(), d["ht"].data_ptr(),
+                             d["lt"].data_ptr(), h, w, md, f["intrinsics"], f["pose"])
+    oracle_run(cpu, frames, md)
+    assert_maps_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+
+
+@pytest.mark.parametrize("bucket_bits", [9, 11])
+def test_chained_buckets_in_the_pipeline(bucket_bits, make_engine, make_oracle):
+    """A tiny directory: most buckets are full or chained, so allocation goes through the resolver
+    and the carve pass through head / chain deletes (resolved by the next frame's first launch)."""
+    vs, md = 0.02, 4.0
+    kw = dict(bucket_bits=bucket_bits, block_bits=13)
+    gpu, cpu = make_engine(vs, 6 * vs, **kw), make_oracle(vs, 6 * vs, **kw)
+    frames = synthetic.stream("room", 16, scale=0.25, noise=True)
+    frames = frames + frames[::-1][:8]
+    dev = device_frames(frames)
+    slow_seen = 0
+    lo = 0
+    for n in (8, 8, 8):
+        gpu.integrate_device_batch(make_batch(gpu, frames, dev, lo, lo + n, md))
+        oracle_run(cpu, frames[lo:lo + n], md)
+        lo += n
+        assert_maps_equal(gpu, cpu)
+        assert_stats_equal(gpu, cpu)
+        slow_seen += cpu.last_frame_stats()["slow_requests"]
+    check_totals(gpu, cpu)
+    assert slow_seen > 0  # the configuration really exercises the chained-bucket paths
+
+
+def test_no_semantics_batch(make_engine, make_oracle):
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    frames = synthetic.stream("wall", 6, scale=0.25, semantic=False)
+    dev = device_frames(frames, semantic=False)
+    gpu.integrate_device_batch(make_batch(gpu, frames, dev, 0, 6, md))
+    oracle_run(cpu, frames, md)
+    assert_maps_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+
+
+def test_full_size_batch_640x480(make_engine, make_oracle):
+    """BASELINE-sized frames through the batched path (the path bench.py times)."""
+    vs, md = 0.005, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+    frames = synthetic.stream("room", 6, scale=1.0, noise=True, holes=True)
+    dev = device_frames(frames)
+    gpu.integrate_device_batch(make_batch(gpu, frames, dev, 0, 6, md))
+    oracle_run(cpu, frames, md)
+    assert_maps_equal(gpu, cpu)
+    check_totals(gpu, cpu)
