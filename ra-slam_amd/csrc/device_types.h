@@ -70,13 +70,16 @@ struct FrameCtl {
   uint32_t n_slow_del;     // head / chain deletes waiting for carve_resolve_slow
   uint32_t pending;        // this frame's carve pass has not been finalised yet
   uint32_t slow_resolved;  // carve_resolve_slow has run for this frame
-  uint32_t n_list[8];      // visible blocks per XCD list (image-tile buckets)
   uint32_t n_winlist;      // > 0: the winners' raster ranks are listed in win_ranks[0, n_winlist) and
                            // k_integrate derives each winner's order from the list (few winners);
                            // 0: req_k holds the order (many winners, rank bitmap path)
-  uint32_t pad[15];
+  uint32_t pad[23];
+  // visible blocks per XCD list (image-tile buckets): list l counts in n_list[l * kListStride], one
+  // 128-byte line per counter (they take ~2000 atomics per frame; sharing a line serialises them)
+  uint32_t n_list[8 * 32];
 };
-static_assert(sizeof(FrameCtl) == 128, "frame counters are one 128-byte line");
+constexpr int kListStride = 32;
+static_assert(sizeof(FrameCtl) == 128 + 1024, "frame counters: one line + one line per list counter");
 
 // Device-resident control block.
 struct Ctl {

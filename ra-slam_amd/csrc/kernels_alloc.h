@@ -27,6 +27,14 @@
 namespace ratsdf {
 
 __device__ inline void set_error(Ctl* ctl, uint32_t code) { atomicCAS(&ctl->error, 0u, code); }
+// one thread: the words of a FrameCtl that are in use
+__device__ inline void zero_frame_ctl(FrameCtl* F) {
+  uint32_t* z = reinterpret_cast<uint32_t*>(F);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) z[i] = 0;
+#pragma unroll
+  for (int l = 0; l < kNumLists; ++l) F->n_list[l * kListStride] = 0;
+}
 __device__ inline uint32_t ld_agent_u32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

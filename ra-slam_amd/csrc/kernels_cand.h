@@ -271,14 +271,18 @@ __device__ inline bool wave_block_visible_full(bool want, int bx, int by, int bz
 // takes slot list `seg` of the frame's candidate set; one lane per candidate looks the block up,
 // absent blocks take the full-frustum test and file their allocation request with the rank the set
 // recorded.  Every slot read is emptied again.
+// `gate()` makes sure the previous frame's queued deletes have happened before the directory is read
+// (carve_resolve_gate); the list itself does not depend on it, so its loads are issued first.
+template <typename Gate>
 __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P, const CandSet& cs,
                                          uint32_t seg, Request* req, uint32_t req_cap,
                                          SlowRequest* slow, uint32_t slow_cap, Ctl* ctl,
-                                         FrameCtl* F) {
+                                         FrameCtl* F, Gate gate) {
   const uint4* list = cs.list + (size_t)seg * cs.seg_cap;
   // the count and the first batch of items are fetched together (list memory is always readable)
   uint4 item = list[threadIdx.x < cs.seg_cap ? threadIdx.x : 0];
   uint32_t n = cs.count[seg * kCandCountStride];
+  (void)gate();
   if (n > cs.seg_cap) n = cs.seg_cap;
   __syncthreads();
   if (threadIdx.x == 0) cs.count[seg * kCandCountStride] = 0;

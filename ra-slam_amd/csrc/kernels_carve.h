@@ -148,9 +148,10 @@ __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb,
 // Directory readers of the next launch: make sure the queued head / chain deletes of the previous
 // frame have happened.  Workgroup 0 of the launch does them; the others wait (the launch is small
 // enough to be fully resident and workgroup 0 is dispatched first).  Uniform per workgroup.
-__device__ inline void carve_resolve_gate(const Table& tab, const CarveBufs& cb, Ctl* ctl,
+// Returns true when there was something to wait for (data read before the call may be stale then).
+__device__ inline bool carve_resolve_gate(const Table& tab, const CarveBufs& cb, Ctl* ctl,
                                           FrameCtl* Fprev) {
-  if (Fprev->n_slow_del == 0) return;  // the steady state
+  if (Fprev->n_slow_del == 0) return false;  // the steady state
   if (blockIdx.x == 0) {
     if (ld_agent(&Fprev->slow_resolved) == 0) carve_resolve_slow(tab, cb, ctl, Fprev);  // uniform
     __threadfence();
@@ -165,6 +166,7 @@ __device__ inline void carve_resolve_gate(const Table& tab, const CarveBufs& cb,
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
+  return true;
 }
 
 // Pool releases of a finished frame with few deletes (the steady state), spread over kReleaseWGs
@@ -251,7 +253,7 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
   const uint32_t n_win = F->n_win, n_slow_req = F->n_slow;
   uint32_t nv = n_win;
 #pragma unroll
-  for (int l = 0; l < kNumLists; ++l) nv += F->n_list[l];
+  for (int l = 0; l < kNumLists; ++l) nv += F->n_list[l * kListStride];
   // voxels updated: per-workgroup counters of k_integrate (consumed here)
   uint32_t upd_part = 0;
   for (uint32_t i = tid; i < cb.upd_n; i += nt) {
@@ -325,8 +327,7 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
       ctl->totals[4] += n_del;
     }
     // counters ready for the frame after next
-    uint32_t* z = reinterpret_cast<uint32_t*>(F);
-    for (int i = 0; i < (int)(sizeof(FrameCtl) / 4); ++i) z[i] = 0;
+    zero_frame_ctl(F);
   }
   __syncthreads();
   return n_del;

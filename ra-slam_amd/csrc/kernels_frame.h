@@ -29,14 +29,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fr
     cand_pixels_role(ahead, blockIdx.x - n_dir_wg, ctl);
     return;
   }
-  carve_resolve_gate(tab, cb, ctl, &ctl->fr[par ^ 1u]);
   FrameCtl* F = &ctl->fr[par];
+  FrameCtl* Fp = &ctl->fr[par ^ 1u];
+  auto gate = [&]() { return carve_resolve_gate(tab, cb, ctl, Fp); };  // uniform per workgroup
   if (blockIdx.x >= n_vis_wg + kCandSegs) {
-    carve_release_role(pool, cb, ctl, &ctl->fr[par ^ 1u], blockIdx.x - n_vis_wg - kCandSegs);
+    if (P.debug == 12) return;  // diagnostic ablations 3 / 11 / 12: skip one role
+    (void)gate();
+    carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - kCandSegs);
   } else if (blockIdx.x >= n_vis_wg) {
-    cand_consume_role(tab, P, cand, blockIdx.x - n_vis_wg, req, req_cap, slow, slow_cap, ctl, F);
-  } else if (P.debug != 3) {
-    visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F);
+    if (P.debug == 11) return;
+    cand_consume_role(tab, P, cand, blockIdx.x - n_vis_wg, req, req_cap, slow, slow_cap, ctl, F, gate);
+  } else {
+    if (P.debug == 3) return;
+    visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F, gate);
   }
 }
 
@@ -87,7 +92,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
   const uint32_t p_win = Fp->n_win, p_slow = Fp->n_slow;
   uint32_t nv = p_win;
 #pragma unroll
-  for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l];
+  for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l * kListStride];
   const uint32_t n_slow = F->n_slow;
   uint32_t n = F->n_req;
   uint32_t u[UPT];
@@ -189,8 +194,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
         ctl->totals[3] = tot[3] + p_win;
         ctl->totals[4] = tot[4] + n_del;
       }
-      uint32_t* z = reinterpret_cast<uint32_t*>(Fp);  // counters ready for the frame after next
-      for (int i = 0; i < (int)(sizeof(FrameCtl) / 4); ++i) z[i] = 0;
+      zero_frame_ctl(Fp);  // counters ready for the frame after next
     }
     uint32_t take = total;
     if ((int64_t)total > (int64_t)nf) {  // voxel_mem.cu:39 assert(idx >= 1)

@@ -68,6 +68,12 @@ struct VecIO<2> {
   }
 };
 
+template <>
+struct VecIO<1> {
+  static __device__ inline void load(const uint32_t* p, uint32_t (&v)[1]) { v[0] = p[0]; }
+  static __device__ inline void store(uint32_t* p, const uint32_t (&v)[1]) { p[0] = v[0]; }
+};
+
 // Update of one voxel block by the waves that own it (WPB waves, `part` = which one).  Returns the
 // number of voxels this lane updated and the lane's min |tsdf| after the update.
 #ifdef RATSDF_STAMPS
@@ -231,14 +237,14 @@ __device__ inline void finish_block(const Table& tab, const CarveBufs& cb, Ctl* 
 // CU (MI355X_MICROARCH.md, residency formula), which pushed the last 20 % of the blocks into a
 // second round of waves.
 template <int VPL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_integrate(
+__global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgpr(80))) void k_integrate(
     Table tab, Pool pool, FrameParams P, const VisItem* vis, uint32_t seg_cap, const Request* req,
     uint32_t req_cap, const uint32_t* req_k, const uint32_t* win_ranks, const float4* texA,
     const uint2* texB, CarveBufs cb, Ctl* ctl, uint32_t par) {
   constexpr int WPB = 8 / VPL;  // waves per voxel block
-  constexpr int BPW = 4 / WPB;  // voxel blocks per 256-thread workgroup
-  __shared__ float smin[4];
-  __shared__ uint32_t supd[4];
+  constexpr int BPW = VPL == 1 ? 1 : 4 / WPB;  // voxel blocks per workgroup (256 threads; 512 for VPL 1)
+  __shared__ float smin[8];
+  __shared__ uint32_t supd[8];
   FrameCtl* F = &ctl->fr[par];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wv = threadIdx.x >> 6;
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_in
   // shorter; it is only used when in range), which takes one memory round trip off every wave
   const uint32_t j0 = wg_in_list * BPW + blk_in_wg;
   const VisItem first = my_vis[j0 < seg_cap ? j0 : 0];
-  uint32_t n_mine = F->n_list[list];
+  uint32_t n_mine = F->n_list[list * kListStride];
   if (n_mine > seg_cap) n_mine = seg_cap;
   uint32_t n_req = F->n_req;
   if (n_req > req_cap) n_req = req_cap;

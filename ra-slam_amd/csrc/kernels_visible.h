@@ -76,68 +76,88 @@ __device__ inline void select_flags_role(const Table& tab, const FrameParams& P,
 // visible blocks to the frame's 8 work lists (one per XCD, see block_list_of) with one atomicAdd per
 // non-empty list.  The lists are unordered; nothing in a frame depends on their order (blocks are
 // independent; the carve pass orders its pool releases by hash entry).
+// `gate()` makes sure the previous frame's queued deletes have happened (carve_resolve_gate); the
+// first load is issued before it so that the two round trips overlap.
+// The set bits of the workgroup's occupancy words are first compacted into an LDS list and then
+// handed out one per lane: a lane that walks the bits of its own word serially pays one dependent
+// memory round trip per block, and the launch waits for the unluckiest lane of 65 536.
+constexpr int kVisWordsPerLane = 1;
+constexpr uint32_t kVisListCap = 2048;  // entries per round (more occupied entries: more rounds)
+
+template <typename Gate>
 __device__ inline void visible_append_role(const Table& tab, const FrameParams& P, uint32_t wg,
-                                           VisItem* vis, uint32_t seg_cap, Ctl* ctl, FrameCtl* F) {
-  __shared__ uint32_t cnt[kNumLists], base[kNumLists], cnt2[kNumLists];
-#ifdef RATSDF_STAMPS
-  unsigned long long* ws = (ctl->debug_buf && P.debug == 10) ? ctl->debug_buf + (size_t)((wg * 4 + (threadIdx.x >> 6)) & 16383) * 8 : nullptr;
-  if (ws && (threadIdx.x & 63) == 0) { ws[0] = (unsigned long long)clock64(); ws[5] = wall_clock64(); }
-#define VSTAMP(i) do { if (ws && (threadIdx.x & 63) == 0) ws[i] = (unsigned long long)clock64(); } while (0)
-#else
-#define VSTAMP(i) do { } while (0)
-#endif
+                                           VisItem* vis, uint32_t seg_cap, Ctl* ctl, FrameCtl* F,
+                                           Gate gate) {
+  __shared__ uint32_t list[kVisListCap];
+  __shared__ uint32_t n_items, more, cnt[kNumLists], base[kNumLists], cnt2[kNumLists];
   const uint32_t nwords = tab.num_entry >> 6;
   const uint32_t w = wg * kVisWG + threadIdx.x;
-  if (threadIdx.x < kNumLists) {
-    cnt[threadIdx.x] = 0;
-    cnt2[threadIdx.x] = 0;
-  }
-  __syncthreads();
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
   unsigned long long occ = w < nwords ? tab.occ[w] : 0ull;
-  VSTAMP(1);
-  unsigned long long sel = 0, l0 = 0, l1 = 0, l2 = 0;  // selection mask + 3 bit planes of the list id
-  while (occ) {
-    const int b = __ffsll((long long)occ) - 1;
-    occ &= occ - 1;
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(tab.entries + ((size_t)w * 64 + b));
-    const uint32_t w0 = p[0], w1 = p[1];
-    const int bx = (int16_t)(w0 & 0xFFFFu), by = (int16_t)(w0 >> 16), bz = (int16_t)(w1 & 0xFFFFu);
-    if (block_visible<false>(bx, by, bz, P)) {                             // voxel_tsdf.cu:98-109
-      const int l = block_list_of(bx, by, bz, P);
-      sel |= 1ull << b;
-      l0 |= (unsigned long long)(l & 1) << b;
-      l1 |= (unsigned long long)((l >> 1) & 1) << b;
-      l2 |= (unsigned long long)((l >> 2) & 1) << b;
-      atomicAdd(&cnt[l], 1u);
+  if (gate())  // rare: the directory changed after the load above was issued
+    occ = w < nwords ? __hip_atomic_load(&tab.occ[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  for (;;) {  // one round unless the workgroup's 16 384 entries hold more than kVisListCap blocks
+    if (tid < kNumLists) {
+      cnt[tid] = 0;
+      cnt2[tid] = 0;
     }
-  }
-  VSTAMP(2);
-  __syncthreads();
-  if (threadIdx.x < kNumLists) {
-    const uint32_t c = cnt[threadIdx.x];
-    base[threadIdx.x] = c ? atomicAdd(&F->n_list[threadIdx.x], c) : 0u;
-  }
-  __syncthreads();
-  VSTAMP(3);
-  while (sel) {
-    const int b = __ffsll((long long)sel) - 1;
-    sel &= sel - 1;
-    const int l = (int)((l0 >> b) & 1) | ((int)((l1 >> b) & 1) << 1) | ((int)((l2 >> b) & 1) << 2);
-    const uint32_t pos = base[l] + atomicAdd(&cnt2[l], 1u);
-    if (pos < seg_cap) {
-      const uint32_t e = w * 64 + b;
+    if (tid == 0) {
+      n_items = 0;
+      more = 0;
+    }
+    __syncthreads();
+    if (occ) {
+      uint32_t at = atomicAdd(&n_items, (uint32_t)__popcll(occ));
+      while (occ && at < kVisListCap) {
+        const int b = __ffsll((long long)occ) - 1;
+        occ &= occ - 1;
+        list[at++] = w * 64 + (uint32_t)b;
+      }
+      if (occ) more = 1;
+    }
+    __syncthreads();
+    const uint32_t n = n_items < kVisListCap ? n_items : kVisListCap;
+    const bool again = more != 0;
+    // one listed entry per lane: load, test (any corner in view, voxel_tsdf.cu:98-109), pick a list
+    EntryWords first{0, 0, -1};
+    for (uint32_t i = tid; i < n; i += nt) {
+      const uint32_t e = list[i];
       const EntryWords ew = load_entry(tab.entries, e);
-      uint4 v;
-      v.x = ew.w0;
-      v.y = ew.w1;
-      v.z = (uint32_t)ew.idx;
-      v.w = e;
-      reinterpret_cast<uint4*>(vis)[(size_t)l * seg_cap + pos] = v;
+      if (i == tid) first = ew;
+      const int bx = (int16_t)(ew.w0 & 0xFFFFu), by = (int16_t)(ew.w0 >> 16),
+                bz = (int16_t)(ew.w1 & 0xFFFFu);
+      uint32_t tag = 0;
+      if (block_visible<false>(bx, by, bz, P)) {
+        const int l = block_list_of(bx, by, bz, P);
+        atomicAdd(&cnt[l], 1u);
+        tag = 0x10000000u | ((uint32_t)l << 29);
+      }
+      list[i] = e | tag;  // entry indices use 27 bits at most (bucket_bits <= 26)
     }
+    __syncthreads();
+    if (tid < kNumLists) {
+      const uint32_t c = cnt[tid];
+      base[tid] = c ? atomicAdd(&F->n_list[tid * kListStride], c) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nt) {
+      const uint32_t t = list[i];
+      if (!(t & 0x10000000u)) continue;
+      const uint32_t e = t & 0x0FFFFFFFu, l = t >> 29;
+      const uint32_t pos = base[l] + atomicAdd(&cnt2[l], 1u);
+      if (pos < seg_cap) {
+        const EntryWords ew = i == tid ? first : load_entry(tab.entries, e);
+        uint4 v;
+        v.x = ew.w0;
+        v.y = ew.w1;
+        v.z = (uint32_t)ew.idx;
+        v.w = e;
+        reinterpret_cast<uint4*>(vis)[(size_t)l * seg_cap + pos] = v;
+      }
+    }
+    if (!again) break;  // uniform
+    __syncthreads();
   }
-#ifdef RATSDF_STAMPS
-  if (ws && (threadIdx.x & 63) == 0) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }
-#endif
 }
 
 template <int Mode>

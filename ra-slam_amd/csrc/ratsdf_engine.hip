@@ -376,8 +376,9 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
   const unsigned extra_a = (ahead_a.n_tiles + 3) / 4;
-  hipLaunchKernelGGL(k_front, dim3(nwg + kCandSegs + kReleaseWGs + extra_a), dim3(256), 0, stream, tab,
-                     P, nwg, cand[par], req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(),
+  const unsigned n_vis_wg = (nwg + kVisWordsPerLane - 1) / kVisWordsPerLane;
+  hipLaunchKernelGGL(k_front, dim3(n_vis_wg + kCandSegs + kReleaseWGs + extra_a), dim3(256), 0, stream,
+                     tab, P, n_vis_wg, cand[par], req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(),
                      ctl, (uint32_t)par, ahead_a);
   st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr);
   if (st != RATSDF_OK) return st;
@@ -398,6 +399,11 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   }
   const CarveBufs cb = carve_bufs();
   switch (vpl) {
+    case 1:
+      hipLaunchKernelGGL(k_integrate<1>, dim3(integrate_grid), dim3(512), 0, stream, tab, pool, P,
+                         vis, seg_cap, req, req_cap, req_k, win_ranks, texA[par], texB[par], cb, ctl,
+                         (uint32_t)par);
+      break;
     case 8:
       hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
                          vis, seg_cap, req, req_cap, req_k, win_ranks, texA[par], texB[par], cb, ctl,
@@ -469,7 +475,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   e->S = (int)ceilf(2.f * e->trunc / e->vs / RATSDF_BLOCK_LEN) + 2;
   if (const char* v = getenv("RATSDF_VPL")) {
     const int x = atoi(v);
-    if (x == 2 || x == 4 || x == 8) e->vpl = x;
+    if (x == 1 || x == 2 || x == 4 || x == 8) e->vpl = x;
   }
   if (const char* v = getenv("RATSDF_DEBUG")) e->debug = atoi(v);
   if (const char* v = getenv("RATSDF_CAND_SPLIT")) {
