@@ -189,8 +189,8 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   }
 }
 
-__device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl) {
-  __shared__ CandLds L;
+// `L`: LDS of the workgroup (the caller owns it so that a kernel with several roles can share one buffer)
+__device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl, CandLds& L) {
   for (uint32_t i = threadIdx.x; i < kCandLdsSlots; i += blockDim.x) {
     L.keys[i] = kCandEmpty;
     L.ranks[i] = kInf;
@@ -312,7 +312,8 @@ __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P,
 // stand-alone candidate pass (single frames, first frame of a batch)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cand(CandJob job,
                                                                                    Ctl* ctl) {
-  cand_pixels_role(job, blockIdx.x, ctl);
+  __shared__ CandLds L;
+  cand_pixels_role(job, blockIdx.x, ctl, L);
 }
 
 }  // namespace ratsdf

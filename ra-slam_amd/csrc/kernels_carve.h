@@ -30,14 +30,19 @@
 namespace ratsdf {
 
 constexpr uint32_t kSmallCarve = 2048;
+constexpr uint32_t kUpdCounters = 1024;  // voxels-updated counters (workgroup index mod this)
+
+// Barrier for data exchanged through LDS only.  __syncthreads() also waits until every global store
+// of the workgroup has been acknowledged (~1 us): the serial role has global stores in flight almost
+// all the time and only ever hands LDS counters across these barriers.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct CarveBufs {
   DelItem* del;        // slot-0 deletes of the frame
   uint32_t del_cap;
   SlowDelete* slow;    // head / chain deletes of the frame
   uint32_t slow_cap;
-  uint32_t* upd_wg;    // voxels updated, one counter per k_integrate workgroup
-  uint32_t upd_n;
+  uint32_t* upd_wg;    // voxels updated: kUpdCounters counters shared by k_integrate's workgroups
   uint32_t* bitmap;    // delete bitmap indexed by hash entry (many-deletes path)
   uint32_t* summary;
   uint32_t* prefix;
@@ -178,11 +183,12 @@ __device__ inline bool carve_resolve_gate(const Table& tab, const CarveBufs& cb,
 // frame have been resolved before this runs (carve_resolve_gate).
 constexpr uint32_t kReleaseWGs = 16;
 
+// `scratch`: 2 * kSmallCarve + 4 words of LDS, 16-byte aligned.
 __device__ inline void carve_release_role(const Pool& pool, const CarveBufs& cb, Ctl* ctl,
-                                          FrameCtl* Fp, uint32_t wg) {
-  __shared__ __attribute__((aligned(16))) uint32_t del_entry[kSmallCarve];
-  __shared__ int32_t del_pool[kSmallCarve];
-  __shared__ uint32_t n_extra;
+                                          FrameCtl* Fp, uint32_t wg, uint32_t* scratch) {
+  uint32_t* del_entry = scratch;
+  int32_t* del_pool = reinterpret_cast<int32_t*>(scratch + kSmallCarve);
+  uint32_t& n_extra = scratch[2 * kSmallCarve];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   // one round of loads: counters, free count and (speculatively) the head of the delete list
   const uint32_t pend = Fp->pending;
@@ -256,7 +262,7 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
   for (int l = 0; l < kNumLists; ++l) nv += F->n_list[l * kListStride];
   // voxels updated: per-workgroup counters of k_integrate (consumed here)
   uint32_t upd_part = 0;
-  for (uint32_t i = tid; i < cb.upd_n; i += nt) {
+  for (uint32_t i = tid; i < kUpdCounters; i += nt) {
     const uint32_t u = cb.upd_wg[i];
     if (u) {
       upd_part += u;

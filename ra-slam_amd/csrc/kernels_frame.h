@@ -24,9 +24,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fr
     Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, Request* req, uint32_t req_cap,
     SlowRequest* slow, uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Pool pool, CarveBufs cb,
     Ctl* ctl, uint32_t par, CandJob ahead) {
+  // one LDS buffer for whichever role the workgroup plays
+  __shared__ __attribute__((aligned(16))) uint32_t role_lds[2 * kSmallCarve + 16];
+  static_assert(sizeof(CandLds) <= sizeof(role_lds) && kVisListCap <= 2 * kSmallCarve, "role LDS");
   const uint32_t n_dir_wg = n_vis_wg + kCandSegs + kReleaseWGs;
   if (blockIdx.x >= n_dir_wg) {
-    cand_pixels_role(ahead, blockIdx.x - n_dir_wg, ctl);
+    cand_pixels_role(ahead, blockIdx.x - n_dir_wg, ctl, *reinterpret_cast<CandLds*>(role_lds));
     return;
   }
   FrameCtl* F = &ctl->fr[par];
@@ -35,13 +38,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fr
   if (blockIdx.x >= n_vis_wg + kCandSegs) {
     if (P.debug == 12) return;  // diagnostic ablations 3 / 11 / 12: skip one role
     (void)gate();
-    carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - kCandSegs);
+    carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - kCandSegs, role_lds);
   } else if (blockIdx.x >= n_vis_wg) {
     if (P.debug == 11) return;
     cand_consume_role(tab, P, cand, blockIdx.x - n_vis_wg, req, req_cap, slow, slow_cap, ctl, F, gate);
   } else {
     if (P.debug == 3) return;
-    visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F, gate);
+    visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F, gate, role_lds);
   }
 }
 
@@ -76,8 +79,8 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
 #define SSTAMP(i) do { } while (0)
 #endif
   constexpr uint32_t NT = 1024;
+  static_assert(NT == kUpdCounters, "one update counter per thread");
   constexpr uint32_t RPT = kSmallRank / NT;   // requests per thread held in registers
-  constexpr uint32_t UPT = 4;                 // update counters per thread
   uint32_t* scratch = reinterpret_cast<uint32_t*>(skeys);
   uint32_t* lds = scratch;  // [32] slow-delete counter, [33] winner counter, [34] update sum
   const uint32_t tid = threadIdx.x;
@@ -95,12 +98,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
   for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l * kListStride];
   const uint32_t n_slow = F->n_slow;
   uint32_t n = F->n_req;
-  uint32_t u[UPT];
-#pragma unroll
-  for (uint32_t k = 0; k < UPT; ++k) {
-    const uint32_t i = tid + k * NT;
-    u[k] = i < cb.upd_n ? cb.upd_wg[i] : 0u;
-  }
+  const uint32_t u = cb.upd_wg[tid & (kUpdCounters - 1)];  // NT == kUpdCounters
   Request r[RPT];  // the first NT requests ride in the first round; more only if there are more
   r[0] = rb.req[tid < rb.req_cap ? tid : 0];
   unsigned long long tot[5] = {0, 0, 0, 0, 0};
@@ -135,26 +133,15 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
     if (i < n) c[k] = tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)];
   }
   if (tid < 3) lds[32 + tid] = 0;
-  __syncthreads();
+  lds_barrier();
   SSTAMP(2);
   // ---- previous frame: its pool releases were pushed by the release role of this frame's k_front
   // (same "few deletes" condition); here only the count and the voxels-updated sum are needed ----
   if (pend) {
     for (uint32_t j = tid; j < ns; j += NT)  // head / chain deletes: rare
       if (cb.slow[j].state == 2) atomicAdd(&lds[32], 1u);
-    uint32_t up = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < UPT; ++k) {
-      up += u[k];
-      if (u[k]) cb.upd_wg[tid + k * NT] = 0;
-    }
-    for (uint32_t i = tid + UPT * NT; i < cb.upd_n; i += NT) {
-      const uint32_t x = cb.upd_wg[i];
-      if (x) {
-        up += x;
-        cb.upd_wg[i] = 0;
-      }
-    }
+    uint32_t up = u;
+    if (u) cb.upd_wg[tid] = 0;
     up = wave_sum(up);
     if ((tid & 63) == 0 && up) atomicAdd(&lds[34], up);
   }
@@ -169,7 +156,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
       rb.win_ranks[slot] = r[k].rank;
     }
   }
-  __syncthreads();
+  lds_barrier();
   SSTAMP(3);
   const uint32_t n_del = pend ? nd + lds[32] : 0u;
   const uint32_t total = lds[33];
@@ -220,7 +207,8 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Pool pool, RankB
                                                      Ctl* ctl, uint32_t par,
                                                      ratsdf_frame_stats* stats, CandJob ahead) {
   if (blockIdx.x != 0) {
-    cand_pixels_role(ahead, blockIdx.x - 1, ctl);
+    __shared__ CandLds L;
+    cand_pixels_role(ahead, blockIdx.x - 1, ctl, L);
     return;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];

@@ -224,7 +224,7 @@ __device__ inline void finish_block(const Table& tab, const CarveBufs& cb, Ctl* 
     }
   }
   if (fin) {
-    if (nupd) atomicAdd(&cb.upd_wg[blockIdx.x], nupd);
+    if (nupd) atomicAdd(&cb.upd_wg[blockIdx.x & (kUpdCounters - 1)], nupd);
     if (m >= .9f) carve_candidate(tab, cb, ctl, F, item);
   }
 }

@@ -87,8 +87,7 @@ constexpr uint32_t kVisListCap = 2048;  // entries per round (more occupied entr
 template <typename Gate>
 __device__ inline void visible_append_role(const Table& tab, const FrameParams& P, uint32_t wg,
                                            VisItem* vis, uint32_t seg_cap, Ctl* ctl, FrameCtl* F,
-                                           Gate gate) {
-  __shared__ uint32_t list[kVisListCap];
+                                           Gate gate, uint32_t* list /* LDS, kVisListCap words */) {
   __shared__ uint32_t n_items, more, cnt[kNumLists], base[kNumLists], cnt2[kNumLists];
   const uint32_t nwords = tab.num_entry >> 6;
   const uint32_t w = wg * kVisWG + threadIdx.x;

@@ -247,7 +247,6 @@ CarveBufs ratsdf_engine::carve_bufs() const {
   cb.slow = slowdel;
   cb.slow_cap = kSlowDelCap;
   cb.upd_wg = upd_wg;
-  cb.upd_n = integrate_grid;
   cb.bitmap = dbitmap;
   cb.summary = dsummary;
   cb.prefix = dprefix;
@@ -531,8 +530,8 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->vis, (size_t)e->vis_cap * sizeof(VisItem)));
   CREATE_CHK(hipMalloc(&e->del_list, (size_t)t.num_block * sizeof(DelItem)));
   CREATE_CHK(hipMalloc(&e->win_ranks, (size_t)kSmallRank * 4));
-  CREATE_CHK(hipMalloc(&e->upd_wg, 65536 * 4));
-  CREATE_CHK(hipMemsetAsync(e->upd_wg, 0, 65536 * 4, e->stream));
+  CREATE_CHK(hipMalloc(&e->upd_wg, kUpdCounters * 4));
+  CREATE_CHK(hipMemsetAsync(e->upd_wg, 0, kUpdCounters * 4, e->stream));
   CREATE_CHK(hipMalloc(&t.dclaim, (size_t)t.num_bucket * 4));
   CREATE_CHK(hipMemsetAsync(t.dclaim, 0xFF, (size_t)t.num_bucket * 4, e->stream));
   e->dwords = (e->dwords + kGroupWords - 1) / kGroupWords * kGroupWords;
