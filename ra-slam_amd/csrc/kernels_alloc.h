@@ -173,15 +173,22 @@ __device__ inline void alloc_request_absent(const Table& t, int x, int y, int z,
   }
 }
 
+// Requests of a consumer workgroup are collected in LDS and appended to the frame's request list with
+// ONE returning atomic per workgroup at the end (a per-lane or per-wave atomicAdd on that single
+// address, ~90 ops/us, was the longest step of k_front for large or finely resolved images).
+constexpr uint32_t kReqBufCap = 512;
+struct ReqBuf {
+  Request item[kReqBufCap];
+  uint32_t n, base;
+};
+
 // alloc_request_absent for a whole wave (every lane calls it; `want` selects the lanes that have an
-// absent, visible block).  Same effect, but the lanes of a wave share ONE returning atomic on the
-// request counter: a per-lane atomicAdd on that single address (~90 ops/us) was the longest step of
-// k_front once workgroup-level duplicates raised the number of requests.
+// absent, visible block).
 __device__ inline void alloc_request_absent_wave(bool want, const Table& t, int x, int y, int z,
                                                  uint32_t rank, const EntryWords& a,
                                                  const EntryWords& b, Request* req, uint32_t req_cap,
                                                  SlowRequest* slow, uint32_t slow_cap, Ctl* ctl,
-                                                 FrameCtl* F) {
+                                                 FrameCtl* F, ReqBuf& B) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t bucket = block_hash(x, y, z, t.bucket_mask);
   const bool special = (a.idx >= 0 && b.idx >= 0) || entry_offset(b) != 0;
@@ -189,17 +196,29 @@ __device__ inline void alloc_request_absent_wave(bool want, const Table& t, int 
   if (want && !special) app = rank < atomicMin(&t.claim[bucket], rank);
   const unsigned long long m = __ballot(app);
   if (m) {  // uniform
+    const uint32_t cnt = (uint32_t)__popcll(m);
     uint32_t base = 0;
     const int leader = __ffsll((long long)m) - 1;
-    if ((int)lane == leader) base = atomicAdd(&F->n_req, (uint32_t)__popcll(m));
+    if ((int)lane == leader) base = atomicAdd(&B.n, cnt);
     base = __shfl(base, leader);
+    const bool in_lds = base + cnt <= kReqBufCap;  // uniform
+    if (!in_lds) {  // buffer full: straight to the global list
+      if ((int)lane == leader) {
+        atomicSub(&B.n, cnt);
+        base = atomicAdd(&F->n_req, cnt);
+      }
+      base = __shfl(base, leader);
+    }
     if (app) {
       const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       // the leader of an ordinary bucket fills its first empty home entry (voxel_hash.cu:67-78);
       // nothing else can take that slot during the pass, so it is fixed here
       const uint32_t e = (bucket << 1) + (a.idx < 0 ? 0u : 1u);
-      if (slot < req_cap) {
-        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, e};
+      const Request r{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, e};
+      if (in_lds) {
+        B.item[slot] = r;
+      } else if (slot < req_cap) {
+        req[slot] = r;
       } else {
         set_error(ctl, RATSDF_ERR_CAPACITY);
       }
@@ -209,6 +228,23 @@ __device__ inline void alloc_request_absent_wave(bool want, const Table& t, int 
     const uint32_t slot = atomicAdd(&F->n_slow, 1u);
     if (slot < slow_cap) {
       slow[slot] = SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank};
+    } else {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+    }
+  }
+}
+
+// all threads of the workgroup: append the collected requests to the frame's list
+__device__ inline void req_buf_flush(ReqBuf& B, Request* req, uint32_t req_cap, Ctl* ctl, FrameCtl* F) {
+  __syncthreads();
+  const uint32_t n = B.n < kReqBufCap ? B.n : kReqBufCap;
+  if (n == 0) return;  // uniform
+  if (threadIdx.x == 0) B.base = atomicAdd(&F->n_req, n);
+  __syncthreads();
+  const uint32_t base = B.base;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    if (base + i < req_cap) {
+      req[base + i] = B.item[i];
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
     }

@@ -275,21 +275,25 @@ __device__ inline bool wave_block_visible_full(bool want, int bx, int by, int bz
 // (carve_resolve_gate); the list itself does not depend on it, so its loads are issued first.
 template <typename Gate>
 __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P, const CandSet& cs,
-                                         uint32_t seg, Request* req, uint32_t req_cap,
-                                         SlowRequest* slow, uint32_t slow_cap, Ctl* ctl,
-                                         FrameCtl* F, Gate gate) {
+                                         uint32_t seg, uint32_t part, uint32_t parts, Request* req,
+                                         uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap,
+                                         Ctl* ctl, FrameCtl* F, Gate gate, ReqBuf& B) {
+  if (threadIdx.x == 0) B.n = 0;
+  __syncthreads();
+  // `parts` workgroups share a list (part = 0 .. parts-1): the lists of a large or finely resolved
+  // image hold thousands of candidates each.  The counters are reset by the serial role afterwards.
   const uint4* list = cs.list + (size_t)seg * cs.seg_cap;
+  const uint32_t stride = parts * blockDim.x;
   // the count and the first batch of items are fetched together (list memory is always readable)
-  uint4 item = list[threadIdx.x < cs.seg_cap ? threadIdx.x : 0];
+  const uint32_t i0 = part * blockDim.x + threadIdx.x;
+  uint4 item = list[i0 < cs.seg_cap ? i0 : 0];
   uint32_t n = cs.count[seg * kCandCountStride];
   (void)gate();
   if (n > cs.seg_cap) n = cs.seg_cap;
-  __syncthreads();
-  if (threadIdx.x == 0) cs.count[seg * kCandCountStride] = 0;
-  for (uint32_t base = 0; base < n; base += blockDim.x) {  // uniform
+  for (uint32_t base = part * blockDim.x; base < n; base += stride) {  // uniform
     const uint32_t i = base + threadIdx.x;
     const bool have = i < n;
-    if (base && have) item = list[i];
+    if (base != part * blockDim.x && have) item = list[i];
     int bx = 0, by = 0, bz = 0;
     EntryWords ea{0, 0, -1}, eb{0, 0, -1};
     bool absent = false;
@@ -305,8 +309,9 @@ __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P,
     }
     const bool want = wave_block_visible_full(absent, bx, by, bz, P);
     alloc_request_absent_wave(want, tab, bx, by, bz, item.z, ea, eb, req, req_cap, slow, slow_cap, ctl,
-                              F);
+                              F, B);
   }
+  req_buf_flush(B, req, req_cap, ctl, F);
 }
 
 // stand-alone candidate pass (single frames, first frame of a batch)

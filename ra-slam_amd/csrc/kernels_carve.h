@@ -59,7 +59,18 @@ __device__ inline uint32_t ld_agent(const uint32_t* p) {
 __device__ inline void carve_candidate(const Table& tab, const CarveBufs& cb, Ctl* ctl, FrameCtl* F,
                                        const VisItem& it) {
   const uint32_t bucket = block_hash(it.x, it.y, it.z, tab.bucket_mask);
-  if (it.entry == (bucket << 1)) {                                       // voxel_hash.cu:114-123
+  // Lock-free cases: slot 0 of the home bucket (voxel_hash.cu:114-123), and the list head (slot 1)
+  // of a bucket WITHOUT a chain.  The reference takes the bucket lock for the head (:125-140), but
+  // with an empty chain no other delete of the pass can want that lock (slot 0 never does, chain
+  // elements do not exist), and its copy-next-into-head step degenerates to clearing the entry.  The
+  // link is read now, not from the visible-list copy: this frame's allocation pass may have appended
+  // a chain element since.
+  bool simple = it.entry == (bucket << 1);
+  if (!simple && it.entry == (bucket << 1) + 1u) {
+    const uint32_t w1 = ld_agent(reinterpret_cast<const uint32_t*>(tab.entries + it.entry) + 1);
+    simple = (w1 >> 16) == 0;
+  }
+  if (simple) {
     uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + it.entry);
     pe[1] = key1(it.z);  // offset = 0
     pe[2] = (uint32_t)-1;
@@ -164,9 +175,8 @@ __device__ inline bool carve_resolve_gate(const Table& tab, const CarveBufs& cb,
     if (threadIdx.x == 0)
       __hip_atomic_store(&Fprev->slow_resolved, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    if (threadIdx.x == 0) {
-      while (__hip_atomic_load(&Fprev->slow_resolved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 2u)
-        __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) {  // relaxed polling (an acquire per poll would flush this CU's L1 each time)
+      while (ld_agent(&Fprev->slow_resolved) != 2u) __builtin_amdgcn_s_sleep(16);
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

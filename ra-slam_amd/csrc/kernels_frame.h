@@ -17,17 +17,21 @@ namespace ratsdf {
 
 // workgroups [0, n_vis_wg)               visible list of the blocks that exist before this frame
 //                                        (longest dependency chain, so it is dispatched first)
-// workgroups [n_vis_wg, +kCandSegs)      allocation requests from the frame's candidate set
+// workgroups [.., +kCandSegs * parts)    allocation requests from the frame's candidate lists
 // workgroups [.., +kReleaseWGs)          pool releases of the previous frame (carve_release_role)
 // workgroups beyond                      look-ahead candidate pass of the next frame
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(
-    Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, Request* req, uint32_t req_cap,
+    Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, uint32_t cand_parts, Request* req,
+    uint32_t req_cap,
     SlowRequest* slow, uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Pool pool, CarveBufs cb,
     Ctl* ctl, uint32_t par, CandJob ahead) {
   // one LDS buffer for whichever role the workgroup plays
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[2 * kSmallCarve + 16];
-  static_assert(sizeof(CandLds) <= sizeof(role_lds) && kVisListCap <= 2 * kSmallCarve, "role LDS");
-  const uint32_t n_dir_wg = n_vis_wg + kCandSegs + kReleaseWGs;
+  static_assert(sizeof(CandLds) <= sizeof(role_lds) && kVisListCap <= 2 * kSmallCarve &&
+                    sizeof(ReqBuf) <= sizeof(role_lds),
+                "role LDS");
+  const uint32_t n_cons_wg = kCandSegs * cand_parts;
+  const uint32_t n_dir_wg = n_vis_wg + n_cons_wg + kReleaseWGs;
   if (blockIdx.x >= n_dir_wg) {
     cand_pixels_role(ahead, blockIdx.x - n_dir_wg, ctl, *reinterpret_cast<CandLds*>(role_lds));
     return;
@@ -35,13 +39,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fr
   FrameCtl* F = &ctl->fr[par];
   FrameCtl* Fp = &ctl->fr[par ^ 1u];
   auto gate = [&]() { return carve_resolve_gate(tab, cb, ctl, Fp); };  // uniform per workgroup
-  if (blockIdx.x >= n_vis_wg + kCandSegs) {
+  if (blockIdx.x >= n_vis_wg + n_cons_wg) {
     if (P.debug == 12) return;  // diagnostic ablations 3 / 11 / 12: skip one role
     (void)gate();
-    carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - kCandSegs, role_lds);
+    carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - n_cons_wg, role_lds);
   } else if (blockIdx.x >= n_vis_wg) {
     if (P.debug == 11) return;
-    cand_consume_role(tab, P, cand, blockIdx.x - n_vis_wg, req, req_cap, slow, slow_cap, ctl, F, gate);
+    const uint32_t c = blockIdx.x - n_vis_wg;
+    cand_consume_role(tab, P, cand, c % kCandSegs, c / kCandSegs, cand_parts, req, req_cap, slow,
+                      slow_cap, ctl, F, gate, *reinterpret_cast<ReqBuf*>(role_lds));
   } else {
     if (P.debug == 3) return;
     visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F, gate, role_lds);
@@ -205,13 +211,16 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
 // workgroups beyond: look-ahead candidate pass of the next frame
 __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Pool pool, RankBufs rb, CarveBufs cb,
                                                      Ctl* ctl, uint32_t par,
-                                                     ratsdf_frame_stats* stats, CandJob ahead) {
+                                                     ratsdf_frame_stats* stats, uint32_t* cand_count,
+                                                     CandJob ahead) {
   if (blockIdx.x != 0) {
     __shared__ CandLds L;
     cand_pixels_role(ahead, blockIdx.x - 1, ctl, L);
     return;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  // the frame's candidate lists have been consumed by k_front: empty them for the frame after next
+  if (cand_count && threadIdx.x < kCandSegs) cand_count[threadIdx.x * kCandCountStride] = 0;
   serial_frame_role(tab, pool, rb, cb, ctl, par, stats, skeys);
 }
 

@@ -73,6 +73,7 @@ struct ratsdf_engine {
   unsigned parity = 0;                   // which texel buffer / candidate set the NEXT frame uses
   bool cand_ready = false;               // that frame's candidate pass has already been enqueued
   unsigned cand_split = 60;              // percent of the look-ahead pass placed in k_alloc_rank
+  unsigned cand_parts_env = 0;           // RATSDF_CAND_PARTS: consumer workgroups per candidate list
   unsigned cand_wgs = 248;               // look-ahead workgroups per host kernel (about one per CU)
   Request* req = nullptr;
   uint32_t req_cap = 0;
@@ -120,7 +121,7 @@ struct ratsdf_engine {
   int free_all();
   int ensure_image(size_t npix, size_t nranks);
   int ensure_stage(size_t npix);
-  int alloc_rank(uint32_t nranks, unsigned par, const CandJob* next = nullptr);
+  int alloc_rank(uint32_t nranks, unsigned par, const CandJob* next = nullptr, bool frame = false);
   int settle();
   CarveBufs carve_bufs() const;
   int select(int mode, const GridBounds& gb, uint32_t* count_slot);
@@ -253,7 +254,7 @@ CarveBufs ratsdf_engine::carve_bufs() const {
   return cb;
 }
 
-int ratsdf_engine::alloc_rank(uint32_t nranks, unsigned par, const CandJob* next) {
+int ratsdf_engine::alloc_rank(uint32_t nranks, unsigned par, const CandJob* next, bool frame) {
   CandJob none;
   memset(&none, 0, sizeof(none));
   const CandJob& job = next ? *next : none;
@@ -273,7 +274,7 @@ int ratsdf_engine::alloc_rank(uint32_t nranks, unsigned par, const CandJob* next
   rb.nwords = (nranks + 31) / 32;
   hipLaunchKernelGGL(k_alloc_rank, dim3(1 + extra), dim3(1024),
                      kSlowSortCap * sizeof(unsigned long long), stream, tab, pool, rb, carve_bufs(), ctl,
-                     (uint32_t)par, d_stats, job);
+                     (uint32_t)par, d_stats, frame ? cand[par].count : (uint32_t*)nullptr, job);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
@@ -376,10 +377,14 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
   const unsigned extra_a = (ahead_a.n_tiles + 3) / 4;
   const unsigned n_vis_wg = (nwg + kVisWordsPerLane - 1) / kVisWordsPerLane;
-  hipLaunchKernelGGL(k_front, dim3(n_vis_wg + kCandSegs + kReleaseWGs + extra_a), dim3(256), 0, stream,
-                     tab, P, n_vis_wg, cand[par], req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(),
+  // consumer workgroups per candidate list: the lists grow with the image and with 1 / voxel size
+  unsigned parts = (unsigned)std::lround((double)npix / 307200.0 * (0.005 / (double)vs) * 2.0);
+  parts = std::min(std::max(parts, 2u), 16u);
+  if (cand_parts_env) parts = cand_parts_env;
+  hipLaunchKernelGGL(k_front, dim3(n_vis_wg + kCandSegs * parts + kReleaseWGs + extra_a), dim3(256), 0,
+                     stream, tab, P, n_vis_wg, cand[par], (uint32_t)parts, req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(),
                      ctl, (uint32_t)par, ahead_a);
-  st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr);
+  st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
   if (st != RATSDF_OK) return st;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -480,6 +485,10 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   if (const char* v = getenv("RATSDF_CAND_SPLIT")) {
     const int x = atoi(v);
     if (x >= 0 && x <= 100) e->cand_split = (unsigned)x;
+  }
+  if (const char* v = getenv("RATSDF_CAND_PARTS")) {
+    const int x = atoi(v);
+    if (x >= 1 && x <= 64) e->cand_parts_env = (unsigned)x;
   }
   if (const char* v = getenv("RATSDF_CAND_WGS")) {
     const int x = atoi(v);
