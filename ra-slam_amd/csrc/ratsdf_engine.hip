@@ -4,6 +4,7 @@
 // Replaces TSDFGrid (utils/tsdf/voxel_tsdf.cu:376-559,847-883), VoxelHashTable / VoxelMemPool host
 // parts (voxel_hash.cu:25-44,225; voxel_mem.cu:13-35,63-67).  gfx950 only; there is no CPU path.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -58,6 +59,7 @@ struct ratsdf_engine {
   int vpl = kDefaultVPL;
   int debug = 0;
   unsigned integrate_grid = 4096;
+  bool grid_from_env = false;
 
   Table tab{};
   Pool pool{};
@@ -399,31 +401,26 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     ev0 = prof_events[prof_used].first;
     ev1 = prof_events[prof_used].second;
     ++prof_used;
-    HIPCHK(hipEventRecord(ev0, stream));
   }
+  // more workgroups for images with several times more visible blocks than 640x480 (measured:
+  // 1280x720 / 2 mm runs 6 % faster with 8192)
+  if (!grid_from_env) integrate_grid = npix >= 600000 ? 8192u : 4096u;
   const CarveBufs cb = carve_bufs();
+  // hipExtLaunchKernelGGL attaches the two events to the dispatch itself: their difference is the
+  // kernel's own start-to-end time (what rocprofv3 reports), without the barrier packets that
+  // hipEventRecord before / after a launch would add (~3 us here).  Null events = a plain launch.
+#define RATSDF_LAUNCH_INTEGRATE(V, NT)                                                              \
+  hipExtLaunchKernelGGL(k_integrate<V>, dim3(integrate_grid), dim3(NT), 0, stream, ev0, ev1, 0, tab, \
+                        pool, P, (const VisItem*)vis, seg_cap, (const Request*)req, req_cap,        \
+                        (const uint32_t*)req_k, (const uint32_t*)win_ranks,                         \
+                        (const float4*)texA[par], (const uint2*)texB[par], cb, ctl, (uint32_t)par)
   switch (vpl) {
-    case 1:
-      hipLaunchKernelGGL(k_integrate<1>, dim3(integrate_grid), dim3(512), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, win_ranks, texA[par], texB[par], cb, ctl,
-                         (uint32_t)par);
-      break;
-    case 8:
-      hipLaunchKernelGGL(k_integrate<8>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, win_ranks, texA[par], texB[par], cb, ctl,
-                         (uint32_t)par);
-      break;
-    case 4:
-      hipLaunchKernelGGL(k_integrate<4>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, win_ranks, texA[par], texB[par], cb, ctl,
-                         (uint32_t)par);
-      break;
-    default:
-      hipLaunchKernelGGL(k_integrate<2>, dim3(integrate_grid), dim3(256), 0, stream, tab, pool, P,
-                         vis, seg_cap, req, req_cap, req_k, win_ranks, texA[par], texB[par], cb, ctl,
-                         (uint32_t)par);
+    case 1: RATSDF_LAUNCH_INTEGRATE(1, 512); break;
+    case 8: RATSDF_LAUNCH_INTEGRATE(8, 256); break;
+    case 4: RATSDF_LAUNCH_INTEGRATE(4, 256); break;
+    default: RATSDF_LAUNCH_INTEGRATE(2, 256);
   }
-  if (timed) HIPCHK(hipEventRecord(ev1, stream));
+#undef RATSDF_LAUNCH_INTEGRATE
 
   HIPCHK(hipGetLastError());
   pending = true;
@@ -496,7 +493,10 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   }
   if (const char* v = getenv("RATSDF_GRID")) {
     const int x = atoi(v);
-    if (x >= 64 && x <= 65536) e->integrate_grid = (unsigned)x;
+    if (x >= 64 && x <= 65536) {
+      e->integrate_grid = (unsigned)x;
+      e->grid_from_env = true;
+    }
   }
   Table& t = e->tab;
   t.num_block = 1 << bb;
