@@ -117,8 +117,19 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
     const V3 pw{(float)gx * P.vs, wy, wz};                              // :187
     const V3 pc3 = se3_apply(P.T, pw);                                  // :190
     const V3 ph = intr_mul(P.K, pc3);                                   // :193
-    const int u = f2i(roundf(ph.x / ph.z));                             // :196-199
-    const int w = f2i(roundf(ph.y / ph.z));                             // :202
+    // hnormalized(): two quotients with the same divisor (shared-divisor form, device_math.h; the
+    // plain IEEE divisions for a depth outside its validity range or non-finite numerators)
+    float qu, qv;
+    if (recip_safe(ph.z) && fabsf(ph.x) < 1e18f && fabsf(ph.y) < 1e18f) {
+      const Recip rz = make_recip(ph.z);
+      qu = div_shared(ph.x, rz);
+      qv = div_shared(ph.y, rz);
+    } else {
+      qu = ph.x / ph.z;
+      qv = ph.y / ph.z;
+    }
+    const int u = f2i(roundf(qu));                                      // :196-199
+    const int w = f2i(roundf(qv));                                      // :202
     inb[j] = u >= 0 && u < P.W && w >= 0 && w < P.H;                    // :205
     kk[j] = inb[j] ? w * P.W + u : 0;
     phz[j] = ph.z;
@@ -141,12 +152,15 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
 #endif
   WSTAMP(2);
   uint32_t nupd = 0;
+  const bool trunc_ok = recip_safe(P.trunc);  // uniform
+  const Recip rtrunc = make_recip(P.trunc);
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
     const float d = ta[j].x;
     const float sdf = ta[j].y * (d - phz[j]);                           // :216
     if (inb[j] && !(d == 0 || d > P.md) && sdf > -P.trunc) {            // :211,217
-      const float ts = fminf(1, sdf / P.trunc);                         // :218
+      const float ts = fminf(1, (trunc_ok && fabsf(sdf) < 1e18f) ? div_shared(sdf, rtrunc)
+                                                                 : sdf / P.trunc);  // :218
       const float wn = __uint_as_float(tb[j].y);                        // :226
       const uint32_t c = cv[j];
       const float wo = (float)(c >> 24);                                // :227
@@ -237,7 +251,7 @@ __device__ inline void finish_block(const Table& tab, const CarveBufs& cb, Ctl* 
 // CU (MI355X_MICROARCH.md, residency formula), which pushed the last 20 % of the blocks into a
 // second round of waves.
 template <int VPL>
-__global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgpr(80))) void k_integrate(
+__global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
     Table tab, Pool pool, FrameParams P, const VisItem* vis, uint32_t seg_cap, const Request* req,
     uint32_t req_cap, const uint32_t* req_k, const uint32_t* win_ranks, const float4* texA,
     const uint2* texB, CarveBufs cb, Ctl* ctl, uint32_t par) {
