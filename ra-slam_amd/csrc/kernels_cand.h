@@ -34,6 +34,7 @@ namespace ratsdf {
 
 constexpr int kCandSegs = 64;           // candidate lists (and consumer workgroups) per frame
 constexpr int kCandCountStride = 32;    // words between list counters (one 128-byte line each)
+constexpr uint32_t kCandReserve = 32;   // list entries a 16x16 super-tile reserves up front
 constexpr unsigned long long kCandEmpty = ~0ull;
 
 struct CandSet {
@@ -195,11 +196,44 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
     L.keys[i] = kCandEmpty;
     L.ranks[i] = kInf;
   }
-  if (threadIdx.x == 0) L.n = 0;
-  __syncthreads();
+  // Space in the global list is reserved NOW, kCandReserve entries per 16x16 super-tile, so that the
+  // returning atomic overlaps the whole pass instead of ending it (it was a full memory round trip
+  // between two barriers at the end of every workgroup); unused entries are written as empties.
+  const uint32_t seg = (J.first_tile + wg) & (kCandSegs - 1);
+  const uint32_t reserve = kCandReserve * ((J.tiles_per_wg + 3) / 4);
+  uint32_t reserved_at = 0;  // thread 0 keeps the answer in a register until it is needed: storing it
+                             // to LDS here, or a __syncthreads(), would wait for the atomic
+  if (threadIdx.x == 0) {
+    L.n = 0;
+    reserved_at = atomicAdd(&J.set.count[seg * kCandCountStride], reserve);
+  }
+#ifdef RATSDF_STAMPS
+  unsigned long long cs[4];
+  cs[0] = clock64();
+  unsigned long long* ws = (ctl->debug_buf && J.P.debug == 8)
+                               ? ctl->debug_buf + (size_t)(((J.first_tile / 4 + wg) * 4 + (threadIdx.x >> 6)) & 16383) * 8
+                               : nullptr;
+  if (ws && (threadIdx.x & 63) == 0) { ws[0] = cs[0]; ws[5] = wall_clock64(); }
+#endif
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS-only barrier (the set is ready)
+#ifdef RATSDF_STAMPS
+  cs[1] = clock64();
+#endif
   if ((threadIdx.x >> 6) < J.tiles_per_wg) cand_pixel_work(J, L, wg, ctl);  // whole waves in or out
+#ifdef RATSDF_STAMPS
+  cs[2] = clock64();
+#endif
   __syncthreads();
-  // compact the occupied slots and append them to one global list: one returning atomic per workgroup
+#ifdef RATSDF_STAMPS
+  cs[3] = clock64();
+  if (threadIdx.x == 0 && (wg & 15) == 0) {
+    atomicAdd(&ctl->stamps[14], cs[1] - cs[0]);
+    atomicAdd(&ctl->stamps[15], cs[2] - cs[1]);
+    atomicAdd(&ctl->stamps[16], cs[3] - cs[2]);
+    atomicAdd(&ctl->stamps[17], 1ull);
+  }
+#endif
+  // compact the occupied slots
   constexpr uint32_t kMaxPerThread = kCandLdsSlots / 64;  // blockDim.x >= 64
   uint32_t pos[kMaxPerThread];
 #pragma unroll
@@ -208,26 +242,39 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
     pos[k] = kInf;
     if (i < kCandLdsSlots && L.keys[i] != kCandEmpty) pos[k] = atomicAdd(&L.n, 1u);
   }
+  if (threadIdx.x == 0) L.base = reserved_at;
   __syncthreads();
-  const uint32_t seg = (J.first_tile + wg) & (kCandSegs - 1);
   const uint32_t n = L.n;
-  if (n == 0) return;  // uniform
-  if (threadIdx.x == 0) L.base = atomicAdd(&J.set.count[seg * kCandCountStride], n);
-  __syncthreads();
   const uint32_t base = L.base;
-  if (base + n > J.set.seg_cap) {  // uniform
-    if (threadIdx.x == 0) set_error(ctl, RATSDF_ERR_CAPACITY);
+  uint32_t base2 = 0;  // a second piece for a workgroup with more candidates than it reserved
+  if (n > reserve) {   // uniform
+    __syncthreads();
+    if (threadIdx.x == 0) L.base = atomicAdd(&J.set.count[seg * kCandCountStride], n - reserve);
+    __syncthreads();
+    base2 = L.base;
+  }
+  if (base + reserve > J.set.seg_cap || (n > reserve && base2 + (n - reserve) > J.set.seg_cap)) {
+    if (threadIdx.x == 0) set_error(ctl, RATSDF_ERR_CAPACITY);  // uniform
     return;
   }
-  uint4* out = J.set.list + (size_t)seg * J.set.seg_cap + base;
+  uint4* out = J.set.list + (size_t)seg * J.set.seg_cap;
 #pragma unroll
   for (uint32_t k = 0; k < kMaxPerThread; ++k) {
     const uint32_t i = threadIdx.x + k * blockDim.x;
     if (pos[k] != kInf) {
       const unsigned long long key = L.keys[i];
-      out[pos[k]] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), L.ranks[i], 0u);
+      const uint32_t at = pos[k] < reserve ? base + pos[k] : base2 + (pos[k] - reserve);
+      out[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), L.ranks[i], 0u);
     }
   }
+  for (uint32_t i = n + threadIdx.x; i < reserve; i += blockDim.x)
+    out[base + i] = make_uint4(kInf, kInf, kInf, 0u);  // empty
+#ifdef RATSDF_STAMPS
+  if (threadIdx.x == 0 && (wg & 15) == 0) atomicAdd(&ctl->stamps[18], (unsigned long long)clock64() - cs[3]);
+  if (ws && (threadIdx.x & 63) == 0) {
+    ws[1] = cs[1]; ws[2] = cs[2]; ws[3] = cs[3]; ws[4] = clock64(); ws[6] = wall_clock64();
+  }
+#endif
 }
 
 // is_block_visible<true> (voxel_tsdf.cu:75-96) for the lanes of a wave that hold an absent
@@ -292,8 +339,9 @@ __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P,
   if (n > cs.seg_cap) n = cs.seg_cap;
   for (uint32_t base = part * blockDim.x; base < n; base += stride) {  // uniform
     const uint32_t i = base + threadIdx.x;
-    const bool have = i < n;
+    bool have = i < n;
     if (base != part * blockDim.x && have) item = list[i];
+    have = have && item.y != kInf;  // reserved but unused entry
     int bx = 0, by = 0, bz = 0;
     EntryWords ea{0, 0, -1}, eb{0, 0, -1};
     bool absent = false;

@@ -379,9 +379,12 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
   const unsigned extra_a = (ahead_a.n_tiles + 3) / 4;
   const unsigned n_vis_wg = (nwg + kVisWordsPerLane - 1) / kVisWordsPerLane;
-  // consumer workgroups per candidate list: the lists grow with the image and with 1 / voxel size
-  unsigned parts = (unsigned)std::lround((double)npix / 307200.0 * (0.005 / (double)vs) * 2.0);
-  parts = std::min(std::max(parts, 2u), 16u);
+  // consumer workgroups per candidate list: every 16x16 super-tile reserves kCandReserve entries
+  // (one pass of 256 lanes per consumer when nothing overflows); finer voxels need more
+  const unsigned supers = ((unsigned)W + 15) / 16 * (((unsigned)H + 15) / 16);
+  unsigned parts = (supers * kCandReserve / kCandSegs + 255) / 256;
+  if (vs < 0.004f) parts *= 2;
+  parts = std::min(std::max(parts, 1u), 32u);
   if (cand_parts_env) parts = cand_parts_env;
   hipLaunchKernelGGL(k_front, dim3(n_vis_wg + kCandSegs * parts + kReleaseWGs + extra_a), dim3(256), 0,
                      stream, tab, P, n_vis_wg, cand[par], (uint32_t)parts, req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(),
@@ -774,6 +777,11 @@ extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
           (double)(t[12] - t[11]) / n, (double)(t[13] - t[12]) / n, (double)t[16] / n, (double)t[17] / n,
           (double)t[18] / n);
   fprintf(stderr, "[stamps] ranks phase, first pass (cold code) %.0f cycles of the two\n", (double)t[19] / n);
+  {
+    const double m = t[17] ? (double)t[17] : 1.0;
+    fprintf(stderr, "[stamps] candidate pass, thread 0 of sampled workgroups (shader cycles): first barrier %.0f | pixel work %.0f | wait for the workgroup %.0f | compaction + stores %.0f\n",
+            (double)t[14] / m, (double)t[15] / m, (double)t[16] / m, (double)t[18] / m);
+  }
   return RATSDF_OK;
 }
 
