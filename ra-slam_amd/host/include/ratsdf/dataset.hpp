@@ -1,0 +1,114 @@
+// dataset.hpp -- offline data providers with the reference's interface
+// (utils/offline_data_provider/offline_data_provider.h:15-94, folder_reader.h / folder_reader.cc),
+// free of OpenCV / yaml-cpp / Eigen:
+//
+//   folder layout (folder_reader.h:38-52)
+//     <folder>/camera_config.yaml      Camera.fx/fy/cx/cy, depthmap_factor, optional Extrinsics (16
+//                                      floats, row-major 4x4)
+//     <folder>/trajectory.txt          one line per frame: id + the top 3 rows of cam_T_world
+//                                      (12 floats, row-major); the reader pre-multiplies the
+//                                      extrinsics into every pose (folder_reader.cc:88,101)
+//     <folder>/<id>_rgb.png            8-bit colour, returned in RGB order (folder_reader.cc:68-70)
+//     <folder>/<id>_depth.png          16-bit grey, returned unchanged (cv::IMREAD_UNCHANGED, :60)
+//
+// PNG decoding is a small zlib-based reader (png.cc) restricted to what cv::imread produces for such
+// files: non-interlaced, colour types 0 / 2 / 3 / 4 / 6, bit depth 8 or 16.  Colour reads follow
+// cv::imread's default flag (8-bit 3 channels: grey is replicated, alpha dropped, 16-bit samples
+// keep their high byte), depth reads keep 16-bit samples as they are.
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "types.hpp"
+
+namespace ratsdf {
+
+struct PngImage {
+  int width = 0, height = 0, channels = 0, bit_depth = 0;  // as stored (after palette expansion)
+  std::vector<uint8_t> data;  // row-major, samples of 16-bit images in host byte order
+};
+// throws std::runtime_error with a message naming the file
+PngImage read_png(const std::string& path);
+
+// "key: value" files as written for ORB-SLAM / OpenCV FileStorage (configs/*.yaml): scalars and
+// one-level flow sequences, comments, a leading %YAML line
+class YamlLite {
+ public:
+  explicit YamlLite(const std::string& path);
+  bool has(const std::string& key) const { return values_.count(key) != 0; }
+  float as_float(const std::string& key) const;                 // throws if missing
+  std::vector<float> as_floats(const std::string& key) const;   // empty if missing
+
+ private:
+  std::map<std::string, std::string> values_;
+};
+
+struct LogEntry {  // folder_reader.h:31-34
+  int id;
+  SE3<float> cam_T_world;
+};
+
+// depth image in metres as offline_eval.cc:74 produces it:
+// cv::Mat::convertTo(CV_32FC1, 1. / factor) = (float)sample * (float)(1.0 / factor)
+std::vector<float> depth_to_metres(const PngImage& depth, float depthmap_factor);
+
+class folder_reader {  // same member names as the reference class
+ public:
+  explicit folder_reader(const std::string& folder_path);
+  CameraIntrinsics<float> get_camera_intrinsics() const;
+  SE3<float> get_camera_extrinsics() const;
+  float get_depth_map_factor() const { return depth_factor_; }
+  void get_depth_frame_by_id(PngImage* depth_img, int frame_idx) const;  // as stored
+  void get_color_frame_by_id(PngImage* rgb_img, int frame_idx) const;    // 8-bit RGB
+  SE3<float> get_camera_pose_by_id(int frame_idx) const;
+  int get_size() const { return size_; }
+  int get_width() const { return width_; }
+  int get_height() const { return height_; }
+
+ private:
+  std::vector<LogEntry> parse_log_entries() const;
+  std::string logdir_;
+  YamlLite camera_config_;
+  std::vector<LogEntry> log_entries_;
+  int size_ = 0, width_ = 0, height_ = 0;
+  float depth_factor_ = 1.f;
+};
+
+// Frames of a folder in order, decoded ahead of the consumer by a few threads (a 640x480 PNG pair
+// takes ~5 ms to inflate and unfilter; the engine integrates a frame in ~40 us).  Not in the
+// reference, whose harness decodes on the integration thread (offline_eval.cc:66-75).
+struct Frame {
+  PngImage rgb;              // 8-bit RGB
+  std::vector<float> depth;  // metres
+  SE3<float> pose;           // cam_T_world, extrinsics included (folder_reader.cc:101)
+};
+
+class FramePrefetcher {
+ public:
+  FramePrefetcher(const folder_reader& reader, int n_frames, int threads);
+  ~FramePrefetcher();
+  bool next(Frame* out);  // false after the last frame; rethrows a decoding error of that frame
+
+ private:
+  struct Slot {
+    Frame frame;
+    std::string error;
+    int ready_for = -1;
+  };
+  void work();
+  const folder_reader& reader_;
+  const int n_;
+  std::vector<Slot> slots_;
+  std::vector<std::thread> workers_;
+  std::mutex mtx_;
+  std::condition_variable cv_;
+  int next_decode_ = 0, consumed_ = 0;
+  bool stop_ = false;
+};
+
+}  // namespace ratsdf
