@@ -120,3 +120,48 @@ def test_full_size_batch_640x480(make_engine, make_oracle):
     oracle_run(cpu, frames, md)
     assert_maps_equal(gpu, cpu)
     check_totals(gpu, cpu)
+
+
+@pytest.mark.parametrize("seed,bucket_bits", [(0, 0), (1, 10), (2, 0), (3, 12)])
+def test_random_interleaving_of_entry_points(seed, bucket_bits, make_engine, make_oracle):
+    """Frames (single and batched), queries, statistics reads and the allocation / deletion hooks in a
+    random order: whatever the engine still owes from the last frame (deferred carve tail,
+    look-ahead state) must be settled correctly by whichever entry point comes next."""
+    rng = np.random.default_rng(100 + seed)
+    vs, md = 0.02, 4.0
+    kw = dict(bucket_bits=bucket_bits, block_bits=13) if bucket_bits else {}
+    gpu, cpu = make_engine(vs, 6 * vs, **kw), make_oracle(vs, 6 * vs, **kw)
+    frames = synthetic.stream("room", 24, scale=0.25, noise=True, holes=True)
+    dev = device_frames(frames)
+    h, w = frames[0]["depth"].shape
+    at = 0
+    for step in range(14):
+        op = rng.integers(0, 6)
+        if op <= 1 and at < len(frames):                     # a batch of 1..5 frames
+            n = int(min(rng.integers(1, 6), len(frames) - at))
+            gpu.integrate_device_batch(make_batch(gpu, frames, dev, at, at + n, md))
+            oracle_run(cpu, frames[at:at + n], md)
+            at += n
+        elif op == 2 and at < len(frames):                   # a single device frame
+            f, d = frames[at], dev[at]
+            gpu.integrate_device(d["rgb"].data_ptr(), d["depth"].data_ptr(), d["ht"].data_ptr(),
+                                 d["lt"].data_ptr(), h, w, md, f["intrinsics"], f["pose"])
+            oracle_run(cpu, [f], md)
+            at += 1
+        elif op == 3:                                        # allocation hook in between
+            pos = rng.integers(-40, 40, size=(int(rng.integers(1, 30)), 3)).astype(np.int16)
+            gpu.test_allocate(pos)
+            cpu.test_allocate(pos)
+        elif op == 4:                                        # deletion hook: some existing blocks
+            ei, bl = cpu.dump_directory()
+            if len(bl):
+                pick = rng.choice(len(bl), size=min(len(bl), int(rng.integers(1, 20))), replace=False)
+                pos = np.stack([bl["x"][pick], bl["y"][pick], bl["z"][pick]], axis=1).astype(np.int16)
+                gpu.test_delete(pos)
+                cpu.test_delete(pos)
+        else:                                                # reads
+            assert gpu.num_active_blocks() == cpu.num_active_blocks()
+            assert_stats_equal(gpu, cpu)
+        if step % 3 == 2:
+            assert_maps_equal(gpu, cpu)
+    assert_maps_equal(gpu, cpu)
