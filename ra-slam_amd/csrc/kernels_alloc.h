@@ -8,17 +8,18 @@
 // outcome is made a pure function of the input: every candidate carries its raster rank
 // (pixel * S + sample) and the pass computes exactly what a sequential, rank-ordered execution of
 // the reference code would:
-//   cand_pixels_role   per pixel: candidate blocks -> the frame's candidate set {block, smallest
-//                      rank}; no directory access (kernels_cand.h; runs ahead of the frame)
-//   cand_consume_role  per distinct candidate: directory lookup, frustum test,
-//                      atomicMin(claim[bucket], rank) for ordinary buckets ("first requester in
-//                      raster order wins the bucket lock"), append to a small slow list for chained
-//                      / full buckets (part of k_front)
-//   k_alloc_rank       one workgroup: (a) replays the slow list in rank order against the claim
-//                      table (time-dependent lock / fill queries), so chain appends lock, link and
-//                      defeat later claims exactly as the sequential code would; (b) winners
-//                      (claim == own rank) set their bit in a rank-indexed bitmap; (c) popcount
-//                      prefix of the bitmap = order of the AquireBlock calls
+//   cand_pixels_role   per pixel: candidate blocks -> the frame's candidate lists {block, smallest
+//                      rank per workgroup}; no directory access (kernels_cand.h; for batched frames
+//                      it runs one frame ahead, inside the previous frame's launches)
+//   cand_consume_role  per candidate: directory lookup, frustum test, atomicMin(claim[bucket], rank)
+//                      for ordinary buckets ("first requester in raster order wins the bucket
+//                      lock"), append to a small slow list for chained / full buckets (k_front)
+//   serial_frame_role  one workgroup (k_alloc_rank, kernels_frame.h): (a) replays the slow list in
+//                      rank order against the claim table (time-dependent lock / fill queries), so
+//                      chain appends lock, link and defeat later claims exactly as the sequential
+//                      code would; (b) winners = requests whose rank equals their bucket's claim;
+//                      (c) their ranks are listed (few) or marked in a rank-indexed bitmap with a
+//                      popcount prefix (many) = order of the AquireBlock calls
 //   commit_request     (inside k_integrate, or k_commit_only for the test hook) one wave per winner:
 //                      pool index heap[free-1-k], directory entry, occupancy bit
 #pragma once
@@ -141,36 +142,6 @@ __device__ inline bool block_present_pre(const Table& t, uint32_t k0, uint32_t k
     off = entry_offset(w);
   }
   return false;
-}
-
-// alloc_request for a block already known to be absent, home entries already loaded.
-__device__ inline void alloc_request_absent(const Table& t, int x, int y, int z, uint32_t rank,
-                                            const EntryWords& a, const EntryWords& b, Request* req,
-                                            uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap,
-                                            Ctl* ctl, FrameCtl* F) {
-  const uint32_t bucket = block_hash(x, y, z, t.bucket_mask);
-  const bool special = (a.idx >= 0 && b.idx >= 0) || entry_offset(b) != 0;
-  if (!special) {
-    const uint32_t old = atomicMin(&t.claim[bucket], rank);
-    if (rank < old) {
-      // the leader of an ordinary bucket fills its first empty home entry (voxel_hash.cu:67-78);
-      // nothing else can take that slot during the pass, so it is fixed here
-      const uint32_t e = (bucket << 1) + (a.idx < 0 ? 0u : 1u);
-      const uint32_t slot = atomicAdd(&F->n_req, 1u);
-      if (slot < req_cap) {
-        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, e};
-      } else {
-        set_error(ctl, RATSDF_ERR_CAPACITY);
-      }
-    }
-  } else {
-    const uint32_t slot = atomicAdd(&F->n_slow, 1u);
-    if (slot < slow_cap) {
-      slow[slot] = SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank};
-    } else {
-      set_error(ctl, RATSDF_ERR_CAPACITY);
-    }
-  }
 }
 
 // Requests of a consumer workgroup are collected in LDS and appended to the frame's request list with

@@ -7,8 +7,8 @@
 // wave and touches no map state, so it does not have to sit on the frame's critical path: when the
 // caller hands over a batch of frames (ratsdf_integrate_device_batch = the queue of
 // TSDFSystem::Run, modules/tsdf_module.cc:88-115), the candidate pass of frame f+1 runs as extra
-// workgroups inside the two single-workgroup kernels of frame f (k_alloc_rank, k_carve), which leave
-// 255 of the 256 CUs idle.  A single frame (ratsdf_integrate_device) runs it as its own launch.
+// workgroups inside frame f's k_front and k_alloc_rank, which leave most of the chip idle.  A single
+// frame (ratsdf_integrate_device) runs it as its own launch.
 //
 // Output of the pass = the frame's candidate list: (block, raster rank = pixel * S + sample) pairs,
 // deduplicated per workgroup with the SMALLEST rank kept.  Only the first request for a block
