@@ -238,9 +238,15 @@ def main():
         for f in frames[:nh]:
             hp.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"], f["pose"])
         th = time.perf_counter() - th
-        host_path = dict(frames_per_s=round(nh / th, 1), frames=nh,
+        # the same frames through ratsdf_integrate_batch (8 at a time, as TSDFSystem's worker does)
+        tb = time.perf_counter()
+        for c0 in range(0, nh, 8):
+            hp.integrate_batch(frames[c0:min(c0 + 8, nh)], a.max_depth)
+        tb = time.perf_counter() - tb
+        host_path = dict(frames_per_s=round(nh / th, 1), frames=nh, batched_frames_per_s=round(nh / tb, 1),
                          note="ratsdf_integrate with host images: H2D copy (4.6 MB/frame) and a "
-                              "stream sync per frame included")
+                              "stream sync per frame included; batched = ratsdf_integrate_batch, "
+                              "8 frames per call")
         hp.close()
 
     # frames in PINNED host memory, uploaded chunk by chunk on a copy stream while the engine

@@ -150,6 +150,21 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
                                   const void* const* d_lt, int height, int width, float max_depth,
                                   const ratsdf_intrinsics* intrinsics,
                                   const ratsdf_pose* cam_T_world);
+/* n consecutive frames from HOST memory: the loop of the reference's TSDFSystem worker over its
+ * queued inputs (modules/tsdf_module.cc:88-115), as one call.  rgb/depth/ht/lt are host arrays of n
+ * host pointers (ht / lt may be NULL = all-ones images); uploads are enqueued ahead of the frames
+ * that use them, frame i+1's map-independent part runs while frame i is integrated, and the call
+ * blocks until all n frames are integrated (like n calls of ratsdf_integrate).  `pinned` != 0 says
+ * that every image buffer comes from ratsdf_host_alloc (uploaded without a staging copy). */
+int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
+                           const float* const* depth, const float* const* ht,
+                           const float* const* lt, int height, int width, float max_depth,
+                           const ratsdf_intrinsics* intrinsics, const ratsdf_pose* cam_T_world,
+                           int pinned);
+/* Page-locked host memory for image buffers (what the reference gets implicitly from
+ * cudaMemcpy of cv::Mat data, voxel_tsdf.cu:433-440, only faster): hipHostMalloc / hipHostFree. */
+int ratsdf_host_alloc(size_t bytes, void** out);
+int ratsdf_host_free(void* p);
 /* cudaStreamSynchronize(stream_), voxel_tsdf.cu:450; also surfaces sticky device-side errors
  * (pool exhausted, work-list overflow). */
 int ratsdf_synchronize(ratsdf_engine* e);

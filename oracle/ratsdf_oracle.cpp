@@ -935,6 +935,28 @@ int ratsdf_oracle_integrate_device_batch(ratsdf_engine*, int, const void* const*
                                          const ratsdf_intrinsics*, const ratsdf_pose*) {
   return RATSDF_ERR_NOT_IMPLEMENTED;
 }
+int ratsdf_oracle_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
+                                  const float* const* depth, const float* const* ht,
+                                  const float* const* lt, int height, int width, float max_depth,
+                                  const ratsdf_intrinsics* K, const ratsdf_pose* P, int) {
+  if (!e || n < 0 || (n > 0 && (!rgb || !depth || !K || !P))) return RATSDF_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < n; ++i) {  // frame by frame: the definition the batched engine must match
+    const int st = ratsdf_oracle_integrate(e, rgb[i], depth[i], (ht && lt) ? ht[i] : nullptr,
+                                           (ht && lt) ? lt[i] : nullptr, height, width, max_depth, &K[i],
+                                           &P[i]);
+    if (st != RATSDF_OK) return st;
+  }
+  return RATSDF_OK;
+}
+int ratsdf_oracle_host_alloc(size_t bytes, void** out) {
+  if (!out) return RATSDF_ERR_BAD_ARGUMENT;
+  *out = bytes ? malloc(bytes) : nullptr;
+  return (*out || !bytes) ? RATSDF_OK : RATSDF_ERR_DEVICE;
+}
+int ratsdf_oracle_host_free(void* p) {
+  free(p);
+  return RATSDF_OK;
+}
 int ratsdf_oracle_synchronize(ratsdf_engine* e) { return e ? e->sticky : RATSDF_ERR_BAD_ARGUMENT; }
 int ratsdf_oracle_stream(ratsdf_engine*, void** s) {
   if (s) *s = nullptr;

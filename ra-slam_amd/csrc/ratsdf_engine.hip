@@ -46,6 +46,7 @@ __global__ void k_init_heap(int32_t* heap, int32_t n) {   // heap_init_kernel, v
 constexpr uint32_t kSlowCap = kSlowSortCap;
 constexpr int kDefaultVPL = 2;  // voxels per lane in k_integrate (RATSDF_VPL=2|4|8 overrides: tuning)
 constexpr uint32_t kSlowDelCap = 1u << 16;
+constexpr int kStageSlots = 8;
 
 }  // namespace
 
@@ -107,10 +108,11 @@ struct ratsdf_engine {
   uint32_t dwords = 0;
   SlowDelete* slowdel = nullptr;
 
-  // staging for the host-image entry point
+  // staging for the host-image entry points: kStageSlots frames of 16 bytes/pixel each
   size_t stage_pix = 0;
   uint8_t* h_stage = nullptr;  // pinned
   uint8_t* d_stage = nullptr;
+  hipEvent_t stage_ev[8] = {};  // upload of the slot's last user has been executed
 
   // profiling of the dominant kernel
   bool profiling = false;
@@ -171,6 +173,8 @@ int ratsdf_engine::free_all() {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h_stage) (void)hipHostFree(h_stage);
+  for (auto& ev : stage_ev)
+    if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : prof_events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -234,9 +238,11 @@ int ratsdf_engine::ensure_stage(size_t npix) {
   if (d_stage) (void)hipFree(d_stage);
   h_stage = nullptr;
   d_stage = nullptr;
-  const size_t bytes = npix * 16;  // rgb 3 (padded to 4) + depth 4 + ht 4 + lt 4
+  const size_t bytes = npix * 16 * kStageSlots;  // per slot: depth 4 + ht 4 + lt 4 + rgb 3 (padded to 4)
   HIPCHK(hipHostMalloc(&h_stage, bytes, hipHostMallocDefault));
   HIPCHK(hipMalloc(&d_stage, bytes));
+  for (int i = 0; i < kStageSlots; ++i)
+    if (!stage_ev[i]) HIPCHK(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
   stage_pix = npix;
   return RATSDF_OK;
 }
@@ -654,6 +660,81 @@ int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, c
   st = e->frame(in, nullptr, height, width, max_depth);
   if (st != RATSDF_OK) return st;
   return e->sticky();  // cudaStreamSynchronize(stream_), voxel_tsdf.cu:450
+}
+
+int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
+                           const float* const* depth, const float* const* ht,
+                           const float* const* lt, int height, int width, float max_depth,
+                           const ratsdf_intrinsics* K, const ratsdf_pose* T, int pinned) {
+  if (!e || n < 0 || (n > 0 && (!rgb || !depth || !K || !T)) || height <= 0 || width <= 0)
+    return RATSDF_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < n; ++i)
+    if (!rgb[i] || !depth[i]) return RATSDF_ERR_BAD_ARGUMENT;
+  if (n == 0) return e->sticky();
+  const size_t npix = (size_t)height * width;
+  int st = e->ensure_stage(npix);
+  if (st != RATSDF_OK) return st;
+  const size_t slot_bytes = npix * 16;
+  auto sem = [&](int i) { return ht && lt && ht[i] && lt[i]; };  // tsdf_module.cc:27-31
+  // layout of a slot: depth | ht | lt | rgb
+  auto upload = [&](int i) -> int {
+    const int slot = i % kStageSlots;
+    uint8_t* d = e->d_stage + (size_t)slot * slot_bytes;
+    if (pinned) {  // straight from the caller's page-locked buffers
+      HIPCHK(hipMemcpyAsync(d, depth[i], npix * 4, hipMemcpyHostToDevice, e->stream));
+      if (sem(i)) {
+        HIPCHK(hipMemcpyAsync(d + npix * 4, ht[i], npix * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(d + npix * 8, lt[i], npix * 4, hipMemcpyHostToDevice, e->stream));
+      }
+      HIPCHK(hipMemcpyAsync(d + npix * 12, rgb[i], npix * 3, hipMemcpyHostToDevice, e->stream));
+      return RATSDF_OK;
+    }
+    uint8_t* h = e->h_stage + (size_t)slot * slot_bytes;
+    if (i >= kStageSlots) HIPCHK(hipEventSynchronize(e->stage_ev[slot]));  // its last upload is done
+    memcpy(h, depth[i], npix * 4);
+    if (sem(i)) {
+      memcpy(h + npix * 4, ht[i], npix * 4);
+      memcpy(h + npix * 8, lt[i], npix * 4);
+    }
+    memcpy(h + npix * 12, rgb[i], npix * 3);
+    HIPCHK(hipMemcpyAsync(d, h, slot_bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipEventRecord(e->stage_ev[slot], e->stream));
+    return RATSDF_OK;
+  };
+  auto input = [&](int i) {
+    uint8_t* d = e->d_stage + (size_t)(i % kStageSlots) * slot_bytes;
+    return ratsdf_engine::FrameIn{d + npix * 12, d, sem(i) ? d + npix * 4 : nullptr,
+                                  sem(i) ? d + npix * 8 : nullptr, &K[i], &T[i]};
+  };
+  // frame i's launches host the look-ahead of frame i+1, so that frame's upload is enqueued first;
+  // a device slot is only overwritten kStageSlots frames later, in stream order
+  st = upload(0);
+  if (st != RATSDF_OK) return st;
+  for (int i = 0; i < n; ++i) {
+    if (i + 1 < n) {
+      st = upload(i + 1);
+      if (st != RATSDF_OK) return st;
+    }
+    const ratsdf_engine::FrameIn cur = input(i);
+    ratsdf_engine::FrameIn nxt{};
+    if (i + 1 < n) nxt = input(i + 1);
+    st = e->frame(cur, i + 1 < n ? &nxt : nullptr, height, width, max_depth);
+    if (st != RATSDF_OK) return st;
+  }
+  return e->sticky();
+}
+
+int ratsdf_host_alloc(size_t bytes, void** out) {
+  if (!out) return RATSDF_ERR_BAD_ARGUMENT;
+  *out = nullptr;
+  if (bytes == 0) return RATSDF_OK;
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return RATSDF_OK;
+}
+
+int ratsdf_host_free(void* p) {
+  if (p) HIPCHK(hipHostFree(p));
+  return RATSDF_OK;
 }
 
 int ratsdf_synchronize(ratsdf_engine* e) {

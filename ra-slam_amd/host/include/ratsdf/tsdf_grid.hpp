@@ -15,6 +15,11 @@ struct Api {
   int (*destroy)(ratsdf_engine*) = nullptr;
   int (*integrate)(ratsdf_engine*, const uint8_t*, const float*, const float*, const float*, int,
                    int, float, const ratsdf_intrinsics*, const ratsdf_pose*) = nullptr;
+  int (*integrate_batch)(ratsdf_engine*, int, const uint8_t* const*, const float* const*,
+                         const float* const*, const float* const*, int, int, float,
+                         const ratsdf_intrinsics*, const ratsdf_pose*, int) = nullptr;
+  int (*host_alloc)(size_t, void**) = nullptr;
+  int (*host_free)(void*) = nullptr;
   int (*query)(ratsdf_engine*, const ratsdf_bounds*, ratsdf_voxel_tsdf**, size_t*) = nullptr;
   int (*gather_valid)(ratsdf_engine*, ratsdf_voxel_tsdf**, size_t*) = nullptr;
   int (*gather_valid_semantic)(ratsdf_engine*, ratsdf_voxel_segm**, size_t*) = nullptr;
@@ -45,6 +50,12 @@ class TSDFGrid {
   void Integrate(const Image& img_rgb, const Image& img_depth, const Image& img_ht,
                  const Image& img_lt, float max_depth, const CameraIntrinsics<float>& intrinsics,
                  const SE3<float>& cam_T_world);
+  // n frames in one call (ratsdf_integrate_batch): what the TSDFSystem worker does with its queue.
+  // ht / lt may be null (all-ones images); `pinned`: every buffer comes from Api::host_alloc
+  void IntegrateBatch(int n, const uint8_t* const* rgb, const float* const* depth,
+                      const float* const* ht, const float* const* lt, int rows, int cols,
+                      float max_depth, const CameraIntrinsics<float>& intrinsics,
+                      const SE3<float>* cam_T_world, bool pinned);
   // voxel_tsdf.cuh:78-79; the two uchar4 images go to host buffers (H*W*4 bytes each, may be null)
   // instead of GLImage8UC4 textures
   void RayCast(float max_depth, const CameraParams& virtual_cam, const SE3<float>& cam_T_world,

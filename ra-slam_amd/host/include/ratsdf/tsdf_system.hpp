@@ -25,11 +25,32 @@
 
 namespace ratsdf {
 
+struct HostBlock {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+};
+
+// Page-locked blocks (Api::host_alloc) recycled between frames: the queue's deep copies live in them
+// so that the worker uploads without a second copy.
+class HostBlockPool {
+ public:
+  explicit HostBlockPool(const Api* api) : api_(api) {}
+  ~HostBlockPool();
+  HostBlock acquire(size_t bytes);
+  void release(const HostBlock& b);
+  bool pinned() const { return true; }
+
+ private:
+  const Api* api_;
+  std::mutex mtx_;
+  std::vector<HostBlock> free_;
+};
+
 struct TSDFSystemInput {  // tsdf_module.h:19-35, images owned by the queue element
   SE3<float> cam_T_world;
   int rows = 0, cols = 0;
-  std::vector<uint8_t> img_rgb;
-  std::vector<float> img_depth, img_ht, img_lt;
+  HostBlock block;       // [depth f32 | ht f32 | lt f32 | rgb u8x3], rows * cols * 16 bytes
+  bool has_sem = false;  // ht / lt given (else: all ones, tsdf_module.cc:29-31)
 };
 
 class TSDFSystem {
@@ -63,7 +84,9 @@ class TSDFSystem {
 
  private:
   void Run();
+  static constexpr size_t kMaxBatch = 8;
   TSDFGrid tsdf_;
+  HostBlockPool pool_;
   float max_depth_;
   const CameraIntrinsics<float> intrinsics_;
   const SE3<float> cam_T_posecam_;

@@ -52,6 +52,9 @@ const Api& Api::Load(const char* path, const char* prefix) {
   api.create = reinterpret_cast<decltype(api.create)>(sym("create"));
   api.destroy = reinterpret_cast<decltype(api.destroy)>(sym("destroy"));
   api.integrate = reinterpret_cast<decltype(api.integrate)>(sym("integrate"));
+  api.integrate_batch = reinterpret_cast<decltype(api.integrate_batch)>(sym("integrate_batch"));
+  api.host_alloc = reinterpret_cast<decltype(api.host_alloc)>(sym("host_alloc"));
+  api.host_free = reinterpret_cast<decltype(api.host_free)>(sym("host_free"));
   api.query = reinterpret_cast<decltype(api.query)>(sym("query"));
   api.gather_valid = reinterpret_cast<decltype(api.gather_valid)>(sym("gather_valid"));
   api.gather_valid_semantic =
@@ -105,6 +108,19 @@ void TSDFGrid::Integrate(const Image& rgb, const Image& depth, const Image& ht, 
                        lt.empty() ? nullptr : static_cast<const float*>(lt.data), depth.rows,
                        depth.cols, max_depth, &k, &p),
        "Integrate");
+}
+
+void TSDFGrid::IntegrateBatch(int n, const uint8_t* const* rgb, const float* const* depth,
+                              const float* const* ht, const float* const* lt, int rows, int cols,
+                              float max_depth, const CameraIntrinsics<float>& K,
+                              const SE3<float>* cam_T_world, bool pinned) {
+  if (!engine_ || n <= 0) return;
+  std::vector<ratsdf_intrinsics> ks((size_t)n, ratsdf_intrinsics{K.fx, K.fy, K.cx, K.cy});
+  std::vector<ratsdf_pose> ps((size_t)n);
+  for (int i = 0; i < n; ++i) ps[(size_t)i] = cam_T_world[i].abi();
+  note(api_->integrate_batch(engine_, n, rgb, depth, ht, lt, rows, cols, max_depth, ks.data(), ps.data(),
+                             pinned ? 1 : 0),
+       "IntegrateBatch");
 }
 
 void TSDFGrid::RayCast(float max_depth, const CameraParams& cam, const SE3<float>& cam_T_world,
@@ -182,17 +198,59 @@ int TSDFGrid::NumActiveBlock() {
   return n;
 }
 
+// ---- page-locked block pool -----------------------------------------------------------------
+HostBlock HostBlockPool::acquire(size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lock(mtx_);
+    for (size_t i = 0; i < free_.size(); ++i)
+      if (free_[i].bytes == bytes) {
+        const HostBlock b = free_[i];
+        free_.erase(free_.begin() + (long)i);
+        return b;
+      }
+  }
+  HostBlock b;
+  b.bytes = bytes;
+  if (api_->host_alloc(bytes, &b.ptr) != RATSDF_OK || !b.ptr) {
+    fprintf(stderr, "[ratsdf] cannot allocate %zu bytes of page-locked memory\n", bytes);
+    abort();
+  }
+  return b;
+}
+
+void HostBlockPool::release(const HostBlock& b) {
+  {
+    std::lock_guard<std::mutex> lock(mtx_);
+    if (free_.size() < 32) {
+      free_.push_back(b);
+      return;
+    }
+  }
+  api_->host_free(b.ptr);
+}
+
+HostBlockPool::~HostBlockPool() {
+  for (const HostBlock& b : free_) api_->host_free(b.ptr);
+}
+
 // ---- TSDFSystem -----------------------------------------------------------------------------
 TSDFSystem::TSDFSystem(float voxel_size, float truncation, float max_depth,
                        const CameraIntrinsics<float>& intrinsics, const SE3<float>& extrinsics,
                        int device, const Api* api)
     : tsdf_(voxel_size, truncation, device, api),
+      pool_(&tsdf_.api()),
       max_depth_(max_depth),
       intrinsics_(intrinsics),
       cam_T_posecam_(extrinsics),
       t_(&TSDFSystem::Run, this) {}
 
-TSDFSystem::~TSDFSystem() { this->terminate(); }
+TSDFSystem::~TSDFSystem() {
+  this->terminate();
+  while (!inputs_.empty()) {  // frames dropped by terminate(): give their blocks back
+    pool_.release(inputs_.front()->block);
+    inputs_.pop();
+  }
+}
 
 void TSDFSystem::Integrate(const SE3<float>& posecam_T_world, const Image& rgb, const Image& depth,
                            const Image& ht, const Image& lt) {
@@ -203,19 +261,18 @@ void TSDFSystem::Integrate(const SE3<float>& posecam_T_world, const Image& rgb, 
   in->rows = depth.rows;
   in->cols = depth.cols;
   const size_t npix = (size_t)depth.rows * depth.cols;
-  const uint8_t* c = static_cast<const uint8_t*>(rgb.data);
-  const float* d = static_cast<const float*>(depth.data);
-  in->img_rgb.assign(c, c + npix * 3);  // clone(), tsdf_module.cc:28-35
-  in->img_depth.assign(d, d + npix);
-  if (ht.empty() || lt.empty()) {
-    in->img_ht.assign(npix, 1.f);  // cv::Mat::ones, tsdf_module.cc:29-31
-    in->img_lt.assign(npix, 1.f);
-  } else {
-    const float* h = static_cast<const float*>(ht.data);
-    const float* l = static_cast<const float*>(lt.data);
-    in->img_ht.assign(h, h + npix);
-    in->img_lt.assign(l, l + npix);
+  // clone(), tsdf_module.cc:28-35 -- into ONE page-locked block [depth | ht | lt | rgb] so that the
+  // worker can upload it without another copy.  Missing ht / lt stay missing: the engine treats
+  // them as the all-ones images the reference would build here (tsdf_module.cc:29-31).
+  in->block = pool_.acquire(npix * 16);
+  in->has_sem = !(ht.empty() || lt.empty());
+  uint8_t* b = static_cast<uint8_t*>(in->block.ptr);
+  memcpy(b, depth.data, npix * 4);
+  if (in->has_sem) {
+    memcpy(b + npix * 4, ht.data, npix * 4);
+    memcpy(b + npix * 8, lt.data, npix * 4);
   }
+  memcpy(b + npix * 12, rgb.data, npix * 3);
   {
     std::lock_guard<std::mutex> lock(mtx_queue_);
     inputs_.push(std::move(in));
@@ -253,7 +310,7 @@ void TSDFSystem::DownloadAllMesh(const std::string& vertices_path, const std::st
 
 void TSDFSystem::Run() {
   while (true) {
-    std::unique_ptr<TSDFSystemInput> input;
+    std::vector<std::unique_ptr<TSDFSystemInput>> batch;
     {
       std::unique_lock<std::mutex> lock(mtx_queue_);
       // wake up for new input or for termination; the reference spins here (tsdf_module.cc:88-102)
@@ -271,22 +328,38 @@ void TSDFSystem::Run() {
       if (inputs_.size() > 10)
         fprintf(stderr, "[TSDF System] Processing cannot catch up (input size: %zu)\n",
                 inputs_.size());
-      input = std::move(inputs_.front());
-      inputs_.pop();
+      // everything that is queued right now (same image size), at most kMaxBatch frames: one engine
+      // call, uploads overlapped with integration; the reference takes one frame per iteration
+      while (!inputs_.empty() && batch.size() < kMaxBatch &&
+             (batch.empty() || (inputs_.front()->rows == batch[0]->rows &&
+                                inputs_.front()->cols == batch[0]->cols))) {
+        batch.push_back(std::move(inputs_.front()));
+        inputs_.pop();
+      }
       busy_ = true;
     }
     {
       std::lock_guard<std::mutex> lock(mtx_read_);
-      const Image rgb{input->img_rgb.data(), input->rows, input->cols, kU8C3};
-      const Image depth{input->img_depth.data(), input->rows, input->cols, kF32C1};
-      const Image ht{input->img_ht.data(), input->rows, input->cols, kF32C1};
-      const Image lt{input->img_lt.data(), input->rows, input->cols, kF32C1};
-      tsdf_.Integrate(rgb, depth, ht, lt, max_depth_, intrinsics_, input->cam_T_world);
+      const size_t n = batch.size(), npix = (size_t)batch[0]->rows * batch[0]->cols;
+      std::vector<const uint8_t*> rgb(n);
+      std::vector<const float*> depth(n), ht(n), lt(n);
+      std::vector<SE3<float>> poses(n);
+      for (size_t i = 0; i < n; ++i) {
+        const uint8_t* b = static_cast<const uint8_t*>(batch[i]->block.ptr);
+        depth[i] = reinterpret_cast<const float*>(b);
+        ht[i] = batch[i]->has_sem ? reinterpret_cast<const float*>(b + npix * 4) : nullptr;
+        lt[i] = batch[i]->has_sem ? reinterpret_cast<const float*>(b + npix * 8) : nullptr;
+        rgb[i] = b + npix * 12;
+        poses[i] = batch[i]->cam_T_world;
+      }
+      tsdf_.IntegrateBatch((int)n, rgb.data(), depth.data(), ht.data(), lt.data(), batch[0]->rows,
+                           batch[0]->cols, max_depth_, intrinsics_, poses.data(), pool_.pinned());
     }
+    for (auto& in : batch) pool_.release(in->block);
     {
       std::lock_guard<std::mutex> lock(mtx_queue_);
       busy_ = false;
-      ++frames_done_;
+      frames_done_ += batch.size();
     }
     cv_queue_.notify_all();
   }

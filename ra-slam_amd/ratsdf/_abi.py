@@ -66,7 +66,7 @@ assert VOXEL_SEGM_DTYPE.itemsize == 20 and RGBW_DTYPE.itemsize == 4
 # every symbol include/ratsdf.h declares (without prefix)
 SYMBOLS = [
     "create", "create_ex", "destroy", "integrate", "integrate_device", "integrate_device_batch",
-    "synchronize", "stream",
+    "integrate_batch", "host_alloc", "host_free", "synchronize", "stream",
     "profile_enable", "profile_read", "totals",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "raycast", "raycast_device", "gather_valid_mesh", "download_all_mesh",
@@ -103,6 +103,10 @@ class Library:
         self.fn["integrate_device"].argtypes = self.fn["integrate"].argtypes
         self.fn["integrate_device_batch"].argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
                                                       C.c_float, vp, vp]
+        self.fn["integrate_batch"].argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float,
+                                               vp, vp, C.c_int]
+        self.fn["host_alloc"].argtypes = [C.c_size_t, C.POINTER(vp)]
+        self.fn["host_free"].argtypes = [vp]
         self.fn["synchronize"].argtypes = [vp]
         self.fn["stream"].argtypes = [vp, C.POINTER(vp)]
         self.fn["profile_enable"].argtypes = [vp, C.c_int]
@@ -244,6 +248,32 @@ class Engine:
         n, rgb, depth, ht, lt, h, w, md, ks, ps = batch
         st = self.lib.fn["integrate_device_batch"](self._h, n, rgb, depth, ht, lt, h, w, md, ks, ps)
         _check(st, "integrate_device_batch")
+
+    def integrate_batch(self, frames, max_depth):
+        """n frames from host memory in one call (ratsdf_integrate_batch).  frames: dicts with rgb,
+        depth, ht, lt (numpy; ht / lt may be None), intrinsics, pose."""
+        n = len(frames)
+        keep = []
+        def col(key, dtype):
+            ptrs = []
+            for f in frames:
+                a = f.get(key)
+                if a is None:
+                    ptrs.append(None)
+                else:
+                    a = np.ascontiguousarray(a, dtype=dtype)
+                    keep.append(a)
+                    ptrs.append(a.ctypes.data)
+            return (C.c_void_p * n)(*ptrs)
+        sem = all(f.get("ht") is not None and f.get("lt") is not None for f in frames)
+        h, w = frames[0]["depth"].shape
+        ks = (Intrinsics * n)(*[_as_intr(f["intrinsics"]) for f in frames])
+        ps = (Pose * n)(*[_as_pose(f["pose"]) for f in frames])
+        st = self.lib.fn["integrate_batch"](self._h, n, col("rgb", np.uint8), col("depth", np.float32),
+                                            col("ht", np.float32) if sem else None,
+                                            col("lt", np.float32) if sem else None, h, w,
+                                            float(max_depth), ks, ps, 0)
+        _check(st, "integrate_batch")
 
     def synchronize(self):
         _check(self.lib.fn["synchronize"](self._h), "synchronize")

@@ -165,3 +165,20 @@ def test_random_interleaving_of_entry_points(seed, bucket_bits, make_engine, mak
         if step % 3 == 2:
             assert_maps_equal(gpu, cpu)
     assert_maps_equal(gpu, cpu)
+
+
+@pytest.mark.parametrize("n,semantic", [(3, True), (11, True), (10, False)])
+def test_host_image_batch(n, semantic, make_engine, make_oracle):
+    """ratsdf_integrate_batch: n frames from host memory in one call (more frames than staging slots
+    in the second case) = n blocking ratsdf_integrate calls."""
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    frames = synthetic.stream("room", n, scale=0.25, noise=True, holes=True, semantic=semantic)
+    gpu.integrate_batch(frames, md)
+    oracle_run(cpu, frames, md)
+    assert_maps_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+    # and the CPU restatement of the same entry point
+    cpu2 = make_oracle(vs, 6 * vs)
+    cpu2.integrate_batch(frames, md)
+    assert_maps_equal(cpu2, cpu)
