@@ -75,7 +75,8 @@ struct ratsdf_engine {
   uint32_t* cand_count = nullptr;        // both sets' list counters
   unsigned parity = 0;                   // which texel buffer / candidate set the NEXT frame uses
   bool cand_ready = false;               // that frame's candidate pass has already been enqueued
-  unsigned cand_split = 60;              // percent of the look-ahead pass placed in k_alloc_rank
+  bool cand_split_env = false;
+  unsigned cand_split = 60;              // percent of the look-ahead pass placed in k_front (rest: k_alloc_rank)
   unsigned cand_parts_env = 0;           // RATSDF_CAND_PARTS: consumer workgroups per candidate list
   unsigned cand_wgs = 248;               // look-ahead workgroups per host kernel (about one per CU)
   Request* req = nullptr;
@@ -369,7 +370,10 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     ahead_b = ahead_a;
     // k_front takes whole 16x16 super-tiles (4 tiles per 256-thread workgroup)
     const uint32_t tiles = ahead_a.n_tiles;
-    const uint32_t tiles_a = (uint32_t)((uint64_t)(tiles / 4) * cand_split / 100) * 4;
+    // share of k_front: 60 % at 640x480; larger images leave k_alloc_rank's 1024-thread workgroups
+    // (one per CU) more than one round of tiles, so k_front takes more (measured at 1280x720)
+    const unsigned split = cand_split_env ? cand_split : (npix >= 600000 ? 80u : cand_split);
+    const uint32_t tiles_a = (uint32_t)((uint64_t)(tiles / 4) * split / 100) * 4;
     ahead_a.n_tiles = tiles_a;
     ahead_a.tiles_per_wg = 4;
     ahead_b.first_tile = tiles_a;
@@ -490,7 +494,10 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   if (const char* v = getenv("RATSDF_DEBUG")) e->debug = atoi(v);
   if (const char* v = getenv("RATSDF_CAND_SPLIT")) {
     const int x = atoi(v);
-    if (x >= 0 && x <= 100) e->cand_split = (unsigned)x;
+    if (x >= 0 && x <= 100) {
+      e->cand_split = (unsigned)x;
+      e->cand_split_env = true;
+    }
   }
   if (const char* v = getenv("RATSDF_CAND_PARTS")) {
     const int x = atoi(v);
