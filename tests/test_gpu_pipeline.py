@@ -182,3 +182,30 @@ def test_host_image_batch(n, semantic, make_engine, make_oracle):
     cpu2 = make_oracle(vs, 6 * vs)
     cpu2.integrate_batch(frames, md)
     assert_maps_equal(cpu2, cpu)
+
+
+def test_pool_exhaustion_inside_a_batch(make_engine, make_oracle):
+    """A pool that is too small for the scene: the batch reports POOL_EXHAUSTED (sticky) like the
+    frame-at-a-time oracle, and both keep the same directory (the insertions that found no block
+    simply did not happen, voxel_mem.cu:39)."""
+    from ratsdf import RatsdfError
+    vs, md = 0.02, 4.0
+    kw = dict(block_bits=5, bucket_bits=12)  # 32 blocks; the first frame alone asks for ~70
+    gpu, cpu = make_engine(vs, 6 * vs, **kw), make_oracle(vs, 6 * vs, **kw)
+    frames = synthetic.stream("room", 4, scale=0.25)
+    dev = device_frames(frames)
+    gpu.integrate_device_batch(make_batch(gpu, frames, dev, 0, 4, md))
+    with pytest.raises(RatsdfError) as ei:
+        gpu.synchronize()
+    assert ei.value.status == 3
+    status = []
+    for f in frames:
+        try:
+            cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+        except RatsdfError as err:
+            status.append(err.status)
+    assert status and set(status) == {3}
+    assert gpu.num_active_blocks() == cpu.num_active_blocks() <= 32
+    from parity import assert_directory_equal, assert_heap_equal
+    assert_directory_equal(gpu, cpu)
+    assert_heap_equal(gpu, cpu)
