@@ -209,3 +209,28 @@ def test_pool_exhaustion_inside_a_batch(make_engine, make_oracle):
     from parity import assert_directory_equal, assert_heap_equal
     assert_directory_equal(gpu, cpu)
     assert_heap_equal(gpu, cpu)
+
+
+def test_large_image_batch_1080p(make_engine, make_oracle):
+    """Three 1920x1080 frames (the reference's maximum image) through the batched host-image entry
+    point: 8 160 candidate tiles per frame, several consumer workgroups per candidate list, the
+    8 192-workgroup grid of k_integrate."""
+    vs, md = 0.01, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+    h, w = 1080, 1920
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    rng = np.random.default_rng(31)
+    frames = []
+    for i in range(3):
+        d = (1.2 + 0.3 * np.sin((xx + 40 * i) / 211.0) * np.cos(yy / 173.0)).astype(np.float32)
+        frames.append(dict(rgb=rng.integers(0, 256, (h, w, 3), dtype=np.uint8), depth=d,
+                           ht=np.clip(0.5 + 0.4 * np.sin(xx / 37) * np.cos(yy / 29), 0.01, 0.99).astype(np.float32),
+                           lt=None, intrinsics=(1400.0, 1400.0, 959.5, 539.5),
+                           pose=(0.0, 0.0, 0.0, 1.0, 0.01 * i, 0.0, 0.0)))
+    for f in frames:
+        f["lt"] = (1 - f["ht"]).astype(np.float32)
+    gpu.integrate_batch(frames, md)
+    oracle_run(cpu, frames, md)
+    assert_maps_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+    assert cpu.last_frame_stats()["visible_blocks"] > 500
