@@ -323,8 +323,8 @@ def main():
             k_avg_s = k_ms / k_n / 1e3
             achieved = b_alg / k_avg_s / 1e9
             traffic = None
-            tpath = ROOT / "profiles" / "traffic_latest.json"
-            if tpath.exists() and a.config == "vga5mm":  # the PMC passes were made on this workload
+            tpath = ROOT / "profiles" / ("traffic_latest.json" if a.config == "vga5mm" else "traffic_hd2mm.json")
+            if tpath.exists():  # PMC passes made on this very workload (tools/traffic.sh)
                 try:
                     traffic = json.loads(tpath.read_text()).get("k_integrate_bytes_per_launch")
                 except Exception:

@@ -2,12 +2,14 @@
 # HBM traffic of the dominant kernel from PMC counters (separate passes, as the microarch guide
 # prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass).  Writes profiles/traffic_latest.json.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+ARGS="$1"            # extra bench.py arguments, e.g. "--config hd2mm"
+OUT="${2:-traffic_latest.json}"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/traffic_$c
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/traffic_$c -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 --no-profile > gpurun_out/traffic_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/traffic_$c -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --host-frames 0 --no-profile $ARGS > gpurun_out/traffic_$c.log 2>&1
 done
-python3 - <<'PY'
-import csv,glob,json,collections,os
+python3 - "$OUT" <<'PY'
+import csv,glob,json,collections,os,sys
 out={}
 for c in ("FETCH_SIZE","WRITE_SIZE"):
     f=sorted(glob.glob(f'gpurun_out/traffic_{c}/*/*counter_collection.csv'), key=os.path.getmtime)[-1]
@@ -26,6 +28,6 @@ res={"kernel":ki,"fetch_size_kb":round(f_kb,1),"write_size_kb":round(w_kb,1),
      "note":"FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B read request); WRITE_SIZE as is; bench workload, steady-state frames",
      "all_kernels_kb":{k:{kk:round(vv,1) for kk,vv in v.items()} for k,v in out.items()}}
 os.makedirs('gpurun_out/profiles_out',exist_ok=True)
-json.dump(res,open('gpurun_out/profiles_out/traffic_latest.json','w'),indent=1)
+json.dump(res,open('gpurun_out/profiles_out/'+sys.argv[1],'w'),indent=1)
 print(json.dumps(res))
 PY
