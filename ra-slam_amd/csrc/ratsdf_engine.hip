@@ -109,6 +109,11 @@ struct ratsdf_engine {
   uint32_t dwords = 0;
   SlowDelete* slowdel = nullptr;
 
+  // query-side download buffers (grow-only)
+  void* dl_dev = nullptr;
+  void* dl_host = nullptr;
+  size_t dl_cap = 0;
+
   // staging for the host-image entry points: kStageSlots frames of 16 bytes/pixel each
   size_t stage_pix = 0;
   uint8_t* h_stage = nullptr;  // pinned
@@ -174,6 +179,8 @@ int ratsdf_engine::free_all() {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h_stage) (void)hipHostFree(h_stage);
+  if (dl_dev) (void)hipFree(dl_dev);
+  if (dl_host) (void)hipHostFree(dl_host);
   for (auto& ev : stage_ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : prof_events) {
@@ -885,6 +892,23 @@ int ratsdf_totals(ratsdf_engine* e, int64_t* out5, int reset) {
   return RATSDF_OK;
 }
 
+// Device and page-locked staging buffers of the query-side downloads: kept between calls and only
+// ever grown (a hipMalloc / hipFree pair and a pageable D2H copy per Query cost more than the kernels).
+static int ensure_download_buffers(ratsdf_engine* e, size_t bytes) {
+  if (bytes <= e->dl_cap) return RATSDF_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->dl_dev) (void)hipFree(e->dl_dev);
+  if (e->dl_host) (void)hipHostFree(e->dl_host);
+  e->dl_dev = nullptr;
+  e->dl_host = nullptr;
+  e->dl_cap = 0;
+  const size_t cap = bytes + bytes / 4;
+  HIPCHK(hipMalloc(&e->dl_dev, cap));
+  HIPCHK(hipHostMalloc(&e->dl_host, cap, hipHostMallocDefault));
+  e->dl_cap = cap;
+  return RATSDF_OK;
+}
+
 static int download_selected(ratsdf_engine* e, bool semantic, void** out, size_t* n) {
   uint32_t cnt = 0;
   HIPCHK(hipMemcpyAsync(&cnt, &e->ctl->n_sel, 4, hipMemcpyDeviceToHost, e->stream));
@@ -894,11 +918,12 @@ static int download_selected(ratsdf_engine* e, bool semantic, void** out, size_t
   void* host = malloc(total ? total * rec : 1);
   if (!host) return RATSDF_ERR_DEVICE;
   if (total) {
-    float* dev = nullptr;
-    if (hipMalloc(&dev, total * rec) != hipSuccess) {
+    const int st = ensure_download_buffers(e, total * rec);
+    if (st != RATSDF_OK) {
       free(host);
-      return RATSDF_ERR_DEVICE;
+      return st;
     }
+    float* dev = static_cast<float*>(e->dl_dev);
     const unsigned grid = cnt < 4096u ? (cnt + 3) / 4 : 1024u;
     if (semantic)
       hipLaunchKernelGGL(k_download<true>, dim3(grid), dim3(256), 0, e->stream, e->pool, e->vis,
@@ -906,13 +931,13 @@ static int download_selected(ratsdf_engine* e, bool semantic, void** out, size_t
     else
       hipLaunchKernelGGL(k_download<false>, dim3(grid), dim3(256), 0, e->stream, e->pool, e->vis,
                          &e->ctl->n_sel, e->vs, dev);
-    hipError_t err = hipMemcpyAsync(host, dev, total * rec, hipMemcpyDeviceToHost, e->stream);
+    hipError_t err = hipMemcpyAsync(e->dl_host, dev, total * rec, hipMemcpyDeviceToHost, e->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-    (void)hipFree(dev);
     if (err != hipSuccess) {
       free(host);
       return RATSDF_ERR_DEVICE;
     }
+    memcpy(host, e->dl_host, total * rec);  // the caller owns `host` (ratsdf_free_buffer)
   }
   *out = host;
   *n = total;
