@@ -234,3 +234,51 @@ def test_large_image_batch_1080p(make_engine, make_oracle):
     assert_maps_equal(gpu, cpu)
     check_totals(gpu, cpu)
     assert cpu.last_frame_stats()["visible_blocks"] > 500
+
+
+def test_many_deletes_take_the_bitmap_path(make_engine, make_oracle):
+    """More than 2 048 deletes in one pass (entry-indexed bitmap + popcount prefix instead of the LDS
+    list): through the deletion hook, and through frames whose surface moves away so that thousands of
+    blocks are carved at once -- once followed by a query (k_settle), once by another frame."""
+    from parity import assert_directory_equal, assert_heap_equal
+    rng = np.random.default_rng(11)
+    gpu, cpu = make_engine(0.01, 0.06), make_oracle(0.01, 0.06)
+    pos = np.unique(rng.integers(-300, 300, size=(6000, 3)).astype(np.int16), axis=0)
+    for e in (gpu, cpu):
+        for _ in range(3):  # one insertion per bucket and pass
+            e.test_allocate(pos)
+    assert gpu.num_active_blocks() == cpu.num_active_blocks() > 5000
+    for e in (gpu, cpu):
+        e.test_delete(pos[:4000])
+    assert_directory_equal(gpu, cpu)
+    assert_heap_equal(gpu, cpu)
+
+    # frames: thousands of blocks sit in the view frustum with their initial values (allocation hook);
+    # a frame without any valid depth updates none of them, so all of them are carved at once
+    vs, md = 0.005, 4.0
+    h, w = 240, 320
+    intr = (285.8, 285.8, 159.5, 119.5)
+    grid = np.array([(x, y, z) for z in range(12, 38) for y in range(-6, 7) for x in range(-8, 9)],
+                    dtype=np.int16)
+    def blind(seed):
+        r = np.random.default_rng(seed)
+        return dict(rgb=r.integers(0, 256, (h, w, 3), dtype=np.uint8), depth=np.zeros((h, w), dtype=np.float32),
+                    ht=np.full((h, w), 0.7, dtype=np.float32), lt=np.full((h, w), 0.3, dtype=np.float32),
+                    intrinsics=intr, pose=(0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0))
+    for follow in ("query", "frame"):
+        gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+        for e in (gpu, cpu):
+            for _ in range(3):
+                e.test_allocate(grid)
+        n0 = cpu.num_active_blocks()
+        assert n0 > 5000 and gpu.num_active_blocks() == n0
+        seq = [blind(1), blind(2)] if follow == "frame" else [blind(1)]
+        dev = device_frames(seq)
+        gpu.integrate_device_batch(make_batch(gpu, seq, dev, 0, len(seq), md))
+        deleted = []
+        for f in seq:
+            oracle_run(cpu, [f], md)
+            deleted.append(cpu.last_frame_stats()["deleted_blocks"])
+        assert deleted[0] > 2048, deleted
+        assert_maps_equal(gpu, cpu)
+        check_totals(gpu, cpu)
