@@ -99,11 +99,13 @@ constexpr int kNumLists = 8;  // one block list per XCD; list 8 (the 9th segment
 // Diagnostic build only (-DRATSDF_STAMPS): thread 0 of the single-workgroup kernels accumulates
 // shader-clock stamps per phase into Ctl-adjacent memory; never compiled into the product library.
 #ifdef RATSDF_STAMPS
+#define RATSDF_DBG(P, n) ((P).debug == (n))  // run-time ablation switches (RATSDF_DEBUG=n)
 #define RATSDF_STAMP(buf, i)                                            \
   do {                                                                  \
     if (threadIdx.x == 0) (buf)[i] += (unsigned long long)clock64();    \
   } while (0)
 #else
+#define RATSDF_DBG(P, n) false
 #define RATSDF_STAMP(buf, i) \
   do {                       \
   } while (0)
@@ -153,5 +155,74 @@ struct Pool {
   float* segm;
   int32_t* heap;
 };
+
+// a bucket lock taken by the chained-bucket resolver (kernels_alloc.h)
+struct XLock {
+  uint32_t bucket, time;
+};
+
+// ---- buffer bundles of the frame kernels ------------------------------------------------------
+struct CarveBufs {
+  DelItem* del;        // slot-0 deletes of the frame
+  uint32_t del_cap;
+  SlowDelete* slow;    // head / chain deletes of the frame
+  uint32_t slow_cap;
+  uint32_t* upd_wg;    // voxels updated: kUpdCounters counters shared by k_integrate's workgroups
+  uint32_t* bitmap;    // delete bitmap indexed by hash entry (many-deletes path)
+  uint32_t* summary;
+  uint32_t* prefix;
+};
+
+// candidate set of a frame (kernels_cand.h)
+struct CandSet {
+  uint4* list;               // [kCandSegs][seg_cap] {x | y << 16, z, rank, -}
+  uint32_t* count;           // [kCandSegs * kCandCountStride]
+  uint32_t seg_cap;
+};
+
+// buffers of the serial allocation-order role (kernels_alloc.h / kernels_frame.h)
+struct RankBufs {
+  Request* req;
+  uint32_t req_cap;
+  uint32_t* req_k;
+  const SlowRequest* slow;
+  uint32_t slow_cap;
+  XLock* xlocks;
+  SlowRequest* distinct;
+  uint32_t* win_ranks;  // raster ranks of the winners (few-winners path, kSmallRank entries)
+  uint32_t* bitmap;   // rank bitmap (many-requests path)
+  uint32_t* summary;
+  uint32_t* prefix;
+  uint32_t nwords;
+};
+
+// Everything about one engine that is constant between (re)allocations, resident in device memory:
+// the kernels' rarely taken paths (space carving, commit of new blocks) read their operands from
+// here instead of holding them in scalar registers for the whole launch, and launches that serve
+// several engines at once (one engine per blockIdx.y) index an array of these.
+struct EngineDev {
+  Table tab;
+  Pool pool;
+  CarveBufs cb;
+  RankBufs rb;
+  Ctl* ctl;
+  ratsdf_frame_stats* stats;
+  SlowRequest* slow;
+  uint32_t slow_cap;
+  uint32_t seg_cap;
+  VisItem* vis;
+  float4* texA[2];
+  uint32_t* texB[2];
+  CandSet cand[2];
+};
+// scalar (SMEM) loads whatever the surrounding code stores: constant address space
+typedef const EngineDev __attribute__((address_space(4))) * EnginePtr;
+// copy of one member (or the whole record) into registers
+template <typename T>
+__device__ inline T ld_const(const T __attribute__((address_space(4))) * p) {
+  T r;
+  __builtin_memcpy(&r, p, sizeof(T));
+  return r;
+}
 
 }  // namespace ratsdf

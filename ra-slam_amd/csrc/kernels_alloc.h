@@ -245,9 +245,6 @@ constexpr int kSlowSortCap = 16384;   // slow requests per pass (LDS bitonic sor
 constexpr int kSlowDistinctCap = 1024;
 constexpr int kXLockCap = 2048;
 
-struct XLock {
-  uint32_t bucket, time;
-};
 
 __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uint32_t req_cap,
                                              const SlowRequest* slow, uint32_t slow_cap,

@@ -25,8 +25,8 @@
 // workgroup (64 counters on separate cache lines: a single-address atomic sustains only ~90 ops/us
 // on this part).  The consumer resets the counters.  Two lists are used alternately (frame parity).
 // Also written here: the packed per-pixel texels k_integrate gathers from (texA = {depth, range,
-// log ht, log lt}, texB = {rgb, w_new}); log(ht), log(lt) and w_new = (1 - d / max_depth) * 4 are
-// functions of the pixel only (voxel_tsdf.cu:226,243,246).
+// log ht - log lt, w_new}, texB = rgb); the logs and w_new = (1 - d / max_depth) * 4 are functions of
+// the pixel only (voxel_tsdf.cu:226,243,246).
 #pragma once
 #include "kernels_alloc.h"
 
@@ -37,11 +37,6 @@ constexpr int kCandCountStride = 32;    // words between list counters (one 128-
 constexpr uint32_t kCandReserve = 32;   // list entries a 16x16 super-tile reserves up front
 constexpr unsigned long long kCandEmpty = ~0ull;
 
-struct CandSet {
-  uint4* list;               // [kCandSegs][seg_cap] {x | y << 16, z, rank, -}
-  uint32_t* count;           // [kCandSegs * kCandCountStride]
-  uint32_t seg_cap;
-};
 
 // One candidate pass (or a share of it).  The image is cut into 16x4-pixel tiles, one per wave; four
 // vertically stacked tiles form a 16x16 super-tile and tiles are numbered super-tile by super-tile,
@@ -55,7 +50,7 @@ struct CandJob {
   const float* ht;
   const float* lt;
   float4* texA;
-  uint2* texB;
+  uint32_t* texB;
   CandSet set;
   uint32_t first_tile, n_tiles;  // this share: tiles [first_tile, first_tile + n_tiles)
   uint32_t tiles_per_wg;         // waves of a workgroup that take a tile; the others only join barriers
@@ -116,19 +111,18 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   const V3 pc = intr_mul(P.Ki, pimg);                                   // :137
   const float r = sqrtf(pc.x * pc.x + (pc.y * pc.y + pc.z * pc.z));     // :140 (Eigen norm order)
   if (inb) {
-    float lh = 0.f, ll = 0.f;
-    if (P.has_sem) {
-      lh = __logf(J.ht[pix]);  // same function as the per-voxel log of the reference's update
-      ll = __logf(J.lt[pix]);
-    }
-    const float wn = (1 - d / P.md) * 4;
+    // log ht - log lt: the observation's log-odds, the only form in which ht and lt enter the
+    // probability update (kernels_integrate.h); -inf / +inf / NaN for ht = 0 / lt = 0 / both
+    float ln = 0.f;
+    if (P.has_sem) ln = __logf(J.ht[pix]) - __logf(J.lt[pix]);
+    const float wn = (1 - d / P.md) * 4;                                // :226
     const uint32_t c = (uint32_t)J.rgb[3 * pix] | ((uint32_t)J.rgb[3 * pix + 1] << 8) |
                        ((uint32_t)J.rgb[3 * pix + 2] << 16);
-    J.texA[pix] = make_float4(d, r, lh, ll);
-    J.texB[pix] = make_uint2(c, __float_as_uint(wn));
+    J.texA[pix] = make_float4(d, r, ln, wn);
+    J.texB[pix] = c;
   }
   const bool valid = inb && !(d == 0 || d > P.md);                      // :141
-  if (P.debug == 1) return;  // uniform
+  if (RATSDF_DBG(P, 1)) return;  // uniform
 
   const V3 pcd{pc.x * d, pc.y * d, pc.z * d};
   const V3 pw = se3_apply(P.Ti, pcd);                                   // :146
@@ -174,7 +168,7 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
     // repeats of the previous sample / the previous pixel carry a larger rank for the same block
     const uint32_t n0 = __shfl_up(k0, 1), n1 = __shfl_up(k1, 1);
     const bool dup = (k0 == prev0 && k1 == prev1) || (lane > 0 && k0 == n0 && k1 == n1);
-    if (act && !dup && shard_owned(bx, P) && P.debug != 2) {
+    if (act && !dup && shard_owned(bx, P) && !RATSDF_DBG(P, 2)) {
       const uint32_t rank = (uint32_t)pix * (uint32_t)P.S + (uint32_t)i;
       const unsigned long long key = (unsigned long long)k0 | ((unsigned long long)k1 << 32);
       if (!cand_lds_insert(L, key, block_hash(bx, by, bz, 0xFFFFFFFFu), rank))
@@ -210,7 +204,7 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
 #ifdef RATSDF_STAMPS
   unsigned long long cs[4];
   cs[0] = clock64();
-  unsigned long long* ws = (ctl->debug_buf && J.P.debug == 8)
+  unsigned long long* ws = (ctl->debug_buf && RATSDF_DBG(J.P, 8))
                                ? ctl->debug_buf + (size_t)(((J.first_tile / 4 + wg) * 4 + (threadIdx.x >> 6)) & 16383) * 8
                                : nullptr;
   if (ws && (threadIdx.x & 63) == 0) { ws[0] = cs[0]; ws[5] = wall_clock64(); }

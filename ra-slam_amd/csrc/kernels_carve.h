@@ -37,16 +37,6 @@ constexpr uint32_t kUpdCounters = 1024;  // voxels-updated counters (workgroup i
 // all the time and only ever hands LDS counters across these barriers.
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct CarveBufs {
-  DelItem* del;        // slot-0 deletes of the frame
-  uint32_t del_cap;
-  SlowDelete* slow;    // head / chain deletes of the frame
-  uint32_t slow_cap;
-  uint32_t* upd_wg;    // voxels updated: kUpdCounters counters shared by k_integrate's workgroups
-  uint32_t* bitmap;    // delete bitmap indexed by hash entry (many-deletes path)
-  uint32_t* summary;
-  uint32_t* prefix;
-};
 
 __device__ inline void occ_clear(const Table& tab, uint32_t e) {
   atomicAnd(&tab.occ[e >> 6], ~(1ull << (e & 63)));

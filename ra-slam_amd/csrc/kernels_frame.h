@@ -40,34 +40,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fr
   FrameCtl* Fp = &ctl->fr[par ^ 1u];
   auto gate = [&]() { return carve_resolve_gate(tab, cb, ctl, Fp); };  // uniform per workgroup
   if (blockIdx.x >= n_vis_wg + n_cons_wg) {
-    if (P.debug == 12) return;  // diagnostic ablations 3 / 11 / 12: skip one role
+    if (RATSDF_DBG(P, 12)) return;  // diagnostic ablations 3 / 11 / 12: skip one role
     (void)gate();
     carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - n_cons_wg, role_lds);
   } else if (blockIdx.x >= n_vis_wg) {
-    if (P.debug == 11) return;
+    if (RATSDF_DBG(P, 11)) return;
     const uint32_t c = blockIdx.x - n_vis_wg;
     cand_consume_role(tab, P, cand, c % kCandSegs, c / kCandSegs, cand_parts, req, req_cap, slow,
                       slow_cap, ctl, F, gate, *reinterpret_cast<ReqBuf*>(role_lds));
   } else {
-    if (P.debug == 3) return;
+    if (RATSDF_DBG(P, 3)) return;
     visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F, gate, role_lds);
   }
 }
 
-struct RankBufs {
-  Request* req;
-  uint32_t req_cap;
-  uint32_t* req_k;
-  const SlowRequest* slow;
-  uint32_t slow_cap;
-  XLock* xlocks;
-  SlowRequest* distinct;
-  uint32_t* win_ranks;  // raster ranks of the winners (few-winners path, kSmallRank entries)
-  uint32_t* bitmap;   // rank bitmap (many-requests path)
-  uint32_t* summary;
-  uint32_t* prefix;
-  uint32_t nwords;
-};
 
 // The serial bookkeeping of a frame in its steady-state shape (few deletes, few requests, no chained
 // buckets involved): carve_finalize of the previous frame + alloc_rank_role of this one, fused so that

@@ -74,6 +74,13 @@ struct VecIO<1> {
   static __device__ inline void store(uint32_t* p, const uint32_t (&v)[1]) { p[0] = v[0]; }
 };
 
+// round-half-away-from-zero of a NON-NEGATIVE float (roundf for x >= 0, NaN stays NaN); the generic
+// roundf additionally restores the sign (v_bfi)
+__device__ inline float round_nonneg(float x) {
+  const float t = truncf(x);
+  return t + ((x - t) >= .5f ? 1.f : 0.f);
+}
+
 // Update of one voxel block by the waves that own it (WPB waves, `part` = which one).  Returns the
 // number of voxels this lane updated and the lane's min |tsdf| after the update.
 #ifdef RATSDF_STAMPS
@@ -84,26 +91,19 @@ struct VecIO<1> {
 template <int VPL>
 __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, const VisItem& item,
                                        bool fresh_in, uint32_t vi0, const float4* texA,
-                                       const uint2* texB, uint32_t* out_nupd, float* out_min,
+                                       const uint32_t* texB, uint32_t* out_nupd, float* out_min,
                                        unsigned long long* wstamps = nullptr) {
   bool fresh = fresh_in;
   const int tx0 = vi0 & 7, ty = (vi0 >> 3) & 7, tz = vi0 >> 6;
   const size_t v = ((size_t)item.idx << 9) + vi0;
   uint32_t tv[VPL], sv[VPL], cv[VPL];
-  if (P.debug == 5) fresh = true;  // diagnostic: no voxel loads / stores
-  if (P.debug != 5) VecIO<VPL>::load(pool.rgbw + v, cv);
+  if (RATSDF_DBG(P, 5)) fresh = true;  // diagnostic: no voxel loads / stores
+  if (!RATSDF_DBG(P, 5)) VecIO<VPL>::load(pool.rgbw + v, cv);
   else
     for (int j = 0; j < VPL; ++j) cv[j] = 0;
   if (!fresh) {
     VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.tsdf + v), tv);
     VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.segm + v), sv);
-  } else {  // AquireBlock initial values, voxel_mem.cu:43-51 (rgb stays as found)
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      tv[j] = __float_as_uint(-1.f);
-      sv[j] = __float_as_uint(.5f);
-      cv[j] = (cv[j] & 0x00FFFFFFu) | 0x01000000u;
-    }
   }
   const int gy = (int16_t)((int16_t)(item.y << 3) + ty);
   const int gz = (int16_t)((int16_t)(item.z << 3) + tz);
@@ -118,7 +118,8 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
     const V3 pc3 = se3_apply(P.T, pw);                                  // :190
     const V3 ph = intr_mul(P.K, pc3);                                   // :193
     // hnormalized(): two quotients with the same divisor (shared-divisor form, device_math.h; the
-    // plain IEEE divisions for a depth outside its validity range or non-finite numerators)
+    // plain IEEE divisions for a depth outside its validity range -- ph.z == 0 happens: a voxel in
+    // the camera plane -- or non-finite numerators)
     float qu, qv;
     if (recip_safe(ph.z) && fabsf(ph.x) < 1e18f && fabsf(ph.y) < 1e18f) {
       const Recip rz = make_recip(ph.z);
@@ -136,67 +137,87 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
   }
   WSTAMP(1);
   float4 ta[VPL];
-  uint2 tb[VPL];
+  uint32_t tb[VPL];
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {  // all gathers in flight together
-    if (P.debug == 4) {            // diagnostic: no gathers
-      ta[j] = make_float4(2.f, 1.f, -0.5f, -0.7f);
-      tb[j] = make_uint2(0x00808080u, __float_as_uint(2.f));
+#ifdef RATSDF_STAMPS
+    if (RATSDF_DBG(P, 4)) {        // diagnostic: no gathers
+      ta[j] = make_float4(2.f, 1.f, -0.5f, 2.f);
+      tb[j] = 0x00808080u;
       continue;
     }
-    ta[j] = texA[kk[j]];           // depth, range, log ht, log lt
-    tb[j] = texB[kk[j]];           // rgb, w_new
+#endif
+    ta[j] = texA[kk[j]];           // depth, range, log ht - log lt, w_new
+    tb[j] = texB[kk[j]];           // rgb
   }
 #ifdef RATSDF_STAMPS
   if (wstamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
   WSTAMP(2);
+  if (fresh) {  // AquireBlock initial values, voxel_mem.cu:43-51 (rgb stays as found)
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      tv[j] = __float_as_uint(-1.f);
+      sv[j] = __float_as_uint(.5f);
+      cv[j] = (cv[j] & 0x00FFFFFFu) | 0x01000000u;
+    }
+  }
   uint32_t nupd = 0;
-  const bool trunc_ok = recip_safe(P.trunc);  // uniform
   const Recip rtrunc = make_recip(P.trunc);
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
     const float d = ta[j].x;
     const float sdf = ta[j].y * (d - phz[j]);                           // :216
-    if (inb[j] && !(d == 0 || d > P.md) && sdf > -P.trunc) {            // :211,217
-      const float ts = fminf(1, (trunc_ok && fabsf(sdf) < 1e18f) ? div_shared(sdf, rtrunc)
-                                                                 : sdf / P.trunc);  // :218
-      const float wn = __uint_as_float(tb[j].y);                        // :226
+    // (the colour word never has its top byte set; testing it here keeps the compiler from sinking
+    // that gather into the branch, where it would be a second, dependent memory round trip)
+    if (inb[j] && !(d == 0 || d > P.md) && sdf > -P.trunc && tb[j] != 0xFFFFFFFFu) {  // :211,217
+      // sdf in (-trunc, range * max_depth]: the shared-divisor quotient is the IEEE one
+      const float ts = fminf(1, div_shared(sdf, rtrunc));               // :218
+      const float wn = ta[j].w;                                         // :226 (per pixel)
       const uint32_t c = cv[j];
       const float wo = (float)(c >> 24);                                // :227
       const float wc = wo + wn;                                         // :228
       const float r_old = (float)(c & 0xFFu), g_old = (float)((c >> 8) & 0xFFu),
                   b_old = (float)((c >> 16) & 0xFFu);
-      const uint32_t cn = tb[j].x;
+      const uint32_t cn = tb[j];
       const float r_new = (float)(cn & 0xFFu), g_new = (float)((cn >> 8) & 0xFFu),
                   b_new = (float)((cn >> 16) & 0xFFu);
-      // wc = weight (1..40) + w_new (0..4): six quotients share it (division, :234-247)
+      // wc = weight (1..40) + w_new (0..4): the quotients of :234-240 share it.  Numerators are
+      // bounded (bytes times weights, |tsdf| <= 1), so no operand leaves the range in which the
+      // shared-divisor form is the correctly rounded quotient; NaN propagates as in IEEE division.
       const Recip rwc = make_recip(wc);
       const float rc = div_shared(r_old * wo + r_new * wn, rwc);        // :234-235
       const float gc = div_shared(g_old * wo + g_new * wn, rwc);
       const float bc = div_shared(b_old * wo + b_new * wn, rwc);
       const float t_old = __uint_as_float(tv[j]);
-      const float t_num = t_old * wo + ts * wn;
-      // a NaN / inf tsdf can only come from NaN / inf inputs; keep IEEE semantics for them
-      tv[j] = __float_as_uint(fabsf(t_num) < 1e18f ? div_shared(t_num, rwc) : t_num / wc);  // :236
-      const uint32_t wq = (uint32_t)f2i(fminf(roundf(wc), 40)) & 0xFFu; // :238
-      cv[j] = ((uint32_t)f2i(roundf(rc)) & 0xFFu) | (((uint32_t)f2i(roundf(gc)) & 0xFFu) << 8) |
-              (((uint32_t)f2i(roundf(bc)) & 0xFFu) << 16) | (wq << 24); // :239-240
-      const float pr = __uint_as_float(sv[j]);
-      if (P.debug != 6) {  // diagnostic 6: no transcendental part
-      // hardware exp2/log2 based exp/log (v_exp_f32 / v_log_f32, ~1e-7 relative): the only
-      // functions of the path whose last bits differ between any two libms anyway
-      // log(0) = -inf is a legal input here (ht = 0, :242-247): guard the shared-divisor form
-      const float lp = wo * __logf(pr) + wn * ta[j].z, ln = wo * __logf(1 - pr) + wn * ta[j].w;
-      const float pos = __expf(fabsf(lp) < 1e18f ? div_shared(lp, rwc) : lp / wc);  // :242-244
-      const float neg = __expf(fabsf(ln) < 1e18f ? div_shared(ln, rwc) : ln / wc);  // :245-247
-      sv[j] = __float_as_uint(pos / (pos + neg));                       // :248
+      tv[j] = __float_as_uint(div_shared(t_old * wo + ts * wn, rwc));   // :236
+      // quotients and the weight are non-negative: roundf without the sign step, and the byte pack
+      // of an integer-valued float is exact in any rounding mode
+      uint32_t o = 0;
+      o = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(rc), 0, o);        // :239-240
+      o = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(gc), 1, o);
+      o = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(bc), 2, o);
+      o = __builtin_amdgcn_cvt_pk_u8_f32(fminf(round_nonneg(wc), 40), 3, o);  // :238
+      cv[j] = o;
+      if (!RATSDF_DBG(P, 6)) {  // diagnostic 6: no transcendental part
+        // probability (:242-248): p' = pos / (pos + neg) with pos = exp((wo log p + wn log ht) / wc),
+        // neg = exp((wo log(1-p) + wn log lt) / wc)  ==  1 / (1 + exp(-(wo L + wn Ln) / wc)) with the
+        // log-odds L = log(p / (1-p)) and the per-pixel Ln = log ht - log lt (texel).  Same function,
+        // one log and one exp instead of two each; hardware v_log / v_exp / v_rcp (~1e-7 relative;
+        // tolerance on the probability is 1e-4, and it feeds nothing else).  0, 1, inf and NaN
+        // behave as in the reference's form (ht = 0 -> p' = 0; ht = lt = 0 -> NaN; ...).
+        const float pr = __uint_as_float(sv[j]);
+        const float odds = pr * __builtin_amdgcn_rcpf(1.f - pr);
+        const float L = __builtin_amdgcn_logf(odds) * 0.69314718f;
+        const float x = (wo * L + wn * ta[j].z) * rwc.r1;
+        const float e = __builtin_amdgcn_exp2f(x * -1.44269504f);
+        sv[j] = __float_as_uint(__builtin_amdgcn_rcpf(1.f + e));
       }
       ++nupd;
     }
   }
   WSTAMP(3);
-  if ((nupd || fresh) && P.debug != 5 && P.debug != 7) {
+  if ((nupd || fresh) && !RATSDF_DBG(P, 5) && !RATSDF_DBG(P, 7)) {
     VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.tsdf + v), tv);
     VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), sv);
     VecIO<VPL>::store(pool.rgbw + v, cv);
@@ -213,35 +234,53 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
 // LDS; one thread adds the update count to its workgroup's counter (a single device-wide counter
 // would cost more than the whole update: ~90 atomics/us per address) and files the block for carving
 // when min |tsdf| >= 0.9 (space_carving_kernel, voxel_tsdf.cu:253-276).
+// smin / supd: [2][8] words, used alternately by consecutive calls (`phase` = call parity), so one
+// LDS-only barrier per call is enough: a wave can only be one call ahead of the slowest reader.
 template <int WPB>
-__device__ inline void finish_block(const Table& tab, const CarveBufs& cb, Ctl* ctl, FrameCtl* F,
-                                    const VisItem& item, bool active, float m, uint32_t nupd,
-                                    uint32_t wv, uint32_t part, uint32_t lane, float* smin,
-                                    uint32_t* supd) {
+__device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, const VisItem& item,
+                                    bool active, float m, uint32_t nupd, uint32_t wv, uint32_t part,
+                                    uint32_t lane, uint32_t phase, float (*smin)[8],
+                                    uint32_t (*supd)[8]) {
   m = wave_min(m);
   nupd = wave_sum(nupd);
   bool fin = active && lane == 0;
   if (WPB > 1) {
-    __syncthreads();  // smin / supd free again
     if (lane == 0) {
-      smin[wv] = m;
-      supd[wv] = nupd;
+      smin[phase][wv] = m;
+      supd[phase][wv] = nupd;
     }
-    __syncthreads();
+    lds_barrier();  // not __syncthreads(): that would also wait for the voxel stores in flight
     fin = fin && part == 0;
     if (fin) {
 #pragma unroll
       for (int i = 1; i < WPB; ++i) {
-        m = fminf(m, smin[wv + i]);
-        nupd += supd[wv + i];
+        m = fminf(m, smin[phase][wv + i]);
+        nupd += supd[phase][wv + i];
       }
     }
   }
   if (fin) {
-    if (nupd) atomicAdd(&cb.upd_wg[blockIdx.x & (kUpdCounters - 1)], nupd);
-    if (m >= .9f) carve_candidate(tab, cb, ctl, F, item);
+    if (nupd) atomicAdd(&upd_wg[blockIdx.x & (kUpdCounters - 1)], nupd);
+    if (m >= .9f) {  // rare: operands come from the engine record, not from registers held all along
+      const Table tab = ld_const(&E->tab);
+      const CarveBufs cb = ld_const(&E->cb);
+      carve_candidate(tab, cb, E->ctl, F, item);
+    }
   }
 }
+
+// What every wave of the voxel update needs, by value (scalar registers).
+struct IntegArgs {
+  uint32_t* rgbw;
+  float* tsdf;
+  float* segm;
+  const float4* texA;
+  const uint32_t* texB;
+  const VisItem* vis;
+  uint32_t seg_cap;
+  FrameCtl* F;
+  uint32_t* upd_wg;
+};
 
 // Work lists: `vis` is kNumLists segments of seg_cap items holding the visible blocks that existed
 // before the frame, bucketed by image tile (block_list_of); workgroup b serves list b & 7, which
@@ -250,81 +289,101 @@ __device__ inline void finish_block(const Table& tab, const CarveBufs& cb, Ctl* 
 // SGPR cap: above 80 SGPRs the hardware admits only 6-7 instead of 8 workgroups of 256 threads per
 // CU (MI355X_MICROARCH.md, residency formula), which pushed the last 20 % of the blocks into a
 // second round of waves.
+// Workgroups [0, n_int_wg) update voxel blocks; workgroups beyond host a share of the NEXT frame's
+// candidate pass (`ahead`, kernels_cand.h): the update is bound by memory latency and leaves the
+// vector ALUs mostly idle, the candidate pass is ALU work on other inputs.
 template <int VPL>
 __global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
-    Table tab, Pool pool, FrameParams P, const VisItem* vis, uint32_t seg_cap, const Request* req,
-    uint32_t req_cap, const uint32_t* req_k, const uint32_t* win_ranks, const float4* texA,
-    const uint2* texB, CarveBufs cb, Ctl* ctl, uint32_t par) {
+    IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, CandJob ahead) {
   constexpr int WPB = 8 / VPL;  // waves per voxel block
   constexpr int BPW = VPL == 1 ? 1 : 4 / WPB;  // voxel blocks per workgroup (256 threads; 512 for VPL 1)
-  __shared__ float smin[8];
-  __shared__ uint32_t supd[8];
-  FrameCtl* F = &ctl->fr[par];
+  __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
+  if (blockIdx.x >= n_int_wg) {
+    if (VPL != 1) cand_pixels_role(ahead, blockIdx.x - n_int_wg, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
+    return;
+  }
+  float (*smin)[8] = reinterpret_cast<float (*)[8]>(role_lds);
+  uint32_t (*supd)[8] = reinterpret_cast<uint32_t (*)[8]>(role_lds + 16);
+  FrameCtl* F = A.F;
+  Pool pool;
+  pool.rgbw = A.rgbw;
+  pool.tsdf = A.tsdf;
+  pool.segm = A.segm;
+  pool.heap = nullptr;
+  const float4* texA = A.texA;
+  const uint32_t* texB = A.texB;
+  const uint32_t seg_cap = A.seg_cap;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wv = threadIdx.x >> 6;
   const uint32_t blk_in_wg = wv / WPB, part = wv % WPB;
   const uint32_t vi0 = (part * 64 + lane) * VPL;  // first voxel of this lane, x + 8y + 64z
   const uint32_t list = blockIdx.x & (kNumLists - 1);
-  const uint32_t wg_in_list = blockIdx.x / kNumLists, wgs_per_list = gridDim.x / kNumLists;
-  const VisItem* my_vis = vis + (size_t)list * seg_cap;
+  const uint32_t wg_in_list = blockIdx.x / kNumLists, wgs_per_list = n_int_wg / kNumLists;
+  const VisItem* my_vis = A.vis + (size_t)list * seg_cap;
   // the first item is fetched together with the counters (the slot exists even if the list is
   // shorter; it is only used when in range), which takes one memory round trip off every wave
   const uint32_t j0 = wg_in_list * BPW + blk_in_wg;
   const VisItem first = my_vis[j0 < seg_cap ? j0 : 0];
   uint32_t n_mine = F->n_list[list * kListStride];
   if (n_mine > seg_cap) n_mine = seg_cap;
-  uint32_t n_req = F->n_req;
-  if (n_req > req_cap) n_req = req_cap;
-  const uint32_t n_win = F->n_win, alloc_base = F->alloc_base, n_winlist = F->n_winlist;
-
-  for (uint32_t it = wg_in_list; it * BPW < n_mine; it += wgs_per_list) {
-    const uint32_t j = it * BPW + blk_in_wg;
-    const bool active = j < n_mine;
+  const uint32_t n_req = F->n_req;  // <= req_cap: clamped below, where the list is read
+  // One loop over the workgroup's items: first its share of the visible list, then its share of this
+  // frame's allocation requests (commit: pool index, directory entry, occupancy bit; the new block
+  // is then updated from its initial values).  A single inlined copy of the voxel update.
+  const uint32_t nv_it = wg_in_list * BPW < n_mine
+                             ? (n_mine - wg_in_list * BPW + wgs_per_list * BPW - 1) / (wgs_per_list * BPW)
+                             : 0u;
+  const uint32_t nr_it = blockIdx.x * BPW < n_req
+                             ? (n_req - blockIdx.x * BPW + n_int_wg * BPW - 1) / (n_int_wg * BPW)
+                             : 0u;
+  for (uint32_t i = 0; i < nv_it + nr_it; ++i) {
     float m = 3.0e38f;
     uint32_t nupd = 0;
+    VisItem item = first;
+    bool active, fresh = false;
 #ifdef RATSDF_STAMPS
-    unsigned long long* ws = (ctl->debug_buf && P.debug != 8 && P.debug != 10) ? ctl->debug_buf + (size_t)((blockIdx.x * 4 + wv) & 16383) * 8 : nullptr;
-    if (ws && lane == 0 && it == wg_in_list) { ws[0] = (unsigned long long)clock64(); ws[5] = wall_clock64(); }
+    unsigned long long* ws = (i == 0 && E->ctl->debug_buf && !RATSDF_DBG(P, 8) && !RATSDF_DBG(P, 10)) ? E->ctl->debug_buf + (size_t)((blockIdx.x * 4 + wv) & 16383) * 8 : nullptr;
+    if (ws && lane == 0) { ws[0] = (unsigned long long)clock64(); ws[5] = wall_clock64(); }
 #else
     unsigned long long* ws = nullptr;
 #endif
-    VisItem item = first;
-    if (active && it != wg_in_list) item = my_vis[j];
-    if (active) integrate_block<VPL>(pool, P, item, false, vi0, texA, texB, &nupd, &m,
-                                     it == wg_in_list ? ws : nullptr);
-#ifdef RATSDF_STAMPS
-    if (ws && lane == 0 && it == wg_in_list) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }
-#endif
-    finish_block<WPB>(tab, cb, ctl, F, item, active, m, nupd, wv, part, lane, smin, supd);
-  }
-  // this frame's allocation requests: commit (pool index, directory entry, occupancy) + first update
-  for (uint32_t it = blockIdx.x; it * BPW < n_req; it += gridDim.x) {
-    const uint32_t t = it * BPW + blk_in_wg;
-    bool active = t < n_req;
-    float m = 3.0e38f;
-    uint32_t nupd = 0;
-    VisItem item{0, 0, 0, 0, -1, 0};
-    if (active) {
-      const Request r = req[t];
-      uint32_t e = 0;
-      int32_t idx = -1;
-      const bool writer = part == 0 && lane == 0;
-      uint32_t k = 0;
-      if (r.flags & kReqWinner) {
-        if (n_winlist) {  // few winners: position in raster order = winners with a smaller rank
-          for (uint32_t j = lane; j < n_winlist; j += 64) k += win_ranks[j] < r.rank;
-          k = wave_sum(k);
-        } else {
-          k = req_k[t];
-        }
-      }
-      active = commit_request(tab, pool, r, k, alloc_base, n_win, writer, &idx, &e);
+    if (i < nv_it) {  // uniform
+      const uint32_t j = (wg_in_list + i * wgs_per_list) * BPW + blk_in_wg;
+      active = j < n_mine;
+      if (active && i != 0) item = my_vis[j];
+    } else {
+      // a new block: operands of the commit come from the engine record
+      const uint32_t t = (blockIdx.x + (i - nv_it) * n_int_wg) * BPW + blk_in_wg;
+      const RankBufs rb = ld_const(&E->rb);
+      active = t < n_req && t < rb.req_cap;
+      fresh = true;
       if (active) {
+        const Table tab = ld_const(&E->tab);
+        Pool cpool = pool;
+        cpool.heap = E->pool.heap;
+        const uint32_t n_win = F->n_win, alloc_base = F->alloc_base, n_winlist = F->n_winlist;
+        const Request r = rb.req[t];
+        uint32_t e = 0;
+        int32_t idx = -1;
+        const bool writer = part == 0 && lane == 0;
+        uint32_t k = 0;
+        if (r.flags & kReqWinner) {
+          if (n_winlist) {  // few winners: position in raster order = winners with a smaller rank
+            for (uint32_t j = lane; j < n_winlist; j += 64) k += rb.win_ranks[j] < r.rank;
+            k = wave_sum(k);
+          } else {
+            k = rb.req_k[t];
+          }
+        }
+        active = commit_request(tab, cpool, r, k, alloc_base, n_win, writer, &idx, &e);
         item = VisItem{r.x, r.y, r.z, 0, idx, e};
-        integrate_block<VPL>(pool, P, item, true, vi0, texA, texB, &nupd, &m);
       }
     }
-    finish_block<WPB>(tab, cb, ctl, F, item, active, m, nupd, wv, part, lane, smin, supd);
+    if (active) integrate_block<VPL>(pool, P, item, fresh, vi0, texA, texB, &nupd, &m, ws);
+#ifdef RATSDF_STAMPS
+    if (ws && lane == 0) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }
+#endif
+    finish_block<WPB>(E, F, A.upd_wg, item, active, m, nupd, wv, part, lane, i & 1u, smin, supd);
   }
 }
 

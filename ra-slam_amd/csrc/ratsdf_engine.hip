@@ -66,17 +66,19 @@ struct ratsdf_engine {
   Pool pool{};
   Ctl* ctl = nullptr;
   ratsdf_frame_stats* d_stats = nullptr;
+  EngineDev* d_eng = nullptr;  // device copy of the engine record (device_types.h)
 
   // image-sized scratch
   size_t pix_cap = 0, rank_cap = 0, cur_nranks = 0;
   float4* texA[2] = {nullptr, nullptr};  // packed per-pixel texels, double-buffered: the candidate
-  uint2* texB[2] = {nullptr, nullptr};   // pass of frame f+1 writes while k_integrate(f) reads
+  uint32_t* texB[2] = {nullptr, nullptr};  // pass of frame f+1 writes while k_integrate(f) reads
   CandSet cand[2] = {};                  // candidate sets, used alternately (kernels_cand.h)
   uint32_t* cand_count = nullptr;        // both sets' list counters
   unsigned parity = 0;                   // which texel buffer / candidate set the NEXT frame uses
   bool cand_ready = false;               // that frame's candidate pass has already been enqueued
   bool cand_split_env = false;
-  unsigned cand_split = 60;              // percent of the look-ahead pass placed in k_front (rest: k_alloc_rank)
+  unsigned cand_split = 60;              // percent of the look-ahead pass placed in k_front,
+  unsigned cand_split_b = 40;            // in k_alloc_rank; the rest rides in k_integrate
   unsigned cand_parts_env = 0;           // RATSDF_CAND_PARTS: consumer workgroups per candidate list
   unsigned cand_wgs = 248;               // look-ahead workgroups per host kernel (about one per CU)
   Request* req = nullptr;
@@ -131,6 +133,9 @@ struct ratsdf_engine {
   int free_all();
   int ensure_image(size_t npix, size_t nranks);
   int ensure_stage(size_t npix);
+  EngineDev record() const;
+  int upload_record();
+  RankBufs rank_bufs(uint32_t nranks) const;
   int alloc_rank(uint32_t nranks, unsigned par, const CandJob* next = nullptr, bool frame = false);
   int settle();
   CarveBufs carve_bufs() const;
@@ -171,7 +176,7 @@ FrameParams ratsdf_engine::base_params() const {
 int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
   void* ptrs[] = {tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
-                  d_stats, texA[0], texA[1], texB[0], texB[1], cand[0].list, cand[1].list, cand_count,
+                  d_stats, d_eng, texA[0], texA[1], texB[0], texB[1], cand[0].list, cand[1].list, cand_count,
                   req, req_k, win_ranks, abitmap, asummary, aprefix,
                   slow, xlocks,
                   distinct, masks, wg_count, vis, del_list, upd_wg, tab.dclaim, dbitmap, dsummary, dprefix,
@@ -191,6 +196,53 @@ int ratsdf_engine::free_all() {
   return RATSDF_OK;
 }
 
+RankBufs ratsdf_engine::rank_bufs(uint32_t nranks) const {
+  RankBufs rb;
+  rb.req = req;
+  rb.req_cap = req_cap;
+  rb.req_k = req_k;
+  rb.win_ranks = win_ranks;
+  rb.slow = slow;
+  rb.slow_cap = kSlowCap;
+  rb.xlocks = xlocks;
+  rb.distinct = distinct;
+  rb.bitmap = abitmap;
+  rb.summary = asummary;
+  rb.prefix = aprefix;
+  rb.nwords = (nranks + 31) / 32;
+  return rb;
+}
+
+EngineDev ratsdf_engine::record() const {
+  EngineDev r;
+  memset(&r, 0, sizeof(r));
+  r.tab = tab;
+  r.pool = pool;
+  r.cb = carve_bufs();
+  r.rb = rank_bufs((uint32_t)cur_nranks);
+  r.ctl = ctl;
+  r.stats = d_stats;
+  r.slow = slow;
+  r.slow_cap = kSlowCap;
+  r.seg_cap = seg_cap;
+  r.vis = vis;
+  for (int i = 0; i < 2; ++i) {
+    r.texA[i] = texA[i];
+    r.texB[i] = texB[i];
+    r.cand[i] = cand[i];
+  }
+  return r;
+}
+
+// the device copy follows every (re)allocation; in stream order, so launches already enqueued keep
+// reading the record they were enqueued with
+int ratsdf_engine::upload_record() {
+  const EngineDev r = record();
+  HIPCHK(hipMemcpyAsync(d_eng, &r, sizeof(r), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));  // `r` is a stack object
+  return RATSDF_OK;
+}
+
 int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
   if (npix <= pix_cap && nranks == cur_nranks) return RATSDF_OK;
   HIPCHK(hipStreamSynchronize(stream));
@@ -201,7 +253,7 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
       texA[i] = nullptr;
       texB[i] = nullptr;
       HIPCHK(hipMalloc(&texA[i], npix * sizeof(float4)));
-      HIPCHK(hipMalloc(&texB[i], npix * sizeof(uint2)));
+      HIPCHK(hipMalloc(&texB[i], npix * sizeof(uint32_t)));
     }
     pix_cap = npix;
   }
@@ -236,7 +288,7 @@ int ratsdf_engine::ensure_image(size_t npix, size_t nranks) {
     HIPCHK(hipMemsetAsync(asummary, 0, (size_t)asum_words * 4, stream));
     cur_nranks = nranks;
   }
-  return RATSDF_OK;
+  return upload_record();
 }
 
 int ratsdf_engine::ensure_stage(size_t npix) {
@@ -275,19 +327,7 @@ int ratsdf_engine::alloc_rank(uint32_t nranks, unsigned par, const CandJob* next
   memset(&none, 0, sizeof(none));
   const CandJob& job = next ? *next : none;
   const unsigned extra = job.n_tiles ? (job.n_tiles + job.tiles_per_wg - 1) / job.tiles_per_wg : 0;
-  RankBufs rb;
-  rb.req = req;
-  rb.req_cap = req_cap;
-  rb.req_k = req_k;
-  rb.win_ranks = win_ranks;
-  rb.slow = slow;
-  rb.slow_cap = kSlowCap;
-  rb.xlocks = xlocks;
-  rb.distinct = distinct;
-  rb.bitmap = abitmap;
-  rb.summary = asummary;
-  rb.prefix = aprefix;
-  rb.nwords = (nranks + 31) / 32;
+  const RankBufs rb = rank_bufs(nranks);
   hipLaunchKernelGGL(k_alloc_rank, dim3(1 + extra), dim3(1024),
                      kSlowSortCap * sizeof(unsigned long long), stream, tab, pool, rb, carve_bufs(), ctl,
                      (uint32_t)par, d_stats, frame ? cand[par].count : (uint32_t*)nullptr, job);
@@ -368,27 +408,36 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     const CandJob job = cand_job(cur, P, par);
     hipLaunchKernelGGL(k_cand, dim3((job.n_tiles + 3) / 4), dim3(256), 0, stream, job, ctl);
   }
-  CandJob ahead_a, ahead_b;  // shares of the next frame's candidate pass: k_front, k_alloc_rank
+  // shares of the next frame's candidate pass: k_front, k_alloc_rank, k_integrate
+  CandJob ahead_a, ahead_b, ahead_c;
   memset(&ahead_a, 0, sizeof(ahead_a));
   memset(&ahead_b, 0, sizeof(ahead_b));
+  memset(&ahead_c, 0, sizeof(ahead_c));
   if (next) {
     const FrameParams Pn = frame_params(*next, H, W, md);
     ahead_a = cand_job(*next, Pn, par ^ 1u);
     ahead_b = ahead_a;
-    // k_front takes whole 16x16 super-tiles (4 tiles per 256-thread workgroup)
+    ahead_c = ahead_a;
+    // k_front and k_integrate take whole 16x16 super-tiles (4 tiles per 256-thread workgroup)
     const uint32_t tiles = ahead_a.n_tiles;
     // share of k_front: 60 % at 640x480; larger images leave k_alloc_rank's 1024-thread workgroups
     // (one per CU) more than one round of tiles, so k_front takes more (measured at 1280x720)
     const unsigned split = cand_split_env ? cand_split : (npix >= 600000 ? 80u : cand_split);
+    const unsigned split_b = cand_split_env ? cand_split_b : 100u - split;
     const uint32_t tiles_a = (uint32_t)((uint64_t)(tiles / 4) * split / 100) * 4;
+    uint32_t tiles_b = (uint32_t)((uint64_t)(tiles / 4) * split_b / 100) * 4;
+    if (split + split_b >= 100u || tiles_a + tiles_b > tiles) tiles_b = tiles - tiles_a;
     ahead_a.n_tiles = tiles_a;
     ahead_a.tiles_per_wg = 4;
     ahead_b.first_tile = tiles_a;
-    ahead_b.n_tiles = tiles - tiles_a;
+    ahead_b.n_tiles = tiles_b;
     // k_alloc_rank runs 1024-thread workgroups, about one per CU; a look-ahead workgroup uses as
     // many of its 16 waves as it needs to cover its tiles
     const uint32_t tpw = (ahead_b.n_tiles + cand_wgs - 1) / cand_wgs;
     ahead_b.tiles_per_wg = std::min<uint32_t>(std::max<uint32_t>(tpw, 1u), 16u);
+    ahead_c.first_tile = tiles_a + tiles_b;
+    ahead_c.n_tiles = tiles - tiles_a - tiles_b;
+    ahead_c.tiles_per_wg = 4;
   }
   parity = par ^ 1u;
   cand_ready = next != nullptr;
@@ -425,15 +474,23 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // more workgroups for images with several times more visible blocks than 640x480 (measured:
   // 1280x720 / 2 mm runs 6 % faster with 8192)
   if (!grid_from_env) integrate_grid = npix >= 600000 ? 8192u : 4096u;
-  const CarveBufs cb = carve_bufs();
   // hipExtLaunchKernelGGL attaches the two events to the dispatch itself: their difference is the
   // kernel's own start-to-end time (what rocprofv3 reports), without the barrier packets that
   // hipEventRecord before / after a launch would add (~3 us here).  Null events = a plain launch.
+  const unsigned extra_c = (ahead_c.n_tiles + 3) / 4;
+  IntegArgs ia;
+  ia.rgbw = pool.rgbw;
+  ia.tsdf = pool.tsdf;
+  ia.segm = pool.segm;
+  ia.texA = texA[par];
+  ia.texB = texB[par];
+  ia.vis = vis;
+  ia.seg_cap = seg_cap;
+  ia.F = &ctl->fr[par];
+  ia.upd_wg = upd_wg;
 #define RATSDF_LAUNCH_INTEGRATE(V, NT)                                                              \
-  hipExtLaunchKernelGGL(k_integrate<V>, dim3(integrate_grid), dim3(NT), 0, stream, ev0, ev1, 0, tab, \
-                        pool, P, (const VisItem*)vis, seg_cap, (const Request*)req, req_cap,        \
-                        (const uint32_t*)req_k, (const uint32_t*)win_ranks,                         \
-                        (const float4*)texA[par], (const uint2*)texB[par], cb, ctl, (uint32_t)par)
+  hipExtLaunchKernelGGL(k_integrate<V>, dim3(integrate_grid + extra_c), dim3(NT), 0, stream, ev0,   \
+                        ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid, ahead_c)
   switch (vpl) {
     case 1: RATSDF_LAUNCH_INTEGRATE(1, 512); break;
     case 8: RATSDF_LAUNCH_INTEGRATE(8, 256); break;
@@ -499,11 +556,16 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     if (x == 1 || x == 2 || x == 4 || x == 8) e->vpl = x;
   }
   if (const char* v = getenv("RATSDF_DEBUG")) e->debug = atoi(v);
-  if (const char* v = getenv("RATSDF_CAND_SPLIT")) {
+  if (const char* v = getenv("RATSDF_CAND_SPLIT")) {  // "a" or "a,b": percent in k_front[, k_alloc_rank]
     const int x = atoi(v);
     if (x >= 0 && x <= 100) {
       e->cand_split = (unsigned)x;
+      e->cand_split_b = 100u - (unsigned)x;
       e->cand_split_env = true;
+      if (const char* c = strchr(v, ',')) {
+        const int y = atoi(c + 1);
+        if (y >= 0 && x + y <= 100) e->cand_split_b = (unsigned)y;
+      }
     }
   }
   if (const char* v = getenv("RATSDF_CAND_PARTS")) {
@@ -552,6 +614,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->pool.heap, (size_t)t.num_block * 4));
   CREATE_CHK(hipMalloc(&e->ctl, sizeof(Ctl)));
   CREATE_CHK(hipMalloc(&e->d_stats, sizeof(ratsdf_frame_stats)));
+  CREATE_CHK(hipMalloc(&e->d_eng, sizeof(EngineDev)));
   CREATE_CHK(hipMalloc(&e->slow, (size_t)kSlowCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->xlocks, (size_t)kXLockCap * sizeof(XLock)));
   CREATE_CHK(hipMalloc(&e->distinct, (size_t)kSlowDistinctCap * sizeof(SlowRequest)));
@@ -594,6 +657,11 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
                                  kSlowSortCap * (int)sizeof(unsigned long long)));
   CREATE_CHK(hipStreamSynchronize(e->stream));
   CREATE_CHK(hipGetLastError());
+  if (e->upload_record() != RATSDF_OK) {
+    e->free_all();
+    delete e;
+    return RATSDF_ERR_DEVICE;
+  }
 #undef CREATE_CHK
   *out = e;
   return RATSDF_OK;
