@@ -228,6 +228,33 @@ int ratsdf_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_verti
 int ratsdf_download_all_mesh(ratsdf_engine* e, const char* vertices_path, const char* indices_path,
                              const char* prob_path);
 
+/* ---- several streams on one GPU --------------------------------------------------------------- */
+/* Frame-batched integration of concurrent streams (BASELINE configs[4] on one device; no reference
+ * counterpart: the reference runs one TSDFGrid per process, modules/tsdf_module.h:152-164).  A group
+ * steps its member engines together: frame f of every member goes through ONE launch triple whose
+ * grids have a slice per member, which fills the chip that a single 640x480 frame leaves mostly
+ * waiting on memory round trips.  Every member's map is exactly what ratsdf_integrate_device_batch on
+ * that member alone would have produced.  Members must live on one device and share voxel size,
+ * truncation and table sizes; they stay usable on their own between group calls (the group orders
+ * its work after / before theirs with events).  HIP engine only. */
+typedef struct ratsdf_group ratsdf_group;
+int ratsdf_group_create(ratsdf_engine* const* engines, int n_engines, ratsdf_group** out);
+int ratsdf_group_destroy(ratsdf_group* g);   /* the member engines are not destroyed */
+int ratsdf_group_size(ratsdf_group* g, int32_t* out);
+/* n_frames consecutive frames of every member stream, inputs resident in HBM.  Element
+ * [f * n_engines + s] of each array belongs to frame f of member s; otherwise as
+ * ratsdf_integrate_device_batch (d_ht / d_lt may be NULL).  Asynchronous. */
+int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n_frames, const void* const* d_rgb,
+                                        const void* const* d_depth, const void* const* d_ht,
+                                        const void* const* d_lt, int height, int width,
+                                        float max_depth, const ratsdf_intrinsics* intrinsics,
+                                        const ratsdf_pose* cam_T_world);
+/* waits for the group's work and runs ratsdf_synchronize on every member (first error wins) */
+int ratsdf_group_synchronize(ratsdf_group* g);
+/* as ratsdf_profile_enable / _read, for the group's k_integrate launches (one launch = all members) */
+int ratsdf_group_profile_enable(ratsdf_group* g, int enable);
+int ratsdf_group_profile_read(ratsdf_group* g, double* integrate_ms, int64_t* launches);
+
 /* ---- multi-GPU support --------------------------------------------------------------------- */
 /* Writes the compact block directory (allocated entries in ascending entry order, 12 B each) into a
  * caller-provided DEVICE buffer so it can be all-gathered with RCCL without touching the host.

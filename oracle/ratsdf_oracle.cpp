@@ -968,6 +968,25 @@ int ratsdf_oracle_profile_read(ratsdf_engine*, double*, int64_t*) {
   return RATSDF_ERR_NOT_IMPLEMENTED;
 }
 
+// groups are a device-launch construct of the HIP engine (several maps per launch): no CPU counterpart
+int ratsdf_oracle_group_create(ratsdf_engine* const*, int, ratsdf_group** out) {
+  if (out) *out = nullptr;
+  return RATSDF_ERR_NOT_IMPLEMENTED;
+}
+int ratsdf_oracle_group_destroy(ratsdf_group*) { return RATSDF_ERR_NOT_IMPLEMENTED; }
+int ratsdf_oracle_group_size(ratsdf_group*, int32_t*) { return RATSDF_ERR_NOT_IMPLEMENTED; }
+int ratsdf_oracle_group_integrate_device_batch(ratsdf_group*, int, const void* const*,
+                                               const void* const*, const void* const*,
+                                               const void* const*, int, int, float,
+                                               const ratsdf_intrinsics*, const ratsdf_pose*) {
+  return RATSDF_ERR_NOT_IMPLEMENTED;
+}
+int ratsdf_oracle_group_synchronize(ratsdf_group*) { return RATSDF_ERR_NOT_IMPLEMENTED; }
+int ratsdf_oracle_group_profile_enable(ratsdf_group*, int) { return RATSDF_ERR_NOT_IMPLEMENTED; }
+int ratsdf_oracle_group_profile_read(ratsdf_group*, double*, int64_t*) {
+  return RATSDF_ERR_NOT_IMPLEMENTED;
+}
+
 int ratsdf_oracle_num_active_blocks(ratsdf_engine* e, int32_t* out) {
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   *out = (int32_t)e->num_block - e->num_free;

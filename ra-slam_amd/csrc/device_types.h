@@ -194,6 +194,7 @@ struct RankBufs {
   uint32_t* summary;
   uint32_t* prefix;
   uint32_t nwords;
+  unsigned long long* sort_scratch;  // kSlowSortCap keys: resolver's sort beyond what fits LDS
 };
 
 // Everything about one engine that is constant between (re)allocations, resident in device memory:

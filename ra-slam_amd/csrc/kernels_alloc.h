@@ -241,7 +241,10 @@ __global__ void k_alloc_list(Table tab, FrameParams P, const int16_t* pos, int n
 // is summarised by its claim (min rank): bucket x is locked from time claim[x] on, and its leader
 // fills the first empty home entry at that time unless an earlier slow request locked x first.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSlowSortCap = 16384;   // slow requests per pass (LDS bitonic sort, 128 KiB)
+constexpr int kSlowSortCap = 16384;   // slow requests per pass (bitonic sort by rank)
+constexpr int kSlowLdsCap = 4096;     // ... sorted in LDS up to this many, in global scratch beyond
+// dynamic LDS of the serial role: sort keys | rank lists (alloc_rank_role) | carve_finalize scratch
+constexpr int kSerialLdsBytes = 34 * 1024;
 constexpr int kSlowDistinctCap = 1024;
 constexpr int kXLockCap = 2048;
 
@@ -249,13 +252,17 @@ constexpr int kXLockCap = 2048;
 __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uint32_t req_cap,
                                              const SlowRequest* slow, uint32_t slow_cap,
                                              XLock* xlocks, SlowRequest* distinct, Ctl* ctl,
-                                             FrameCtl* F, unsigned long long* skeys) {
+                                             FrameCtl* F, unsigned long long* lds_keys,
+                                             unsigned long long* global_keys) {
   uint32_t n = F->n_slow;
   if (n > slow_cap) n = slow_cap;
   if (n > (uint32_t)kSlowSortCap) {
     if (threadIdx.x == 0) set_error(ctl, RATSDF_ERR_CAPACITY);
     n = kSlowSortCap;
   }
+  // few keys (always, with the default directory size): LDS; many: a global scratch buffer, which is
+  // coherent inside one workgroup (same CU, write-through L1, __syncthreads() drains the stores)
+  unsigned long long* skeys = n <= (uint32_t)kSlowLdsCap ? lds_keys : global_keys;
   uint32_t m = 1;
   while (m < n) m <<= 1;
   for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
@@ -518,20 +525,22 @@ __device__ inline void lds_rank_all(uint32_t* keys, uint32_t n, Emit emit) {
 
 constexpr uint32_t kSmallRank = 4096;  // LDS list capacity (16 KiB of the resolver's sort buffer)
 
-// All threads of one workgroup; `skeys` = the workgroup's dynamic LDS (kSlowSortCap keys), `nf` = the
+// All threads of one workgroup; `skeys` = the workgroup's dynamic LDS (kSerialLdsBytes), `nf` = the
 // pool's free count at the start of this pass.
 __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t req_cap,
                                        uint32_t* req_k, const SlowRequest* slow, uint32_t slow_cap,
                                        XLock* xlocks, SlowRequest* distinct, uint32_t* bitmap,
-                                       uint32_t* summary, uint32_t* prefix, uint32_t nwords, Ctl* ctl,
-                                       FrameCtl* F, int32_t nf, unsigned long long* skeys) {
+                                       uint32_t* summary, uint32_t* prefix, uint32_t nwords,
+                                       unsigned long long* sort_scratch, Ctl* ctl, FrameCtl* F,
+                                       int32_t nf, unsigned long long* skeys) {
   uint32_t* lds = reinterpret_cast<uint32_t*>(skeys);  // [0,32): scan scratch, [32]: counter
   uint32_t* lds_rank = lds + 64;                       // kSmallRank words
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   RATSDF_STAMP(ctl->stamps, 8);
   const uint32_t n_slow = F->n_slow;
   if (n_slow != 0) {  // uniform
-    resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, distinct, ctl, F, skeys);
+    resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, distinct, ctl, F, skeys,
+                          sort_scratch);
     __syncthreads();
   }
   uint32_t n = n_slow ? ld_agent_u32(&F->n_req) : F->n_req;  // the resolver appends requests

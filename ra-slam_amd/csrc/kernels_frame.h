@@ -15,25 +15,65 @@
 
 namespace ratsdf {
 
+// One frame of one stream as the kernels see it when their operands live in device memory (launches
+// that serve several engines at once, one engine per blockIdx.y: "frame-batched" integration of
+// concurrent streams): the parameters of the frame, its input images, and which of the engine's two
+// texel / candidate / counter sets it uses.
+struct FrameJob {
+  FrameParams P;
+  const float* depth;
+  const uint8_t* rgb;
+  const float* ht;
+  const float* lt;
+  uint32_t par;
+  uint32_t pad;
+};
+typedef const FrameJob __attribute__((address_space(4))) * JobPtr;
+
+// which tiles of the look-ahead candidate pass a launch hosts (same for every engine of the launch)
+struct AheadGeom {
+  uint32_t first_tile, n_tiles, tiles_per_wg, tiles_x;
+};
+
+// the candidate pass of frame `J` of engine `E`, restricted to `g`
+__device__ inline CandJob make_cand_job(EnginePtr E, JobPtr J, const AheadGeom& g) {
+  CandJob j;
+  j.P = ld_const(&J->P);
+  j.depth = J->depth;
+  j.rgb = J->rgb;
+  j.ht = J->ht;
+  j.lt = J->lt;
+  const uint32_t par = J->par;
+  j.texA = E->texA[par];
+  j.texB = E->texB[par];
+  j.set = ld_const(&E->cand[par]);
+  j.first_tile = g.first_tile;
+  j.n_tiles = g.n_tiles;
+  j.tiles_per_wg = g.tiles_per_wg;
+  j.tiles_x = g.tiles_x;
+  return j;
+}
+
 // workgroups [0, n_vis_wg)               visible list of the blocks that exist before this frame
 //                                        (longest dependency chain, so it is dispatched first)
 // workgroups [.., +kCandSegs * parts)    allocation requests from the frame's candidate lists
 // workgroups [.., +kReleaseWGs)          pool releases of the previous frame (carve_release_role)
-// workgroups beyond                      look-ahead candidate pass of the next frame
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(
-    Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, uint32_t cand_parts, Request* req,
-    uint32_t req_cap,
-    SlowRequest* slow, uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Pool pool, CarveBufs cb,
-    Ctl* ctl, uint32_t par, CandJob ahead) {
-  // one LDS buffer for whichever role the workgroup plays
-  __shared__ __attribute__((aligned(16))) uint32_t role_lds[2 * kSmallCarve + 16];
-  static_assert(sizeof(CandLds) <= sizeof(role_lds) && kVisListCap <= 2 * kSmallCarve &&
-                    sizeof(ReqBuf) <= sizeof(role_lds),
+// workgroups beyond                      look-ahead candidate pass of the next frame (`ahead()`)
+constexpr uint32_t kFrontLdsWords = 2 * kSmallCarve + 16;
+template <typename Ahead>
+__device__ inline void front_body(const Table& tab, const FrameParams& P, uint32_t n_vis_wg,
+                                  const CandSet& cand, uint32_t cand_parts, Request* req,
+                                  uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap, VisItem* vis,
+                                  uint32_t seg_cap, const Pool& pool, const CarveBufs& cb, Ctl* ctl,
+                                  uint32_t par, Ahead ahead, uint32_t* role_lds) {
+  static_assert(sizeof(CandLds) <= kFrontLdsWords * 4 && kVisListCap <= 2 * kSmallCarve &&
+                    sizeof(ReqBuf) <= kFrontLdsWords * 4,
                 "role LDS");
   const uint32_t n_cons_wg = kCandSegs * cand_parts;
   const uint32_t n_dir_wg = n_vis_wg + n_cons_wg + kReleaseWGs;
   if (blockIdx.x >= n_dir_wg) {
-    cand_pixels_role(ahead, blockIdx.x - n_dir_wg, ctl, *reinterpret_cast<CandLds*>(role_lds));
+    const CandJob job = ahead();
+    cand_pixels_role(job, blockIdx.x - n_dir_wg, ctl, *reinterpret_cast<CandLds*>(role_lds));
     return;
   }
   FrameCtl* F = &ctl->fr[par];
@@ -54,6 +94,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fr
   }
 }
 
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(
+    Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, uint32_t cand_parts, Request* req,
+    uint32_t req_cap,
+    SlowRequest* slow, uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Pool pool, CarveBufs cb,
+    Ctl* ctl, uint32_t par, CandJob ahead) {
+  // one LDS buffer for whichever role the workgroup plays
+  __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
+  front_body(tab, P, n_vis_wg, cand, cand_parts, req, req_cap, slow, slow_cap, vis, seg_cap, pool, cb,
+             ctl, par, [&]() { return ahead; }, role_lds);
+}
+
+// the same launch for several engines: engine blockIdx.y, operands from its record and its job
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front_g(
+    EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_vis_wg, uint32_t cand_parts, AheadGeom ag) {
+  __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
+  EnginePtr E = engs + blockIdx.y;
+  JobPtr J = cur + blockIdx.y;
+  const uint32_t par = J->par;
+  const RankBufs rb = ld_const(&E->rb);
+  front_body(ld_const(&E->tab), ld_const(&J->P), n_vis_wg, ld_const(&E->cand[par]), cand_parts, rb.req,
+             rb.req_cap, E->slow, E->slow_cap, E->vis, E->seg_cap, ld_const(&E->pool),
+             ld_const(&E->cb), E->ctl, par, [&]() { return make_cand_job(E, nxt + blockIdx.y, ag); },
+             role_lds);
+}
 
 // The serial bookkeeping of a frame in its steady-state shape (few deletes, few requests, no chained
 // buckets involved): carve_finalize of the previous frame + alloc_rank_role of this one, fused so that
@@ -108,7 +172,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
     int32_t nf = nf0;
     nf += (int32_t)carve_finalize(tab, pool, cb, ctl, Fp, stats, nf, scratch);
     alloc_rank_role(tab, rb.req, rb.req_cap, rb.req_k, rb.slow, rb.slow_cap, rb.xlocks, rb.distinct,
-                    rb.bitmap, rb.summary, rb.prefix, rb.nwords, ctl, F, nf, skeys);
+                    rb.bitmap, rb.summary, rb.prefix, rb.nwords, rb.sort_scratch, ctl, F, nf, skeys);
     return;
   }
 
@@ -208,6 +272,65 @@ __global__ __launch_bounds__(1024) void k_alloc_rank(Table tab, Pool pool, RankB
   // the frame's candidate lists have been consumed by k_front: empty them for the frame after next
   if (cand_count && threadIdx.x < kCandSegs) cand_count[threadIdx.x * kCandCountStride] = 0;
   serial_frame_role(tab, pool, rb, cb, ctl, par, stats, skeys);
+}
+
+// several engines: the serial workgroups of all of them run side by side (one per blockIdx.y)
+__global__ __launch_bounds__(1024) void k_alloc_rank_g(EnginePtr engs, JobPtr cur, JobPtr nxt,
+                                                       AheadGeom ag) {
+  EnginePtr E = engs + blockIdx.y;
+  if (blockIdx.x != 0) {
+    __shared__ CandLds L;
+    const CandJob ahead = make_cand_job(E, nxt + blockIdx.y, ag);
+    cand_pixels_role(ahead, blockIdx.x - 1, E->ctl, L);
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+  const uint32_t par = cur[blockIdx.y].par;
+  uint32_t* cand_count = E->cand[par].count;
+  if (threadIdx.x < kCandSegs) cand_count[threadIdx.x * kCandCountStride] = 0;
+  RankBufs rb = ld_const(&E->rb);
+  const FrameParams P = ld_const(&cur[blockIdx.y].P);
+  rb.nwords = ((uint32_t)(P.W * P.H) * (uint32_t)P.S + 31u) / 32u;
+  serial_frame_role(ld_const(&E->tab), ld_const(&E->pool), rb, ld_const(&E->cb), E->ctl, par, E->stats,
+                    skeys);
+}
+
+// first frame of a batch, several engines: its candidate pass as a launch of its own
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cand_g(EnginePtr engs,
+                                                                                     JobPtr cur,
+                                                                                     AheadGeom ag) {
+  __shared__ CandLds L;
+  EnginePtr E = engs + blockIdx.y;
+  const CandJob job = make_cand_job(E, cur + blockIdx.y, ag);
+  cand_pixels_role(job, blockIdx.x, E->ctl, L);
+}
+
+// voxel update of several engines (kernels_integrate.h: integrate_body)
+template <int VPL>
+__global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate_g(
+    EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_int_wg, AheadGeom ag) {
+  __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
+  EnginePtr E = engs + blockIdx.y;
+  if (blockIdx.x >= n_int_wg) {
+    if (VPL != 1) {
+      const CandJob ahead = make_cand_job(E, nxt + blockIdx.y, ag);
+      cand_pixels_role(ahead, blockIdx.x - n_int_wg, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
+    }
+    return;
+  }
+  JobPtr J = cur + blockIdx.y;
+  const uint32_t par = J->par;
+  IntegArgs A;
+  A.rgbw = E->pool.rgbw;
+  A.tsdf = E->pool.tsdf;
+  A.segm = E->pool.segm;
+  A.texA = E->texA[par];
+  A.texB = E->texB[par];
+  A.vis = E->vis;
+  A.seg_cap = E->seg_cap;
+  A.F = &E->ctl->fr[par];
+  A.upd_wg = E->cb.upd_wg;
+  integrate_body<VPL>(A, ld_const(&J->P), E, n_int_wg, role_lds);
 }
 
 }  // namespace ratsdf

@@ -293,15 +293,10 @@ struct IntegArgs {
 // candidate pass (`ahead`, kernels_cand.h): the update is bound by memory latency and leaves the
 // vector ALUs mostly idle, the candidate pass is ALU work on other inputs.
 template <int VPL>
-__global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
-    IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, CandJob ahead) {
+__device__ inline void integrate_body(const IntegArgs& A, const FrameParams& P, EnginePtr E,
+                                      uint32_t n_int_wg, uint32_t* role_lds) {
   constexpr int WPB = 8 / VPL;  // waves per voxel block
   constexpr int BPW = VPL == 1 ? 1 : 4 / WPB;  // voxel blocks per workgroup (256 threads; 512 for VPL 1)
-  __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
-  if (blockIdx.x >= n_int_wg) {
-    if (VPL != 1) cand_pixels_role(ahead, blockIdx.x - n_int_wg, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
-    return;
-  }
   float (*smin)[8] = reinterpret_cast<float (*)[8]>(role_lds);
   uint32_t (*supd)[8] = reinterpret_cast<uint32_t (*)[8]>(role_lds + 16);
   FrameCtl* F = A.F;
@@ -385,6 +380,17 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgp
 #endif
     finish_block<WPB>(E, F, A.upd_wg, item, active, m, nupd, wv, part, lane, i & 1u, smin, supd);
   }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
+    IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, CandJob ahead) {
+  __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
+  if (blockIdx.x >= n_int_wg) {
+    if (VPL != 1) cand_pixels_role(ahead, blockIdx.x - n_int_wg, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
+    return;
+  }
+  integrate_body<VPL>(A, P, E, n_int_wg, role_lds);
 }
 
 }  // namespace ratsdf

@@ -29,6 +29,23 @@ using namespace ratsdf;
     }                                                                                     \
   } while (0)
 
+// Scoped "current device" of the calling thread: HIP's current device is per thread and defaults to
+// 0, so every entry point that allocates or launches selects the engine's device first and restores
+// the caller's on the way out.
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DeviceGuard(int device) {
+    if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device)
+      changed = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 namespace {
 
 __global__ void k_init_table(Entry* entries, uint32_t* claim, unsigned long long* occ,
@@ -93,6 +110,7 @@ struct ratsdf_engine {
   SlowRequest* slow = nullptr;
   XLock* xlocks = nullptr;
   SlowRequest* distinct = nullptr;
+  unsigned long long* sort_scratch = nullptr;  // resolver's sort keys beyond the LDS capacity
 
   // directory-sized scratch
   unsigned long long* masks = nullptr;  // selection / visibility mask, one bit per directory entry
@@ -151,6 +169,11 @@ struct ratsdf_engine {
   int sticky();
   int drain_profile();
   FrameParams base_params() const;
+  struct Geom {
+    unsigned n_vis_wg, parts, n_front_wg, n_cand_wg, grid;
+    AheadGeom a, b, c;  // look-ahead shares of k_front, k_alloc_rank, k_integrate
+  };
+  Geom geometry(int H, int W, bool has_next, int split_a, int split_b) const;
 };
 
 FrameParams ratsdf_engine::base_params() const {
@@ -179,7 +202,7 @@ int ratsdf_engine::free_all() {
                   d_stats, d_eng, texA[0], texA[1], texB[0], texB[1], cand[0].list, cand[1].list, cand_count,
                   req, req_k, win_ranks, abitmap, asummary, aprefix,
                   slow, xlocks,
-                  distinct, masks, wg_count, vis, del_list, upd_wg, tab.dclaim, dbitmap, dsummary, dprefix,
+                  distinct, sort_scratch, masks, wg_count, vis, del_list, upd_wg, tab.dclaim, dbitmap, dsummary, dprefix,
                   slowdel, d_stage, d_mc};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -210,6 +233,7 @@ RankBufs ratsdf_engine::rank_bufs(uint32_t nranks) const {
   rb.summary = asummary;
   rb.prefix = aprefix;
   rb.nwords = (nranks + 31) / 32;
+  rb.sort_scratch = sort_scratch;
   return rb;
 }
 
@@ -329,7 +353,7 @@ int ratsdf_engine::alloc_rank(uint32_t nranks, unsigned par, const CandJob* next
   const unsigned extra = job.n_tiles ? (job.n_tiles + job.tiles_per_wg - 1) / job.tiles_per_wg : 0;
   const RankBufs rb = rank_bufs(nranks);
   hipLaunchKernelGGL(k_alloc_rank, dim3(1 + extra), dim3(1024),
-                     kSlowSortCap * sizeof(unsigned long long), stream, tab, pool, rb, carve_bufs(), ctl,
+                     kSerialLdsBytes, stream, tab, pool, rb, carve_bufs(), ctl,
                      (uint32_t)par, d_stats, frame ? cand[par].count : (uint32_t*)nullptr, job);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
@@ -394,6 +418,49 @@ CandJob ratsdf_engine::cand_job(const FrameIn& in, const FrameParams& P, unsigne
   return j;
 }
 
+// Launch geometry of a frame: workgroup counts and the split of the NEXT frame's candidate pass over
+// this frame's three launches (percent in k_front and in k_alloc_rank; the rest rides in k_integrate).
+ratsdf_engine::Geom ratsdf_engine::geometry(int H, int W, bool has_next, int split_a,
+                                            int split_b) const {
+  Geom g;
+  memset(&g, 0, sizeof(g));
+  const size_t npix = (size_t)H * W;
+  const uint32_t tiles_x = (uint32_t)((W + 15) / 16);
+  const uint32_t tiles = tiles_x * (uint32_t)((H + 15) / 16) * 4u;
+  g.n_cand_wg = (tiles + 3) / 4;
+  g.a.tiles_x = g.b.tiles_x = g.c.tiles_x = tiles_x;
+  g.a.tiles_per_wg = g.b.tiles_per_wg = g.c.tiles_per_wg = 4;
+  if (has_next) {
+    // k_front and k_integrate take whole 16x16 super-tiles (4 tiles per 256-thread workgroup)
+    const uint32_t tiles_a = (uint32_t)((uint64_t)(tiles / 4) * (unsigned)split_a / 100) * 4;
+    uint32_t tiles_b = (uint32_t)((uint64_t)(tiles / 4) * (unsigned)split_b / 100) * 4;
+    if (split_a + split_b >= 100 || tiles_a + tiles_b > tiles) tiles_b = tiles - tiles_a;
+    g.a.n_tiles = tiles_a;
+    g.b.first_tile = tiles_a;
+    g.b.n_tiles = tiles_b;
+    // k_alloc_rank runs 1024-thread workgroups; a look-ahead workgroup uses as many of its 16 waves
+    // as it needs to cover its tiles
+    const uint32_t tpw = (tiles_b + cand_wgs - 1) / cand_wgs;
+    g.b.tiles_per_wg = std::min<uint32_t>(std::max<uint32_t>(tpw, 1u), 16u);
+    g.c.first_tile = tiles_a + tiles_b;
+    g.c.n_tiles = tiles - tiles_a - tiles_b;
+  }
+  g.n_vis_wg = (nwg + kVisWordsPerLane - 1) / kVisWordsPerLane;
+  // consumer workgroups per candidate list: every 16x16 super-tile reserves kCandReserve entries
+  // (one pass of 256 lanes per consumer when nothing overflows); finer voxels need more
+  const unsigned supers = ((unsigned)W + 15) / 16 * (((unsigned)H + 15) / 16);
+  unsigned parts = (supers * kCandReserve / kCandSegs + 255) / 256;
+  if (vs < 0.004f) parts *= 2;
+  parts = std::min(std::max(parts, 1u), 32u);
+  if (cand_parts_env) parts = cand_parts_env;
+  g.parts = parts;
+  g.n_front_wg = g.n_vis_wg + kCandSegs * parts + kReleaseWGs + (g.a.n_tiles + 3) / 4;
+  // more workgroups for images with several times more visible blocks than 640x480 (measured:
+  // 1280x720 / 2 mm runs 6 % faster with 8192)
+  g.grid = grid_from_env ? integrate_grid : (npix >= 600000 ? 8192u : 4096u);
+  return g;
+}
+
 // One frame.  `next` (same image size) is the frame the caller will integrate right after this one,
 // if it already knows it: its candidate pass then rides in this frame's single-workgroup kernels.
 int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, float md) {
@@ -408,6 +475,11 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     const CandJob job = cand_job(cur, P, par);
     hipLaunchKernelGGL(k_cand, dim3((job.n_tiles + 3) / 4), dim3(256), 0, stream, job, ctl);
   }
+  // share of k_front: 60 % at 640x480; larger images leave k_alloc_rank's 1024-thread workgroups
+  // more than one round of tiles, so k_front takes more (measured at 1280x720)
+  const int split = (int)(cand_split_env ? cand_split : (npix >= 600000 ? 80u : cand_split));
+  const int split_b = (int)(cand_split_env ? cand_split_b : 100u - (unsigned)split);
+  const Geom g = geometry(H, W, next != nullptr, split, split_b);
   // shares of the next frame's candidate pass: k_front, k_alloc_rank, k_integrate
   CandJob ahead_a, ahead_b, ahead_c;
   memset(&ahead_a, 0, sizeof(ahead_a));
@@ -418,42 +490,21 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     ahead_a = cand_job(*next, Pn, par ^ 1u);
     ahead_b = ahead_a;
     ahead_c = ahead_a;
-    // k_front and k_integrate take whole 16x16 super-tiles (4 tiles per 256-thread workgroup)
-    const uint32_t tiles = ahead_a.n_tiles;
-    // share of k_front: 60 % at 640x480; larger images leave k_alloc_rank's 1024-thread workgroups
-    // (one per CU) more than one round of tiles, so k_front takes more (measured at 1280x720)
-    const unsigned split = cand_split_env ? cand_split : (npix >= 600000 ? 80u : cand_split);
-    const unsigned split_b = cand_split_env ? cand_split_b : 100u - split;
-    const uint32_t tiles_a = (uint32_t)((uint64_t)(tiles / 4) * split / 100) * 4;
-    uint32_t tiles_b = (uint32_t)((uint64_t)(tiles / 4) * split_b / 100) * 4;
-    if (split + split_b >= 100u || tiles_a + tiles_b > tiles) tiles_b = tiles - tiles_a;
-    ahead_a.n_tiles = tiles_a;
-    ahead_a.tiles_per_wg = 4;
-    ahead_b.first_tile = tiles_a;
-    ahead_b.n_tiles = tiles_b;
-    // k_alloc_rank runs 1024-thread workgroups, about one per CU; a look-ahead workgroup uses as
-    // many of its 16 waves as it needs to cover its tiles
-    const uint32_t tpw = (ahead_b.n_tiles + cand_wgs - 1) / cand_wgs;
-    ahead_b.tiles_per_wg = std::min<uint32_t>(std::max<uint32_t>(tpw, 1u), 16u);
-    ahead_c.first_tile = tiles_a + tiles_b;
-    ahead_c.n_tiles = tiles - tiles_a - tiles_b;
-    ahead_c.tiles_per_wg = 4;
+    auto set = [](CandJob& j, const AheadGeom& ag) {
+      j.first_tile = ag.first_tile;
+      j.n_tiles = ag.n_tiles;
+      j.tiles_per_wg = ag.tiles_per_wg;
+    };
+    set(ahead_a, g.a);
+    set(ahead_b, g.b);
+    set(ahead_c, g.c);
   }
   parity = par ^ 1u;
   cand_ready = next != nullptr;
 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
-  const unsigned extra_a = (ahead_a.n_tiles + 3) / 4;
-  const unsigned n_vis_wg = (nwg + kVisWordsPerLane - 1) / kVisWordsPerLane;
-  // consumer workgroups per candidate list: every 16x16 super-tile reserves kCandReserve entries
-  // (one pass of 256 lanes per consumer when nothing overflows); finer voxels need more
-  const unsigned supers = ((unsigned)W + 15) / 16 * (((unsigned)H + 15) / 16);
-  unsigned parts = (supers * kCandReserve / kCandSegs + 255) / 256;
-  if (vs < 0.004f) parts *= 2;
-  parts = std::min(std::max(parts, 1u), 32u);
-  if (cand_parts_env) parts = cand_parts_env;
-  hipLaunchKernelGGL(k_front, dim3(n_vis_wg + kCandSegs * parts + kReleaseWGs + extra_a), dim3(256), 0,
-                     stream, tab, P, n_vis_wg, cand[par], (uint32_t)parts, req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(),
+  hipLaunchKernelGGL(k_front, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
+                     (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(),
                      ctl, (uint32_t)par, ahead_a);
   st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
   if (st != RATSDF_OK) return st;
@@ -471,9 +522,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     ev1 = prof_events[prof_used].second;
     ++prof_used;
   }
-  // more workgroups for images with several times more visible blocks than 640x480 (measured:
-  // 1280x720 / 2 mm runs 6 % faster with 8192)
-  if (!grid_from_env) integrate_grid = npix >= 600000 ? 8192u : 4096u;
+  const unsigned integrate_grid = g.grid;
   // hipExtLaunchKernelGGL attaches the two events to the dispatch itself: their difference is the
   // kernel's own start-to-end time (what rocprofv3 reports), without the barrier packets that
   // hipEventRecord before / after a launch would add (~3 us here).  Null events = a plain launch.
@@ -539,7 +588,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RATSDF_ERR_NO_DEVICE;
   if (cfg->device < 0 || cfg->device >= ndev) return RATSDF_ERR_BAD_ARGUMENT;
-  HIPCHK(hipSetDevice(cfg->device));
+  DeviceGuard guard(cfg->device);  // the caller's current device is restored on return
   ratsdf_engine* e = new (std::nothrow) ratsdf_engine();
   if (!e) return RATSDF_ERR_DEVICE;
   e->device = cfg->device;
@@ -618,6 +667,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->slow, (size_t)kSlowCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->xlocks, (size_t)kXLockCap * sizeof(XLock)));
   CREATE_CHK(hipMalloc(&e->distinct, (size_t)kSlowDistinctCap * sizeof(SlowRequest)));
+  CREATE_CHK(hipMalloc(&e->sort_scratch, (size_t)kSlowSortCap * sizeof(unsigned long long)));
   CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * kVisWG * 8));
   CREATE_CHK(hipMalloc(&e->wg_count, (size_t)e->nwg * 4));
   e->seg_cap = (uint32_t)t.num_block;              // any list can hold every block
@@ -652,9 +702,6 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
                      e->pool.heap, t.num_block);
   const int32_t nf = t.num_block;
   CREATE_CHK(hipMemcpyAsync(&e->ctl->num_free, &nf, 4, hipMemcpyHostToDevice, e->stream));
-  CREATE_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_alloc_rank),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 kSlowSortCap * (int)sizeof(unsigned long long)));
   CREATE_CHK(hipStreamSynchronize(e->stream));
   CREATE_CHK(hipGetLastError());
   if (e->upload_record() != RATSDF_OK) {
@@ -677,8 +724,8 @@ int ratsdf_create(float voxel_size, float truncation, int device, ratsdf_engine*
 }
 
 int ratsdf_destroy(ratsdf_engine* e) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
-  (void)hipSetDevice(e->device);
   e->free_all();
   delete e;
   return RATSDF_OK;
@@ -687,6 +734,7 @@ int ratsdf_destroy(ratsdf_engine* e) {
 int ratsdf_integrate_device(ratsdf_engine* e, const void* d_rgb, const void* d_depth,
                             const void* d_ht, const void* d_lt, int height, int width,
                             float max_depth, const ratsdf_intrinsics* K, const ratsdf_pose* T) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !d_rgb || !d_depth || !K || !T || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   if (!d_ht || !d_lt) d_ht = d_lt = nullptr;
@@ -698,6 +746,7 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
                                   const void* const* d_depth, const void* const* d_ht,
                                   const void* const* d_lt, int height, int width, float max_depth,
                                   const ratsdf_intrinsics* K, const ratsdf_pose* T) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || n < 0 || (n > 0 && (!d_rgb || !d_depth || !K || !T)) || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   for (int i = 0; i < n; ++i)
@@ -721,6 +770,7 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
 int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, const float* ht,
                      const float* lt, int height, int width, float max_depth,
                      const ratsdf_intrinsics* K, const ratsdf_pose* T) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !rgb || !depth || !K || !T || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   if (!ht || !lt) ht = lt = nullptr;  // modules/tsdf_module.cc:27-31
@@ -748,6 +798,7 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
                            const float* const* depth, const float* const* ht,
                            const float* const* lt, int height, int width, float max_depth,
                            const ratsdf_intrinsics* K, const ratsdf_pose* T, int pinned) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || n < 0 || (n > 0 && (!rgb || !depth || !K || !T)) || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   for (int i = 0; i < n; ++i)
@@ -820,18 +871,21 @@ int ratsdf_host_free(void* p) {
 }
 
 int ratsdf_synchronize(ratsdf_engine* e) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   return e->sticky();
 }
 
 int ratsdf_stream(ratsdf_engine* e, void** out) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   *out = (void*)e->stream;
   return RATSDF_OK;
 }
 
 int ratsdf_profile_enable(ratsdf_engine* e, int enable) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   const int st = e->drain_profile();
   e->profiling = enable != 0;
@@ -839,6 +893,7 @@ int ratsdf_profile_enable(ratsdf_engine* e, int enable) {
 }
 
 int ratsdf_profile_read(ratsdf_engine* e, double* ms, int64_t* launches) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   const int st = e->drain_profile();
   if (ms) *ms = e->prof_ms;
@@ -849,6 +904,7 @@ int ratsdf_profile_read(ratsdf_engine* e, double* ms, int64_t* launches) {
 }
 
 int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int32_t nf = 0;
@@ -859,6 +915,7 @@ int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out) {
 }
 
 int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   HIPCHK(hipMemcpyAsync(out, e->d_stats, sizeof(*out), hipMemcpyDeviceToHost, e->stream));
@@ -868,6 +925,7 @@ int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
 
 // diagnostic: per-wave stamps of the LAST k_integrate launch (stamps build only)
 extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
+  DeviceGuard guard(e ? e->device : -1);
   static unsigned long long* buf = nullptr;
   const size_t n = 16384 * 8;
   if (enable) {
@@ -929,6 +987,7 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
 
 // diagnostic: prints the accumulated phase stamps of the single-workgroup kernels (stamps build only)
 extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
+  DeviceGuard guard(e ? e->device : -1);
   unsigned long long t[32];
   unsigned long long tot[5];
   HIPCHK(hipMemcpyAsync(t, e->ctl->stamps, sizeof(t), hipMemcpyDeviceToHost, e->stream));
@@ -949,6 +1008,7 @@ extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
 }
 
 int ratsdf_totals(ratsdf_engine* e, int64_t* out5, int reset) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   unsigned long long t[5] = {0, 0, 0, 0, 0};
@@ -1020,6 +1080,7 @@ static inline int16_t host_f2s(float f) {  // static_cast<short>, BoundingCube::
 }
 
 int ratsdf_query(ratsdf_engine* e, const ratsdf_bounds* b, ratsdf_voxel_tsdf** out, size_t* n) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !b || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   const float scale = (float)(1. / e->vs);  // volumn.Scale<short>(1. / voxel_size_), voxel_tsdf.cu:534
@@ -1031,6 +1092,7 @@ int ratsdf_query(ratsdf_engine* e, const ratsdf_bounds* b, ratsdf_voxel_tsdf** o
 }
 
 int ratsdf_gather_valid(ratsdf_engine* e, ratsdf_voxel_tsdf** out, size_t* n) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
@@ -1039,6 +1101,7 @@ int ratsdf_gather_valid(ratsdf_engine* e, ratsdf_voxel_tsdf** out, size_t* n) {
 }
 
 int ratsdf_gather_valid_semantic(ratsdf_engine* e, ratsdf_voxel_segm** out, size_t* n) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
@@ -1047,6 +1110,7 @@ int ratsdf_gather_valid_semantic(ratsdf_engine* e, ratsdf_voxel_segm** out, size
 }
 
 int ratsdf_download_all(ratsdf_engine* e, const char* path) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !path) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   ratsdf_voxel_segm* buf = nullptr;
@@ -1071,6 +1135,7 @@ int ratsdf_free_buffer(void* p) {
 
 int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
                           const ratsdf_pose* T, float max_depth, void* d_rgba, void* d_normal) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !K || !T || height <= 0 || width <= 0 || !(max_depth > 0))
     return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
@@ -1092,6 +1157,7 @@ int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int heig
 
 int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
                    const ratsdf_pose* T, float max_depth, uint8_t* rgba, uint8_t* normal) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || height <= 0 || width <= 0) return RATSDF_ERR_BAD_ARGUMENT;
   const size_t bytes = (size_t)height * width * 4;
   uint8_t* d = nullptr;
@@ -1125,6 +1191,7 @@ static int mask_positions(ratsdf_engine* e, const uint32_t* mask, size_t n, uint
 
 int ratsdf_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_vertices,
                              int32_t** indices, size_t* n_triangles, float** vertex_prob) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !vertices || !n_vertices || !indices || !n_triangles || !vertex_prob)
     return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
@@ -1201,6 +1268,7 @@ int ratsdf_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_verti
 }
 
 int ratsdf_download_all_mesh(ratsdf_engine* e, const char* vp, const char* ip, const char* pp) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !vp || !ip || !pp) return RATSDF_ERR_BAD_ARGUMENT;
   float *v = nullptr, *pr = nullptr;
   int32_t* idx = nullptr;
@@ -1229,6 +1297,7 @@ int ratsdf_download_all_mesh(ratsdf_engine* e, const char* vp, const char* ip, c
 
 int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t capacity,
                                    void* d_count) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !d_blocks || capacity < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
@@ -1249,6 +1318,7 @@ static int upload_s3(ratsdf_engine* e, const int16_t* src, int32_t n, int16_t** 
 }
 
 int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || (!bp && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return e->sticky();
@@ -1273,6 +1343,7 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
 }
 
 int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || (!bp && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   // keep the first occurrence of every position (a repeated Delete is a no-op in list order)
@@ -1302,6 +1373,7 @@ int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
 
 int ratsdf_test_retrieve(ratsdf_engine* e, const int16_t* pts, int32_t n, ratsdf_rgbw* rgbw,
                          float* tsdf, float* prob, ratsdf_block* blocks) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || (!pts && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return RATSDF_OK;
@@ -1330,6 +1402,7 @@ int ratsdf_test_retrieve(ratsdf_engine* e, const int16_t* pts, int32_t n, ratsdf
 
 int ratsdf_test_assign_rgbw(ratsdf_engine* e, const int16_t* pts, const ratsdf_rgbw* vals,
                             int32_t n) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || ((!pts || !vals) && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return RATSDF_OK;
@@ -1349,6 +1422,7 @@ int ratsdf_test_assign_rgbw(ratsdf_engine* e, const int16_t* pts, const ratsdf_r
 
 int ratsdf_dump_directory(ratsdf_engine* e, int32_t** entry_index, ratsdf_block** blocks,
                           size_t* n) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || !entry_index || !blocks || !n) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
@@ -1379,6 +1453,7 @@ int ratsdf_dump_directory(ratsdf_engine* e, int32_t** entry_index, ratsdf_block*
 
 int ratsdf_dump_voxels(ratsdf_engine* e, const int32_t* pool_idx, int32_t n, float* tsdf,
                        ratsdf_rgbw* rgbw, float* prob) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e || (!pool_idx && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return RATSDF_OK;
@@ -1402,6 +1477,7 @@ int ratsdf_dump_voxels(ratsdf_engine* e, const int32_t* pool_idx, int32_t n, flo
 }
 
 int ratsdf_dump_heap(ratsdf_engine* e, int32_t* num_free, int32_t* heap) {
+  DeviceGuard guard(e ? e->device : -1);
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (num_free)
@@ -1426,5 +1502,302 @@ const char* ratsdf_status_string(int s) {
   }
 }
 const char* ratsdf_backend(void) { return "hip-gfx950"; }
+
+}  // extern "C"
+
+// ================================== groups =====================================================
+// Several engines (maps) of one device stepped together: frame i of every member stream goes through
+// ONE k_front / k_alloc_rank / k_integrate triple whose grids have one slice per engine (blockIdx.y).
+// A single 640x480 frame leaves most of the chip waiting on memory round trips and launch ramps; S
+// frames per launch fill it.  Operands come from device tables: the engine records (device_types.h:
+// EngineDev) and a per-batch table of FrameJob {parameters, image pointers, parity} per frame and slot.
+struct ratsdf_group {
+  int device = 0;
+  int S = 0;
+  std::vector<ratsdf_engine*> eng;
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> ev_member;  // member stream -> group stream
+  hipEvent_t ev_done = nullptr;       // group stream -> member streams
+  EngineDev* d_engs = nullptr;
+  FrameJob* d_jobs = nullptr;
+  size_t jobs_cap = 0;
+  // page-locked staging of the tables, two of each, used alternately (a copy may still be pending
+  // when the next batch is being prepared)
+  EngineDev* h_engs[2] = {nullptr, nullptr};
+  FrameJob* h_jobs[2] = {nullptr, nullptr};
+  size_t h_jobs_cap = 0;
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
+  unsigned batch_no = 0;
+  int split_a = 100, split_b = 0;  // look-ahead share of k_front / k_alloc_rank (rest: k_integrate)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  uint64_t prof_frame = 0;
+  double prof_ms = 0;
+  int64_t prof_n = 0;
+
+  int drain_profile() {
+    if (!prof_used) return RATSDF_OK;
+    HIPCHK(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < prof_used; ++i) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, prof_events[i].first, prof_events[i].second));
+      prof_ms += ms;
+      ++prof_n;
+    }
+    prof_used = 0;
+    return RATSDF_OK;
+  }
+  void free_all() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (d_engs) (void)hipFree(d_engs);
+    if (d_jobs) (void)hipFree(d_jobs);
+    for (int i = 0; i < 2; ++i) {
+      if (h_engs[i]) (void)hipHostFree(h_engs[i]);
+      if (h_jobs[i]) (void)hipHostFree(h_jobs[i]);
+      if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]);
+    }
+    for (auto& ev : ev_member)
+      if (ev) (void)hipEventDestroy(ev);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+    for (auto& ev : prof_events) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+extern "C" {
+
+int ratsdf_group_create(ratsdf_engine* const* engines, int n, ratsdf_group** out) {
+  if (!engines || !out || n < 1 || n > 64) return RATSDF_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < n; ++i) {
+    const ratsdf_engine* a = engines[i];
+    if (!a) return RATSDF_ERR_BAD_ARGUMENT;
+    const ratsdf_engine* b = engines[0];
+    // one launch geometry for all members
+    if (a->device != b->device || a->vs != b->vs || a->trunc != b->trunc ||
+        a->block_bits != b->block_bits || a->bucket_bits != b->bucket_bits || a->vpl != b->vpl)
+      return RATSDF_ERR_BAD_ARGUMENT;
+    for (int j = 0; j < i; ++j)
+      if (engines[j] == a) return RATSDF_ERR_BAD_ARGUMENT;
+  }
+  DeviceGuard guard(engines[0]->device);
+  ratsdf_group* g = new (std::nothrow) ratsdf_group();
+  if (!g) return RATSDF_ERR_DEVICE;
+  g->device = engines[0]->device;
+  g->S = n;
+  g->eng.assign(engines, engines + n);
+  g->ev_member.assign((size_t)n, nullptr);
+  if (const char* v = getenv("RATSDF_GROUP_SPLIT")) {  // "a[,b]" like RATSDF_CAND_SPLIT
+    const int x = atoi(v);
+    if (x >= 0 && x <= 100) {
+      g->split_a = x;
+      g->split_b = 0;
+      if (const char* c = strchr(v, ',')) {
+        const int y = atoi(c + 1);
+        if (y >= 0 && x + y <= 100) g->split_b = y;
+      }
+    }
+  }
+#define GROUP_CHK(expr)                                                  \
+  do {                                                                   \
+    if ((expr) != hipSuccess) {                                          \
+      fprintf(stderr, "[ratsdf] group create failed: %s\n", #expr);      \
+      g->free_all();                                                     \
+      delete g;                                                          \
+      return RATSDF_ERR_DEVICE;                                          \
+    }                                                                    \
+  } while (0)
+  GROUP_CHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+  GROUP_CHK(hipMalloc(&g->d_engs, (size_t)n * sizeof(EngineDev)));
+  for (int i = 0; i < 2; ++i) {
+    GROUP_CHK(hipHostMalloc(&g->h_engs[i], (size_t)n * sizeof(EngineDev), hipHostMallocDefault));
+    GROUP_CHK(hipEventCreateWithFlags(&g->ev_stage[i], hipEventDisableTiming));
+  }
+  for (int i = 0; i < n; ++i)
+    GROUP_CHK(hipEventCreateWithFlags(&g->ev_member[(size_t)i], hipEventDisableTiming));
+  GROUP_CHK(hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming));
+#undef GROUP_CHK
+  *out = g;
+  return RATSDF_OK;
+}
+
+int ratsdf_group_destroy(ratsdf_group* g) {
+  if (!g) return RATSDF_ERR_BAD_ARGUMENT;
+  DeviceGuard guard(g->device);
+  g->free_all();
+  delete g;
+  return RATSDF_OK;
+}
+
+int ratsdf_group_size(ratsdf_group* g, int32_t* out) {
+  if (!g || !out) return RATSDF_ERR_BAD_ARGUMENT;
+  *out = g->S;
+  return RATSDF_OK;
+}
+
+// Frame f of member s is element [f * S + s] of every array.
+int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* const* d_rgb,
+                                        const void* const* d_depth, const void* const* d_ht,
+                                        const void* const* d_lt, int height, int width,
+                                        float max_depth, const ratsdf_intrinsics* K,
+                                        const ratsdf_pose* T) {
+  if (!g || n < 0 || (n > 0 && (!d_rgb || !d_depth || !K || !T)) || height <= 0 || width <= 0)
+    return RATSDF_ERR_BAD_ARGUMENT;
+  if (n == 0) return RATSDF_OK;
+  const int S = g->S;
+  const size_t npix = (size_t)height * width;
+  for (size_t i = 0; i < (size_t)n * S; ++i)
+    if (!d_rgb[i] || !d_depth[i]) return RATSDF_ERR_BAD_ARGUMENT;
+  DeviceGuard guard(g->device);
+  ratsdf_engine* e0 = g->eng[0];
+  if (npix * (size_t)e0->S >= 0xFFFFFFFFull) return RATSDF_ERR_BAD_ARGUMENT;
+  for (ratsdf_engine* e : g->eng) {
+    if (e->cand_ready) return RATSDF_ERR_BAD_ARGUMENT;  // cannot happen between complete calls
+    const int st = e->ensure_image(npix, npix * (size_t)e->S);
+    if (st != RATSDF_OK) return st;
+  }
+  // ---- tables ----
+  const unsigned slot = g->batch_no++ & 1u;
+  const size_t njobs = (size_t)n * S;
+  if (njobs > g->jobs_cap) {
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (g->d_jobs) (void)hipFree(g->d_jobs);
+    g->d_jobs = nullptr;
+    g->jobs_cap = 0;
+    HIPCHK(hipMalloc(&g->d_jobs, njobs * sizeof(FrameJob)));
+    g->jobs_cap = njobs;
+  }
+  if (njobs > g->h_jobs_cap) {
+    HIPCHK(hipStreamSynchronize(g->stream));
+    for (int i = 0; i < 2; ++i) {
+      if (g->h_jobs[i]) (void)hipHostFree(g->h_jobs[i]);
+      g->h_jobs[i] = nullptr;
+      HIPCHK(hipHostMalloc(&g->h_jobs[i], njobs * sizeof(FrameJob), hipHostMallocDefault));
+    }
+    g->h_jobs_cap = njobs;
+  }
+  HIPCHK(hipEventSynchronize(g->ev_stage[slot]));  // the copy that last used this staging pair is done
+  for (int s = 0; s < S; ++s) g->h_engs[slot][s] = g->eng[(size_t)s]->record();
+  FrameJob* hj = g->h_jobs[slot];
+  for (int f = 0; f < n; ++f)
+    for (int s = 0; s < S; ++s) {
+      const size_t i = (size_t)f * S + s;
+      ratsdf_engine* e = g->eng[(size_t)s];
+      const void* ht = (d_ht && d_lt) ? d_ht[i] : nullptr;
+      const void* lt = (d_ht && d_lt) ? d_lt[i] : nullptr;
+      if (!ht || !lt) ht = lt = nullptr;
+      const ratsdf_engine::FrameIn in{d_rgb[i], d_depth[i], ht, lt, &K[i], &T[i]};
+      FrameJob& j = hj[i];
+      j.P = e->frame_params(in, height, width, max_depth);
+      j.depth = (const float*)in.depth;
+      j.rgb = (const uint8_t*)in.rgb;
+      j.ht = (const float*)in.ht;
+      j.lt = (const float*)in.lt;
+      j.par = (e->parity + (unsigned)f) & 1u;
+      j.pad = 0;
+    }
+  // ---- ordering with the members' own streams (queries, single-engine frames) ----
+  for (int s = 0; s < S; ++s) {
+    HIPCHK(hipEventRecord(g->ev_member[(size_t)s], g->eng[(size_t)s]->stream));
+    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_member[(size_t)s], 0));
+  }
+  HIPCHK(hipMemcpyAsync(g->d_engs, g->h_engs[slot], (size_t)S * sizeof(EngineDev),
+                        hipMemcpyHostToDevice, g->stream));
+  HIPCHK(hipMemcpyAsync(g->d_jobs, hj, njobs * sizeof(FrameJob), hipMemcpyHostToDevice, g->stream));
+  HIPCHK(hipEventRecord(g->ev_stage[slot], g->stream));
+
+  // ---- launches ----
+  EnginePtr engs = (EnginePtr)g->d_engs;
+  const ratsdf_engine::Geom g1 = e0->geometry(height, width, true, g->split_a, g->split_b);
+  const ratsdf_engine::Geom g0 = e0->geometry(height, width, false, 0, 0);
+  {  // nobody looked ahead for the first frame: its candidate pass runs in line
+    AheadGeom all = g0.a;
+    all.first_tile = 0;
+    all.n_tiles = g0.n_cand_wg * 4;
+    hipLaunchKernelGGL(k_cand_g, dim3(g0.n_cand_wg, S), dim3(256), 0, g->stream, engs,
+                       (JobPtr)g->d_jobs, all);
+  }
+  for (int f = 0; f < n; ++f) {
+    const bool has_next = f + 1 < n;
+    const ratsdf_engine::Geom& gg = has_next ? g1 : g0;
+    JobPtr cur = (JobPtr)(g->d_jobs + (size_t)f * S);
+    JobPtr nxt = (JobPtr)(g->d_jobs + (size_t)(has_next ? f + 1 : f) * S);
+    hipLaunchKernelGGL(k_front_g, dim3(gg.n_front_wg, S), dim3(256), 0, g->stream, engs, cur, nxt,
+                       (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, gg.a);
+    const unsigned extra_b = gg.b.n_tiles ? (gg.b.n_tiles + gg.b.tiles_per_wg - 1) / gg.b.tiles_per_wg : 0;
+    hipLaunchKernelGGL(k_alloc_rank_g, dim3(1 + extra_b, S), dim3(1024), kSerialLdsBytes, g->stream,
+                       engs, cur, nxt, gg.b);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g->profiling && (g->prof_frame++ % 4 == 0)) {
+      if (g->prof_used == g->prof_events.size()) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        g->prof_events.emplace_back(a, b);
+      }
+      ev0 = g->prof_events[g->prof_used].first;
+      ev1 = g->prof_events[g->prof_used].second;
+      ++g->prof_used;
+    }
+    const unsigned extra_c = (gg.c.n_tiles + 3) / 4;
+#define RATSDF_LAUNCH_INTEGRATE_G(V, NT)                                                            \
+  hipExtLaunchKernelGGL(k_integrate_g<V>, dim3(gg.grid + extra_c, S), dim3(NT), 0, g->stream, ev0,  \
+                        ev1, 0, engs, cur, nxt, (uint32_t)gg.grid, gg.c)
+    switch (e0->vpl) {
+      case 1: RATSDF_LAUNCH_INTEGRATE_G(1, 512); break;
+      case 8: RATSDF_LAUNCH_INTEGRATE_G(8, 256); break;
+      case 4: RATSDF_LAUNCH_INTEGRATE_G(4, 256); break;
+      default: RATSDF_LAUNCH_INTEGRATE_G(2, 256);
+    }
+#undef RATSDF_LAUNCH_INTEGRATE_G
+    if (g->profiling && g->prof_used >= 4096) {
+      const int st = g->drain_profile();
+      if (st != RATSDF_OK) return st;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(g->ev_done, g->stream));
+  for (ratsdf_engine* e : g->eng) {
+    HIPCHK(hipStreamWaitEvent(e->stream, g->ev_done, 0));
+    e->parity = (e->parity + (unsigned)n) & 1u;
+    e->cand_ready = false;
+    e->pending = true;
+  }
+  return RATSDF_OK;
+}
+
+int ratsdf_group_synchronize(ratsdf_group* g) {
+  if (!g) return RATSDF_ERR_BAD_ARGUMENT;
+  DeviceGuard guard(g->device);
+  HIPCHK(hipStreamSynchronize(g->stream));
+  int worst = RATSDF_OK;
+  for (ratsdf_engine* e : g->eng) {
+    const int st = ratsdf_synchronize(e);
+    if (st != RATSDF_OK && worst == RATSDF_OK) worst = st;
+  }
+  return worst;
+}
+
+int ratsdf_group_profile_enable(ratsdf_group* g, int enable) {
+  if (!g) return RATSDF_ERR_BAD_ARGUMENT;
+  DeviceGuard guard(g->device);
+  const int st = g->drain_profile();
+  g->profiling = enable != 0;
+  return st;
+}
+
+int ratsdf_group_profile_read(ratsdf_group* g, double* ms, int64_t* launches) {
+  if (!g) return RATSDF_ERR_BAD_ARGUMENT;
+  DeviceGuard guard(g->device);
+  const int st = g->drain_profile();
+  if (ms) *ms = g->prof_ms;
+  if (launches) *launches = g->prof_n;
+  g->prof_ms = 0;
+  g->prof_n = 0;
+  return st;
+}
 
 }  // extern "C"

@@ -7,7 +7,7 @@ import os
 from pathlib import Path
 
 from . import _abi
-from ._abi import (BLOCK_DTYPE, RGBW_DTYPE, VOXEL_SEGM_DTYPE, VOXEL_TSDF_DTYPE, Bounds, Engine,
+from ._abi import (BLOCK_DTYPE, RGBW_DTYPE, VOXEL_SEGM_DTYPE, VOXEL_TSDF_DTYPE, Bounds, Engine, Group,
                    Intrinsics, Library, Pose, RatsdfError)
 from .pose import compose, identity_pose, invert, pose_from_matrix
 
@@ -36,6 +36,6 @@ class TSDFGrid(Engine):
         super().__init__(library(), voxel_size, truncation, device=device, **kw)
 
 
-__all__ = ["TSDFGrid", "Engine", "Library", "library", "Intrinsics", "Pose", "Bounds",
+__all__ = ["TSDFGrid", "Engine", "Group", "Library", "library", "Intrinsics", "Pose", "Bounds",
            "RatsdfError", "pose_from_matrix", "compose", "invert", "identity_pose", "BLOCK_DTYPE",
            "RGBW_DTYPE", "VOXEL_TSDF_DTYPE", "VOXEL_SEGM_DTYPE", "LIB_PATH"]

@@ -70,7 +70,9 @@ SYMBOLS = [
     "profile_enable", "profile_read", "totals",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "raycast", "raycast_device", "gather_valid_mesh", "download_all_mesh",
-    "export_directory_device", "test_allocate", "test_delete",
+    "export_directory_device", "group_create", "group_destroy", "group_size",
+    "group_integrate_device_batch", "group_synchronize", "group_profile_enable", "group_profile_read",
+    "test_allocate", "test_delete",
     "test_retrieve", "test_assign_rgbw", "dump_directory", "dump_voxels", "dump_heap",
     "status_string", "backend",
 ]
@@ -126,6 +128,14 @@ class Library:
                                                  C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
         self.fn["download_all_mesh"].argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p]
         self.fn["export_directory_device"].argtypes = [vp, vp, C.c_int32, vp]
+        self.fn["group_create"].argtypes = [vp, C.c_int, C.POINTER(vp)]
+        self.fn["group_destroy"].argtypes = [vp]
+        self.fn["group_size"].argtypes = [vp, C.POINTER(C.c_int32)]
+        self.fn["group_integrate_device_batch"].argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int,
+                                                            C.c_int, C.c_float, vp, vp]
+        self.fn["group_synchronize"].argtypes = [vp]
+        self.fn["group_profile_enable"].argtypes = [vp, C.c_int]
+        self.fn["group_profile_read"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         self.fn["test_allocate"].argtypes = [vp, vp, C.c_int32]
         self.fn["test_delete"].argtypes = [vp, vp, C.c_int32]
         self.fn["test_retrieve"].argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp]
@@ -426,3 +436,55 @@ class Engine:
         heap = np.zeros(1 << self.block_bits, dtype=np.int32)
         _check(self.lib.fn["dump_heap"](self._h, C.byref(nf), heap.ctypes.data), "dump_heap")
         return nf.value, heap
+
+
+class Group:
+    """Several engines of one GPU stepped together (ratsdf_group_*): frame f of every member stream
+    goes through one launch triple.  Members stay usable on their own between group calls."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self.lib = self.engines[0].lib
+        arr = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+        h = C.c_void_p()
+        _check(self.lib.fn["group_create"](arr, len(self.engines), C.byref(h)), "group_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fn["group_destroy"](self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def make_batch(self, d_rgb, d_depth, d_ht, d_lt, height, width, max_depth, intrinsics, poses):
+        """Arguments are lists over frames of lists over members (raw device pointers, intrinsics,
+        poses); returns an opaque tuple for integrate_device_batch."""
+        n, s = len(d_rgb), len(self.engines)
+        flat = lambda rows: [v for row in rows for v in row]
+        arr = lambda rows: (C.c_void_p * (n * s))(*flat(rows)) if rows is not None else None
+        ks = (Intrinsics * (n * s))(*[_as_intr(k) for k in flat(intrinsics)])
+        ps = (Pose * (n * s))(*[_as_pose(p) for p in flat(poses)])
+        return (n, arr(d_rgb), arr(d_depth), arr(d_ht), arr(d_lt), int(height), int(width),
+                float(max_depth), ks, ps)
+
+    def integrate_device_batch(self, batch):
+        n, rgb, depth, ht, lt, h, w, md, ks, ps = batch
+        _check(self.lib.fn["group_integrate_device_batch"](self._h, n, rgb, depth, ht, lt, h, w, md,
+                                                           ks, ps), "group_integrate_device_batch")
+
+    def synchronize(self):
+        _check(self.lib.fn["group_synchronize"](self._h), "group_synchronize")
+
+    def profile_enable(self, on=True):
+        _check(self.lib.fn["group_profile_enable"](self._h, 1 if on else 0), "group_profile_enable")
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        _check(self.lib.fn["group_profile_read"](self._h, C.byref(ms), C.byref(n)),
+               "group_profile_read")
+        return ms.value, n.value

@@ -101,6 +101,45 @@ def main():
         print(json.dumps(dict(probe="streams", S=S, frames_per_s=round(nfr / dt, 1),
                               alg_gbps=round(alg / dt / 1e9, 1), frac_of_8TBs=round(alg / dt / 8e12, 4))),
               flush=True)
+    # (c) the same S streams through ONE launch triple per frame step (ratsdf_group_*)
+    for S in [int(s) for s in a.streams.split(",")]:
+        sel = engs[:S]
+        grp = ratsdf.Group([e for e, _, _, _ in sel])
+        H, W = sel[0][3]
+        fr_all = [[synthetic.frame("room", 45 * s + i, cam=cam, noise=True, holes=True) for i in range(half)]
+                  for s in range(S)]
+        fr_all = [fr + fr[::-1] for fr in fr_all]
+        rows = lambda key: [[sel[s][2][key][f].data_ptr() for s in range(S)] for f in range(a.frames)]
+        gb = grp.make_batch(rows("rgb"), rows("depth"), rows("ht"), rows("lt"), H, W, 4.0,
+                            [[fr_all[s][f]["intrinsics"] for s in range(S)] for f in range(a.frames)],
+                            [[fr_all[s][f]["pose"] for s in range(S)] for f in range(a.frames)])
+        grp.integrate_device_batch(gb)
+        grp.synchronize()
+        for e, _, _, _ in sel:
+            e.totals(reset=True)
+        grp.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            grp.integrate_device_batch(gb)
+        t1 = time.perf_counter()
+        grp.synchronize()
+        dt = time.perf_counter() - t0
+        kms, kn = grp.profile_read()
+        grp.profile_enable(False)
+        alg = 0.0
+        for e, _, _, (H, W) in sel:
+            tt = e.totals()
+            alg += 15.0 * W * H * tt["frames"] + 12.0 * tt["visible_blocks"] + 24.0 * tt["updated_voxels"]
+        nfr = S * a.steps * a.frames
+        k_us = kms / max(kn, 1) * 1e3
+        print(json.dumps(dict(probe="group", S=S, frames_per_s=round(nfr / dt, 1),
+                              us_per_step=round(dt / (a.steps * a.frames) * 1e6, 2),
+                              host_enqueue_frac=round((t1 - t0) / dt, 3),
+                              alg_gbps=round(alg / dt / 1e9, 1), frac_of_8TBs=round(alg / dt / 8e12, 4),
+                              k_integrate_us=round(k_us, 2),
+                              k_integrate_frac=round(alg / nfr * S / (k_us * 1e-6) / 8e12, 4) if kn else None)),
+              flush=True)
+        grp.close()
     for e, _, _, _ in engs:
         e.close()
 
