@@ -330,7 +330,8 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgp
   A.seg_cap = E->seg_cap;
   A.F = &E->ctl->fr[par];
   A.upd_wg = E->cb.upd_wg;
-  integrate_body<VPL>(A, ld_const(&J->P), E, n_int_wg, role_lds);
+  const FrameParams P = ld_const(&J->P);
+#include "integrate_body.inc"
 }
 
 }  // namespace ratsdf

@@ -293,96 +293,6 @@ struct IntegArgs {
 // candidate pass (`ahead`, kernels_cand.h): the update is bound by memory latency and leaves the
 // vector ALUs mostly idle, the candidate pass is ALU work on other inputs.
 template <int VPL>
-__device__ inline void integrate_body(const IntegArgs& A, const FrameParams& P, EnginePtr E,
-                                      uint32_t n_int_wg, uint32_t* role_lds) {
-  constexpr int WPB = 8 / VPL;  // waves per voxel block
-  constexpr int BPW = VPL == 1 ? 1 : 4 / WPB;  // voxel blocks per workgroup (256 threads; 512 for VPL 1)
-  float (*smin)[8] = reinterpret_cast<float (*)[8]>(role_lds);
-  uint32_t (*supd)[8] = reinterpret_cast<uint32_t (*)[8]>(role_lds + 16);
-  FrameCtl* F = A.F;
-  Pool pool;
-  pool.rgbw = A.rgbw;
-  pool.tsdf = A.tsdf;
-  pool.segm = A.segm;
-  pool.heap = nullptr;
-  const float4* texA = A.texA;
-  const uint32_t* texB = A.texB;
-  const uint32_t seg_cap = A.seg_cap;
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wv = threadIdx.x >> 6;
-  const uint32_t blk_in_wg = wv / WPB, part = wv % WPB;
-  const uint32_t vi0 = (part * 64 + lane) * VPL;  // first voxel of this lane, x + 8y + 64z
-  const uint32_t list = blockIdx.x & (kNumLists - 1);
-  const uint32_t wg_in_list = blockIdx.x / kNumLists, wgs_per_list = n_int_wg / kNumLists;
-  const VisItem* my_vis = A.vis + (size_t)list * seg_cap;
-  // the first item is fetched together with the counters (the slot exists even if the list is
-  // shorter; it is only used when in range), which takes one memory round trip off every wave
-  const uint32_t j0 = wg_in_list * BPW + blk_in_wg;
-  const VisItem first = my_vis[j0 < seg_cap ? j0 : 0];
-  uint32_t n_mine = F->n_list[list * kListStride];
-  if (n_mine > seg_cap) n_mine = seg_cap;
-  const uint32_t n_req = F->n_req;  // <= req_cap: clamped below, where the list is read
-  // One loop over the workgroup's items: first its share of the visible list, then its share of this
-  // frame's allocation requests (commit: pool index, directory entry, occupancy bit; the new block
-  // is then updated from its initial values).  A single inlined copy of the voxel update.
-  const uint32_t nv_it = wg_in_list * BPW < n_mine
-                             ? (n_mine - wg_in_list * BPW + wgs_per_list * BPW - 1) / (wgs_per_list * BPW)
-                             : 0u;
-  const uint32_t nr_it = blockIdx.x * BPW < n_req
-                             ? (n_req - blockIdx.x * BPW + n_int_wg * BPW - 1) / (n_int_wg * BPW)
-                             : 0u;
-  for (uint32_t i = 0; i < nv_it + nr_it; ++i) {
-    float m = 3.0e38f;
-    uint32_t nupd = 0;
-    VisItem item = first;
-    bool active, fresh = false;
-#ifdef RATSDF_STAMPS
-    unsigned long long* ws = (i == 0 && E->ctl->debug_buf && !RATSDF_DBG(P, 8) && !RATSDF_DBG(P, 10)) ? E->ctl->debug_buf + (size_t)((blockIdx.x * 4 + wv) & 16383) * 8 : nullptr;
-    if (ws && lane == 0) { ws[0] = (unsigned long long)clock64(); ws[5] = wall_clock64(); }
-#else
-    unsigned long long* ws = nullptr;
-#endif
-    if (i < nv_it) {  // uniform
-      const uint32_t j = (wg_in_list + i * wgs_per_list) * BPW + blk_in_wg;
-      active = j < n_mine;
-      if (active && i != 0) item = my_vis[j];
-    } else {
-      // a new block: operands of the commit come from the engine record
-      const uint32_t t = (blockIdx.x + (i - nv_it) * n_int_wg) * BPW + blk_in_wg;
-      const RankBufs rb = ld_const(&E->rb);
-      active = t < n_req && t < rb.req_cap;
-      fresh = true;
-      if (active) {
-        const Table tab = ld_const(&E->tab);
-        Pool cpool = pool;
-        cpool.heap = E->pool.heap;
-        const uint32_t n_win = F->n_win, alloc_base = F->alloc_base, n_winlist = F->n_winlist;
-        const Request r = rb.req[t];
-        uint32_t e = 0;
-        int32_t idx = -1;
-        const bool writer = part == 0 && lane == 0;
-        uint32_t k = 0;
-        if (r.flags & kReqWinner) {
-          if (n_winlist) {  // few winners: position in raster order = winners with a smaller rank
-            for (uint32_t j = lane; j < n_winlist; j += 64) k += rb.win_ranks[j] < r.rank;
-            k = wave_sum(k);
-          } else {
-            k = rb.req_k[t];
-          }
-        }
-        active = commit_request(tab, cpool, r, k, alloc_base, n_win, writer, &idx, &e);
-        item = VisItem{r.x, r.y, r.z, 0, idx, e};
-      }
-    }
-    if (active) integrate_block<VPL>(pool, P, item, fresh, vi0, texA, texB, &nupd, &m, ws);
-#ifdef RATSDF_STAMPS
-    if (ws && lane == 0) { ws[4] = (unsigned long long)clock64(); ws[6] = wall_clock64(); }
-#endif
-    finish_block<WPB>(E, F, A.upd_wg, item, active, m, nupd, wv, part, lane, i & 1u, smin, supd);
-  }
-}
-
-template <int VPL>
 __global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
     IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, CandJob ahead) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
@@ -390,7 +300,7 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgp
     if (VPL != 1) cand_pixels_role(ahead, blockIdx.x - n_int_wg, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
     return;
   }
-  integrate_body<VPL>(A, P, E, n_int_wg, role_lds);
+#include "integrate_body.inc"
 }
 
 }  // namespace ratsdf

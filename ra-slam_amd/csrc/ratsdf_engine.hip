@@ -98,6 +98,10 @@ struct ratsdf_engine {
   unsigned cand_split_b = 40;            // in k_alloc_rank; the rest rides in k_integrate
   unsigned cand_parts_env = 0;           // RATSDF_CAND_PARTS: consumer workgroups per candidate list
   unsigned cand_wgs = 248;               // look-ahead workgroups per host kernel (about one per CU)
+  // dynamic LDS of k_alloc_rank: the serial role needs kSerialLdsBytes; asking for more than half a
+  // CU's LDS keeps the look-ahead workgroups of the launch off the serial workgroup's CU (sharing it
+  // stretched the frame's critical path by a quarter)
+  unsigned serial_lds = 100 * 1024;
   Request* req = nullptr;
   uint32_t req_cap = 0;
   uint32_t* abitmap = nullptr;   // rank bitmap, many-request path only (whole 32-word groups)
@@ -353,7 +357,7 @@ int ratsdf_engine::alloc_rank(uint32_t nranks, unsigned par, const CandJob* next
   const unsigned extra = job.n_tiles ? (job.n_tiles + job.tiles_per_wg - 1) / job.tiles_per_wg : 0;
   const RankBufs rb = rank_bufs(nranks);
   hipLaunchKernelGGL(k_alloc_rank, dim3(1 + extra), dim3(1024),
-                     kSerialLdsBytes, stream, tab, pool, rb, carve_bufs(), ctl,
+                     serial_lds, stream, tab, pool, rb, carve_bufs(), ctl,
                      (uint32_t)par, d_stats, frame ? cand[par].count : (uint32_t*)nullptr, job);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
@@ -621,6 +625,10 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     const int x = atoi(v);
     if (x >= 1 && x <= 64) e->cand_parts_env = (unsigned)x;
   }
+  if (const char* v = getenv("RATSDF_SERIAL_LDS")) {
+    const int x = atoi(v);
+    if (x >= kSerialLdsBytes && x <= 160 * 1024) e->serial_lds = (unsigned)x;
+  }
   if (const char* v = getenv("RATSDF_CAND_WGS")) {
     const int x = atoi(v);
     if (x >= 1 && x <= 4096) e->cand_wgs = (unsigned)x;
@@ -702,6 +710,8 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
                      e->pool.heap, t.num_block);
   const int32_t nf = t.num_block;
   CREATE_CHK(hipMemcpyAsync(&e->ctl->num_free, &nf, 4, hipMemcpyHostToDevice, e->stream));
+  CREATE_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_alloc_rank),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
   CREATE_CHK(hipStreamSynchronize(e->stream));
   CREATE_CHK(hipGetLastError());
   if (e->upload_record() != RATSDF_OK) {

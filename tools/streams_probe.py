@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--config", default="vga5mm")
+    ap.add_argument("--only-group", action="store_true")
     a = ap.parse_args()
     cam, vs = ("scannet", 0.005) if a.config == "vga5mm" else ("l515_720p", 0.002)
     dev = torch.device("cuda", 0)
@@ -53,7 +54,7 @@ def main():
 
     # (a) enqueue cost on an idle queue: short bursts, nothing queued before
     e, b, t, (H, W) = engs[0]
-    for burst in (4, 16, 60):
+    for burst in (() if a.only_group else (4, 16, 60)):
         small = e.make_batch([x.data_ptr() for x in t["rgb"][:burst]], [x.data_ptr() for x in t["depth"][:burst]],
                              [x.data_ptr() for x in t["ht"][:burst]], [x.data_ptr() for x in t["lt"][:burst]],
                              H, W, 4.0, b[8][:burst], b[9][:burst])
@@ -72,7 +73,7 @@ def main():
                               total_us_per_frame=round(tot * 1e6, 2))), flush=True)
 
     # (b) S engines, S threads
-    for S in [int(s) for s in a.streams.split(",")]:
+    for S in ([] if a.only_group else [int(s) for s in a.streams.split(",")]):
         sel = engs[:S]
         for e, _, _, _ in sel:
             e.synchronize()
