@@ -58,6 +58,13 @@ def parse():
                     help="frames timed through the host-image entry point, PCIe included (0 = skip)")
     ap.add_argument("--sync-every", type=int, default=0,
                     help="diagnostic: host-synchronise every N frames (0 = only at the end)")
+    ap.add_argument("--reps", type=int, default=5,
+                    help="timed repetitions of the K steps; value = the median repetition")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="N = 1: also time S concurrent streams on this GPU through one launch "
+                         "triple per frame step (ratsdf_group_*); 0 / 1 = skip")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="vga5mm, N = 1: skip the bounded 1280x720 / 2 mm leg (`secondary`)")
     return ap.parse_args()
 
 
@@ -67,6 +74,152 @@ def make_stream(scene, cam, nframes, phase):
     half = [synthetic.frame(scene, phase + i, cam=cam, noise=True, holes=True) for i in
             range(nframes)]
     return half + half[::-1]
+
+
+def alg_bytes(W, H, tot):
+    """15 W H + 12 V + 24 U per frame, summed over the frames counted in `tot`."""
+    return 15.0 * W * H * tot["frames"] + 12.0 * tot["visible_blocks"] + 24.0 * tot["updated_voxels"]
+
+
+def traffic_file(config):
+    return ROOT / "profiles" / ("traffic_latest.json" if config == "vga5mm" else "traffic_hd2mm.json")
+
+
+def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", engines=1):
+    if not k_n:
+        return None
+    k_avg_s = k_ms / k_n / 1e3
+    achieved = b_alg_per_launch / k_avg_s / 1e9
+    traffic, src = None, None
+    tpath = traffic_file(config)
+    if engines == 1 and tpath.exists():  # PMC passes made on this very workload (tools/traffic.sh)
+        try:
+            traffic = json.loads(tpath.read_text()).get("k_integrate_bytes_per_launch")
+            src = f"profiles/{tpath.name} (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        except Exception:
+            traffic = None
+    return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src,
+                alg_bytes_per_launch=round(b_alg_per_launch), avg_launch_us=round(k_avg_s * 1e6, 2),
+                launches=k_n)
+
+
+def bench_streams(ratsdf, torch, dev, dev_index, S, scene, cam, vs, md, nfr, steps, reps):
+    """S concurrent streams of this GPU through ONE launch triple per frame step (ratsdf_group_*:
+    frame-batched integration, BASELINE configs[4] on one device).  Every member's map is exactly
+    what the member alone would produce (tests/test_gpu_group.py)."""
+    from ratsdf import synthetic
+    half = nfr // 2
+    streams = []
+    for s in range(S):
+        fr = [synthetic.frame(scene, 45 * s + i, cam=cam, noise=True, holes=True) for i in range(half)]
+        streams.append(fr + fr[::-1])
+    H, W = streams[0][0]["depth"].shape
+    dt_ = [[{k: torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")} for f in fr]
+           for fr in streams]
+    engines = [ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index) for _ in range(S)]
+    grp = ratsdf.Group(engines)
+    n = len(streams[0])
+    rows = lambda key: [[dt_[s][f][key].data_ptr() for s in range(S)] for f in range(n)]
+    gb = grp.make_batch(rows("rgb"), rows("depth"), rows("ht"), rows("lt"), H, W, md,
+                        [[streams[s][f]["intrinsics"] for s in range(S)] for f in range(n)],
+                        [[streams[s][f]["pose"] for s in range(S)] for f in range(n)])
+    for _ in range(3):
+        grp.integrate_device_batch(gb)
+    grp.synchronize()
+    for e in engines:
+        e.totals(reset=True)
+    grp.profile_enable(True)
+    rep_dt = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            grp.integrate_device_batch(gb)
+        grp.synchronize()
+        rep_dt.append(time.perf_counter() - t0)
+    k_ms, k_n = grp.profile_read()
+    grp.profile_enable(False)
+    tot = [e.totals() for e in engines]
+    b_alg = sum(alg_bytes(W, H, t) for t in tot)
+    frames_total = sum(t["frames"] for t in tot)
+    dt = sorted(rep_dt)[len(rep_dt) // 2]
+    fps = S * steps * n / dt
+    out = dict(streams=S, frames_per_s=round(fps, 1), frames_per_s_min_max=[round(S * steps * n / max(rep_dt), 1),
+                                                                         round(S * steps * n / min(rep_dt), 1)],
+               us_per_frame_step=round(dt / (steps * n) * 1e6, 2), frames_per_step=n, steps=steps, reps=reps,
+               alg_gbps_whole_frame=round(b_alg / frames_total * fps / 1e9, 1),
+               roofline=roofline_block(b_alg / frames_total * S, k_ms, k_n, "vga5mm", kernel="k_integrate_g",
+                                       engines=S),
+               note="one k_front_g / k_alloc_rank_g / k_integrate_g launch per frame step serves all "
+                    "streams (one grid slice per stream); a k_integrate_g launch = S frames")
+    grp.close()
+    for e in engines:
+        e.close()
+    return out
+
+
+def bench_secondary(ratsdf, torch, dev, dev_index, md, cpu_threads):
+    """Bounded 1280x720 / 2 mm / L515 leg (BASELINE configs[3] workload on one GPU; north_star asks
+    for both stream sizes): throughput, k_integrate roofline and parity against the CPU oracle."""
+    from ratsdf import synthetic
+    from oracle_binding import load_oracle
+    from parity import assert_maps_equal
+    from ratsdf._abi import Engine
+    vs, cam, half, steps, reps = 0.002, "l515_720p", 10, 8, 3
+    fr = [synthetic.frame("room", i, cam=cam, noise=True, holes=True) for i in range(half)]
+    frames = fr + fr[::-1]
+    H, W = frames[0]["depth"].shape
+    d = [{k: torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")} for f in frames]
+    intr = [ratsdf.Intrinsics(*f["intrinsics"]) for f in frames]
+    pose = [ratsdf.Pose(*f["pose"]) for f in frames]
+    # parity on the first pass over the stream
+    cpu = Engine(load_oracle(), vs, 6 * vs, threads=cpu_threads)
+    chk = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
+    t0 = time.perf_counter()
+    for f in frames:
+        cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+    t_cpu = time.perf_counter() - t0
+    for i, f in enumerate(frames):
+        chk.integrate_device(d[i]["rgb"].data_ptr(), d[i]["depth"].data_ptr(), d[i]["ht"].data_ptr(),
+                             d[i]["lt"].data_ptr(), H, W, md, intr[i], pose[i])
+    chk.synchronize()
+    worst = assert_maps_equal(chk, cpu)
+    chk.close()
+    cpu.close()
+    eng = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
+    batch = eng.make_batch([x["rgb"].data_ptr() for x in d], [x["depth"].data_ptr() for x in d],
+                           [x["ht"].data_ptr() for x in d], [x["lt"].data_ptr() for x in d], H, W, md,
+                           intr, pose)
+    for _ in range(3):
+        eng.integrate_device_batch(batch)
+    eng.synchronize()
+    eng.totals(reset=True)
+    eng.profile_enable(True)
+    rep_dt = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.integrate_device_batch(batch)
+        eng.synchronize()
+        rep_dt.append(time.perf_counter() - t0)
+    k_ms, k_n = eng.profile_read()
+    eng.profile_enable(False)
+    tot = eng.totals()
+    dt = sorted(rep_dt)[len(rep_dt) // 2]
+    fps = steps * len(frames) / dt
+    b_alg = alg_bytes(W, H, tot) / max(tot["frames"], 1)
+    out = dict(config="hd2mm", workload=f"synthetic 'room' stream, {cam} intrinsics {W}x{H}, voxel 2 mm, "
+                                        f"truncation 12 mm, max depth {md:g} m, {len(frames)}-frame ping-pong",
+               value=round(fps, 1), unit="frames/s", steps=steps, reps=reps, frames_per_step=len(frames),
+               frame=dict(avg_visible_blocks=round(tot["visible_blocks"] / tot["frames"], 1),
+                          avg_updated_voxels=round(tot["updated_voxels"] / tot["frames"], 1),
+                          alg_bytes=round(b_alg)),
+               roofline=roofline_block(b_alg, k_ms, k_n, "hd2mm"),
+               cpu_frames_per_s=round(len(frames) / t_cpu, 1), cpu_threads=cpu_threads,
+               parity=dict(frames=len(frames), max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"],
+                           directory="bit-exact"))
+    eng.close()
+    return out
 
 
 def main():
@@ -211,14 +364,24 @@ def main():
         step()
     fence()
     eng.totals(reset=True)
+    # K steps, timed `reps` times back to back (each bracketed by barrier + synchronize); the value
+    # is the median repetition.  The dominant kernel is timed inside the same region: every 4th
+    # k_integrate launch carries a start and a stop event attached to its dispatch.
     if not a.no_profile:
         eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    t_enqueue = time.perf_counter() - t0
-    fence()
-    dt = time.perf_counter() - t0
+    rep_dt = []
+    for _ in range(max(a.reps, 1)):
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        d = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        rep_dt.append(d)
+    dt = sorted(rep_dt)[len(rep_dt) // 2]
     k_ms, k_n = (0.0, 0)
     if not a.no_profile:
         k_ms, k_n = eng.profile_read()
@@ -226,9 +389,35 @@ def main():
     tot = eng.totals()
     stats = eng.last_frame_stats()
 
-    # host-image entry point (ratsdf_integrate: pinned staging + PCIe copy + sync per frame, like the
-    # reference's Integrate).  Reported separately; never the headline value.
+    # host cost of enqueueing a frame, measured on an IDLE queue (short bursts, synchronised in
+    # between): while the GPU is the bottleneck a long enqueue loop only measures the back-pressure
+    # of the full hardware queue, not the host
+    enq_us = None
+    if not a.sync_every:
+        burst = min(16, len(frames))
+        small = eng.make_batch([t.data_ptr() for t in d_rgb[:burst]], [t.data_ptr() for t in d_depth[:burst]],
+                               [t.data_ptr() for t in d_ht[:burst]], [t.data_ptr() for t in d_lt[:burst]],
+                               H, W, a.max_depth, intr[:burst], pose[:burst])
+        best = None
+        for _ in range(5):
+            eng.synchronize()
+            t0 = time.perf_counter()
+            eng.integrate_device_batch(small)
+            d = (time.perf_counter() - t0) / burst
+            best = d if best is None else min(best, d)
+        eng.synchronize()
+        enq_us = best * 1e6
+
+    # Host-image entry points, PCIe included (the reference's calling convention: TSDFSystem::Integrate
+    # hands over cv::Mat images in host memory, modules/tsdf_module.cc:22-37,88-115).  Reported
+    # separately; never the headline value.
+    #   per frame   ratsdf_integrate: staging copy + H2D + a stream sync per frame
+    #   batched     ratsdf_integrate_batch, 8 frames per call from pageable memory (what
+    #               ratsdf::TSDFSystem's worker does with its queue); uploads on a copy stream
+    #   pinned      the same call on page-locked buffers (ratsdf_host_alloc), 32 frames per call:
+    #               no staging copy, bound by the PCIe link (63 GB/s spec)
     host_path = None
+    pinned_path = None
     if rank == 0 and world == 1 and a.host_frames > 0:
         hp = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
         nh = min(a.host_frames, len(frames))
@@ -238,79 +427,61 @@ def main():
         for f in frames[:nh]:
             hp.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"], f["pose"])
         th = time.perf_counter() - th
-        # the same frames through ratsdf_integrate_batch (8 at a time, as TSDFSystem's worker does)
+        hp.integrate_batch(frames[:8], a.max_depth)
+        nb = 0
         tb = time.perf_counter()
-        for c0 in range(0, nh, 8):
-            hp.integrate_batch(frames[c0:min(c0 + 8, nh)], a.max_depth)
+        for _ in range(4):
+            for c0 in range(0, len(frames) - 7, 8):
+                hp.integrate_batch(frames[c0:c0 + 8], a.max_depth)
+                nb += 8
         tb = time.perf_counter() - tb
-        host_path = dict(frames_per_s=round(nh / th, 1), frames=nh, batched_frames_per_s=round(nh / tb, 1),
+        bytes_per_frame = sum(frames[0][k].nbytes for k in ("rgb", "depth", "ht", "lt"))
+        host_path = dict(frames_per_s=round(nh / th, 1), frames=nh, batched_frames_per_s=round(nb / tb, 1),
+                         batched_frames=nb, batched_h2d_gbps=round(nb * bytes_per_frame / tb / 1e9, 1),
                          note="ratsdf_integrate with host images: H2D copy (4.6 MB/frame) and a "
                               "stream sync per frame included; batched = ratsdf_integrate_batch, "
-                              "8 frames per call")
+                              "8 frames per call from pageable memory")
+        # page-locked copies of the stream's frames
+        pin = []
+        for f in frames:
+            g = dict(f)
+            for k in ("rgb", "depth", "ht", "lt"):
+                g[k] = hp.host_alloc(f[k].shape, f[k].dtype)
+                g[k][...] = f[k]
+            pin.append(g)
+        C = 32
+        chunks = [pin[c0:c0 + C] for c0 in range(0, len(pin) - C + 1, C)] or [pin]
+        for ch in chunks[:1]:
+            hp.integrate_batch(ch, a.max_depth, pinned=True)
+        npin = 0
+        tp = time.perf_counter()
+        while npin < 2000:
+            for ch in chunks:
+                hp.integrate_batch(ch, a.max_depth, pinned=True)
+                npin += len(ch)
+        tp = time.perf_counter() - tp
+        pinned_path = dict(frames_per_s=round(npin / tp, 1), frames=npin,
+                           h2d_gbps=round(npin * bytes_per_frame / tp / 1e9, 1), link_gbps_spec=63.0,
+                           note=f"ratsdf_integrate_batch(pinned=1), {len(chunks[0])} frames per call from "
+                                "ratsdf_host_alloc buffers: uploads on the engine's copy stream up to 7 "
+                                "frames ahead of the integration, one sync per call")
+        for g in pin:
+            for k in ("rgb", "depth", "ht", "lt"):
+                hp.host_free(g[k])
         hp.close()
 
-    # frames in PINNED host memory, uploaded chunk by chunk on a copy stream while the engine
-    # integrates the previous chunk ("separately reported, including H2D from pinned host
-    # memory").  PCIe-bound; reported separately, never the headline value.
-    pinned_path = None
-    if rank == 0 and world == 1 and a.host_frames > 0:
-        pp = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
-        pext = torch.cuda.ExternalStream(pp.stream(), device=dev)
-        copy_stream = torch.cuda.Stream(device=dev)
-        C = 6                                            # frames per chunk, two chunks in flight
-        keys = ("rgb", "depth", "ht", "lt")
-        h_pin = [{k: torch.from_numpy(f[k]).pin_memory() for k in keys} for f in frames]
-        ring = [[{k: torch.empty_like(h_pin[0][k], device=dev) for k in keys} for _ in range(C)]
-                for _ in range(2)]
-        batches = {}
-        def chunk_batch(slot, idx):
-            key = (slot, tuple(idx))
-            if key not in batches:
-                r = ring[slot]
-                batches[key] = pp.make_batch([r[j]["rgb"].data_ptr() for j in range(len(idx))],
-                                             [r[j]["depth"].data_ptr() for j in range(len(idx))],
-                                             [r[j]["ht"].data_ptr() for j in range(len(idx))],
-                                             [r[j]["lt"].data_ptr() for j in range(len(idx))], H, W,
-                                             a.max_depth, [intr[i] for i in idx], [pose[i] for i in idx])
-            return batches[key]
-        def run_pinned(n_frames):
-            free_ev = [None, None]                      # ring slot may be overwritten after this event
-            order = [i % len(frames) for i in range(n_frames)]
-            for c0 in range(0, n_frames, C):
-                idx = order[c0:c0 + C]
-                slot = (c0 // C) & 1
-                with torch.cuda.stream(copy_stream):
-                    if free_ev[slot] is not None:
-                        copy_stream.wait_event(free_ev[slot])
-                    for j, i in enumerate(idx):
-                        for k in keys:
-                            ring[slot][j][k].copy_(h_pin[i][k], non_blocking=True)
-                    up = torch.cuda.Event()
-                    up.record(copy_stream)
-                pext.wait_event(up)
-                pp.integrate_device_batch(chunk_batch(slot, idx))
-                done = torch.cuda.Event()
-                done.record(pext)
-                free_ev[slot] = done
-            pp.synchronize()
-            torch.cuda.synchronize()
-        run_pinned(4 * C)
-        npin = max(a.host_frames, 20 * C) // C * C
-        tp = time.perf_counter()
-        run_pinned(npin)
-        tp = time.perf_counter() - tp
-        bytes_per_frame = sum(h_pin[0][k].numel() * h_pin[0][k].element_size() for k in keys)
-        pinned_path = dict(frames_per_s=round(npin / tp, 1), frames=npin,
-                           h2d_gbps=round(npin * bytes_per_frame / tp / 1e9, 1),
-                           note=f"frames in pinned host memory, {C}-frame chunks uploaded on a copy "
-                                "stream while the previous chunk is integrated "
-                                "(ratsdf_integrate_device_batch)")
-        pp.close()
+    # ---- S streams on this GPU through one launch triple per frame step ------------------------
+    multi = None
+    if rank == 0 and world == 1 and a.streams > 1 and not a.shard:
+        multi = bench_streams(ratsdf, torch, dev, dev_index, a.streams, a.scene, a.cam, vs, a.max_depth,
+                              min(60, len(frames)), max(a.steps // 2, 4), 3)
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # ---- the other stream size north_star names, bounded ----------------------------------------
+    secondary = None
+    if rank == 0 and world == 1 and a.config == "vga5mm" and not a.no_secondary and a.cpu_frames > 0:
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        secondary = [bench_secondary(ratsdf, torch, dev, dev_index, a.max_depth,
+                                     min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16"))))]
 
     nframes = a.steps * len(frames)
     if rank == 0:
@@ -318,21 +489,7 @@ def main():
         V = tot["visible_blocks"] / max(tot["frames"], 1)
         U = tot["updated_voxels"] / max(tot["frames"], 1)
         b_alg = 15.0 * W * H + 12.0 * V + 24.0 * U
-        roof = None
-        if k_n:
-            k_avg_s = k_ms / k_n / 1e3
-            achieved = b_alg / k_avg_s / 1e9
-            traffic = None
-            tpath = ROOT / "profiles" / ("traffic_latest.json" if a.config == "vga5mm" else "traffic_hd2mm.json")
-            if tpath.exists():  # PMC passes made on this very workload (tools/traffic.sh)
-                try:
-                    traffic = json.loads(tpath.read_text()).get("k_integrate_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = dict(bound="hbm", kernel="k_integrate", achieved=round(achieved, 1),
-                        peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                        traffic=traffic, alg_bytes_per_launch=round(b_alg),
-                        avg_launch_us=round(k_avg_s * 1e6, 2), launches=k_n)
+        roof = roofline_block(b_alg, k_ms, k_n, a.config)
         out = {
             "metric": ("depth+semantic frames/sec integrated @640x480, 5mm voxels" if a.config == "vga5mm"
                        else f"depth+semantic frames/sec integrated @{W}x{H}, {vs * 1e3:g}mm voxels"),
@@ -342,6 +499,9 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "reps": len(rep_dt),
+            "value_min_max": [round((1 if a.shard else world) * nframes / max(rep_dt), 1),
+                              round((1 if a.shard else world) * nframes / min(rep_dt), 1)],
             "higher_is_better": True,
             "scaling": "strong" if (a.shard and world > 1) else "weak",
             "vs_baseline": None,
@@ -359,12 +519,18 @@ def main():
             "directory_blocks_all_ranks": (int(cnt_all.sum().item()) if world > 1 else None),
             "frame": {"avg_visible_blocks": round(V, 1), "avg_updated_voxels": round(U, 1),
                       "alg_bytes": round(b_alg), "alg_gbps_whole_frame": round(b_alg * fps / world / 1e9, 1),
-                      "active_blocks": stats["active_blocks"]},
-            "host_enqueue_frac": round(t_enqueue / dt, 3),
+                      "active_blocks": stats["active_blocks"],
+                      "avg_allocated_blocks": round(tot["allocated_blocks"] / max(tot["frames"], 1), 2),
+                      "avg_deleted_blocks": round(tot["deleted_blocks"] / max(tot["frames"], 1), 2)},
+            # host cost of a frame's three launches on an idle queue / GPU time per frame
+            "host_enqueue_us_per_frame": round(enq_us, 2) if enq_us else None,
+            "host_enqueue_frac": round(enq_us * 1e-6 / (dt / nframes), 3) if enq_us else None,
             "roofline": roof,
             "cpu_baseline": cpu_baseline,
             "host_image_path": host_path,
             "pinned_h2d_path": pinned_path,
+            "multi_stream": multi,
+            "secondary": secondary,
             "parity": parity,
         }
         print(json.dumps(out))

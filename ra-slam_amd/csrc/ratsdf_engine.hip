@@ -143,6 +143,8 @@ struct ratsdf_engine {
   uint8_t* h_stage = nullptr;  // pinned
   uint8_t* d_stage = nullptr;
   hipEvent_t stage_ev[8] = {};  // upload of the slot's last user has been executed
+  hipEvent_t use_ev[9] = {};    // the frame that read the slot has been executed (+1: call fence)
+  hipStream_t copy_stream = nullptr;  // uploads of ratsdf_integrate_batch
 
   // profiling of the dominant kernel
   bool profiling = false;
@@ -160,6 +162,7 @@ struct ratsdf_engine {
   RankBufs rank_bufs(uint32_t nranks) const;
   int alloc_rank(uint32_t nranks, unsigned par, const CandJob* next = nullptr, bool frame = false);
   int settle();
+  void abandon_pipeline();
   CarveBufs carve_bufs() const;
   int select(int mode, const GridBounds& gb, uint32_t* count_slot);
   struct FrameIn {
@@ -213,8 +216,12 @@ int ratsdf_engine::free_all() {
   if (h_stage) (void)hipHostFree(h_stage);
   if (dl_dev) (void)hipFree(dl_dev);
   if (dl_host) (void)hipHostFree(dl_host);
+  if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   for (auto& ev : stage_ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : use_ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (copy_stream) (void)hipStreamDestroy(copy_stream);
   for (auto& ev : prof_events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -331,6 +338,9 @@ int ratsdf_engine::ensure_stage(size_t npix) {
   HIPCHK(hipMalloc(&d_stage, bytes));
   for (int i = 0; i < kStageSlots; ++i)
     if (!stage_ev[i]) HIPCHK(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
+  for (int i = 0; i <= kStageSlots; ++i)
+    if (!use_ev[i]) HIPCHK(hipEventCreateWithFlags(&use_ev[i], hipEventDisableTiming));
+  if (!copy_stream) HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
   stage_pix = npix;
   return RATSDF_OK;
 }
@@ -361,6 +371,19 @@ int ratsdf_engine::alloc_rank(uint32_t nranks, unsigned par, const CandJob* next
                      (uint32_t)par, d_stats, frame ? cand[par].count : (uint32_t*)nullptr, job);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
+}
+
+// After a failed launch or copy in the middle of a batch: nothing may stay queued that reads the
+// caller's buffers, and the look-ahead state must not leak into the next call (a frame that skipped
+// k_cand because "its candidate pass already ran" would consume the stale lists of a frame that
+// never came).
+void ratsdf_engine::abandon_pipeline() {
+  if (stream) (void)hipStreamSynchronize(stream);
+  if (cand_ready && cand[parity].count)  // lists filled for a frame that will not be integrated
+    (void)hipMemsetAsync(cand[parity].count, 0, (size_t)kCandSegs * kCandCountStride * 4, stream);
+  cand_ready = false;
+  (void)settle();
+  if (stream) (void)hipStreamSynchronize(stream);
 }
 
 // Everything but a following frame needs the last frame's carve pass completed first.
@@ -772,7 +795,10 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
     ratsdf_engine::FrameIn nxt{};
     if (i + 1 < n) nxt = input(i + 1);
     const int st = e->frame(cur, i + 1 < n ? &nxt : nullptr, height, width, max_depth);
-    if (st != RATSDF_OK) return st;
+    if (st != RATSDF_OK) {
+      e->abandon_pipeline();
+      return st;
+    }
   }
   return RATSDF_OK;
 }
@@ -819,29 +845,33 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
   if (st != RATSDF_OK) return st;
   const size_t slot_bytes = npix * 16;
   auto sem = [&](int i) { return ht && lt && ht[i] && lt[i]; };  // tsdf_module.cc:27-31
-  // layout of a slot: depth | ht | lt | rgb
+  // Uploads run on their own stream, up to kStageSlots frames ahead of the frames that use them, so
+  // the PCIe copy of later frames overlaps the integration of earlier ones (one stream would
+  // serialise them).  Per device slot: up_ev = its upload has been executed, use_ev = the frame that
+  // read it has been executed.  Layout of a slot: depth | ht | lt | rgb.
   auto upload = [&](int i) -> int {
     const int slot = i % kStageSlots;
     uint8_t* d = e->d_stage + (size_t)slot * slot_bytes;
+    if (i >= kStageSlots) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->use_ev[slot], 0));
     if (pinned) {  // straight from the caller's page-locked buffers
-      HIPCHK(hipMemcpyAsync(d, depth[i], npix * 4, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(d, depth[i], npix * 4, hipMemcpyHostToDevice, e->copy_stream));
       if (sem(i)) {
-        HIPCHK(hipMemcpyAsync(d + npix * 4, ht[i], npix * 4, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(d + npix * 8, lt[i], npix * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(d + npix * 4, ht[i], npix * 4, hipMemcpyHostToDevice, e->copy_stream));
+        HIPCHK(hipMemcpyAsync(d + npix * 8, lt[i], npix * 4, hipMemcpyHostToDevice, e->copy_stream));
       }
-      HIPCHK(hipMemcpyAsync(d + npix * 12, rgb[i], npix * 3, hipMemcpyHostToDevice, e->stream));
-      return RATSDF_OK;
+      HIPCHK(hipMemcpyAsync(d + npix * 12, rgb[i], npix * 3, hipMemcpyHostToDevice, e->copy_stream));
+    } else {
+      uint8_t* h = e->h_stage + (size_t)slot * slot_bytes;
+      if (i >= kStageSlots) HIPCHK(hipEventSynchronize(e->stage_ev[slot]));  // its last upload is done
+      memcpy(h, depth[i], npix * 4);
+      if (sem(i)) {
+        memcpy(h + npix * 4, ht[i], npix * 4);
+        memcpy(h + npix * 8, lt[i], npix * 4);
+      }
+      memcpy(h + npix * 12, rgb[i], npix * 3);
+      HIPCHK(hipMemcpyAsync(d, h, slot_bytes, hipMemcpyHostToDevice, e->copy_stream));
     }
-    uint8_t* h = e->h_stage + (size_t)slot * slot_bytes;
-    if (i >= kStageSlots) HIPCHK(hipEventSynchronize(e->stage_ev[slot]));  // its last upload is done
-    memcpy(h, depth[i], npix * 4);
-    if (sem(i)) {
-      memcpy(h + npix * 4, ht[i], npix * 4);
-      memcpy(h + npix * 8, lt[i], npix * 4);
-    }
-    memcpy(h + npix * 12, rgb[i], npix * 3);
-    HIPCHK(hipMemcpyAsync(d, h, slot_bytes, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipEventRecord(e->stage_ev[slot], e->stream));
+    HIPCHK(hipEventRecord(e->stage_ev[slot], e->copy_stream));
     return RATSDF_OK;
   };
   auto input = [&](int i) {
@@ -849,22 +879,46 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
     return ratsdf_engine::FrameIn{d + npix * 12, d, sem(i) ? d + npix * 4 : nullptr,
                                   sem(i) ? d + npix * 8 : nullptr, &K[i], &T[i]};
   };
-  // frame i's launches host the look-ahead of frame i+1, so that frame's upload is enqueued first;
-  // a device slot is only overwritten kStageSlots frames later, in stream order
-  st = upload(0);
-  if (st != RATSDF_OK) return st;
+  // whatever happens, the caller's buffers (and the staging slots) are no longer in use on return
+  auto fail = [&](int status) {
+    (void)hipStreamSynchronize(e->copy_stream);
+    e->abandon_pipeline();
+    return status;
+  };
+  // the previous call's frames may still be reading the slots (they do not: every call ends with a
+  // synchronisation), and nothing earlier on the engine's stream may be overtaken by the uploads
+  HIPCHK(hipEventRecord(e->use_ev[kStageSlots], e->stream));
+  HIPCHK(hipStreamWaitEvent(e->copy_stream, e->use_ev[kStageSlots], 0));
+  const int ahead = kStageSlots - 1;  // uploads enqueued ahead of the frame being launched
+  int uploaded = 0;
   for (int i = 0; i < n; ++i) {
-    if (i + 1 < n) {
-      st = upload(i + 1);
-      if (st != RATSDF_OK) return st;
+    // frame i's launches host the look-ahead of frame i+1: both uploads precede them
+    while (uploaded < n && uploaded <= i + 1) {
+      st = upload(uploaded);
+      if (st != RATSDF_OK) return fail(st);
+      ++uploaded;
     }
+    if (hipStreamWaitEvent(e->stream, e->stage_ev[i % kStageSlots], 0) != hipSuccess ||
+        (i + 1 < n && hipStreamWaitEvent(e->stream, e->stage_ev[(i + 1) % kStageSlots], 0) != hipSuccess))
+      return fail(RATSDF_ERR_DEVICE);
     const ratsdf_engine::FrameIn cur = input(i);
     ratsdf_engine::FrameIn nxt{};
     if (i + 1 < n) nxt = input(i + 1);
     st = e->frame(cur, i + 1 < n ? &nxt : nullptr, height, width, max_depth);
-    if (st != RATSDF_OK) return st;
+    if (st != RATSDF_OK) return fail(st);
+    // frame i's images were last read by its candidate pass, which ran in frame i-1's launches or
+    // before; recording after frame i is the simple, safe point
+    if (hipEventRecord(e->use_ev[i % kStageSlots], e->stream) != hipSuccess) return fail(RATSDF_ERR_DEVICE);
+    // run further ahead with the uploads while the queue is busy
+    while (uploaded < n && uploaded <= i + ahead) {
+      st = upload(uploaded);
+      if (st != RATSDF_OK) return fail(st);
+      ++uploaded;
+    }
   }
-  return e->sticky();
+  st = e->sticky();
+  if (st == RATSDF_ERR_DEVICE) return fail(st);
+  return st;
 }
 
 int ratsdf_host_alloc(size_t bytes, void** out) {

@@ -259,9 +259,27 @@ class Engine:
         st = self.lib.fn["integrate_device_batch"](self._h, n, rgb, depth, ht, lt, h, w, md, ks, ps)
         _check(st, "integrate_device_batch")
 
-    def integrate_batch(self, frames, max_depth):
+    def host_alloc(self, shape, dtype):
+        """numpy array in page-locked host memory (ratsdf_host_alloc); release with host_free()."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        _check(self.lib.fn["host_alloc"](n, C.byref(p)), "host_alloc")
+        buf = (C.c_char * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            _check(self.lib.fn["host_free"](p), "host_free")
+
+    def integrate_batch(self, frames, max_depth, pinned=False):
         """n frames from host memory in one call (ratsdf_integrate_batch).  frames: dicts with rgb,
-        depth, ht, lt (numpy; ht / lt may be None), intrinsics, pose."""
+        depth, ht, lt (numpy; ht / lt may be None), intrinsics, pose.  pinned=True: every image is a
+        host_alloc() array (uploaded without a staging copy)."""
         n = len(frames)
         keep = []
         def col(key, dtype):
@@ -282,7 +300,7 @@ class Engine:
         st = self.lib.fn["integrate_batch"](self._h, n, col("rgb", np.uint8), col("depth", np.float32),
                                             col("ht", np.float32) if sem else None,
                                             col("lt", np.float32) if sem else None, h, w,
-                                            float(max_depth), ks, ps, 0)
+                                            float(max_depth), ks, ps, 1 if pinned else 0)
         _check(st, "integrate_batch")
 
     def synchronize(self):
