@@ -309,33 +309,24 @@ def main():
         chk.close()
         cpu.close()
 
-    # ---- directory all-gather (N > 1): one fixed-capacity exchange per step -------------------
-    cap = 1 << 16
+    # ---- directory all-gather (N > 1): one exchange per step (ratsdf/multi.py) -------------------
+    ex = None
     if world > 1:
-        dir_local = torch.zeros(cap * 3, dtype=torch.int32, device=dev)   # 12-byte entries
-        dir_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        dir_all = torch.zeros(world * cap * 3, dtype=torch.int32, device=dev)
-        cnt_all = torch.zeros(world, dtype=torch.int32, device=dev)
+        from ratsdf import multi
+        if backend == "nccl":
+            # 2^16 entries (768 KiB per rank and step); a larger directory raises in result(), it is
+            # never truncated silently
+            ex = multi.DirectoryExchange(capacity=1 << 16, device=dev)
+        else:  # rehearsal backend (gloo): stage through the host
+            ex = multi.DirectoryExchange(capacity=1 << 16)
 
     def exchange():
-        # engine stream -> (event) -> torch stream -> RCCL all-gather -> (event) -> engine stream
-        eng.export_directory_device(dir_local.data_ptr(), cap, dir_count.data_ptr())
-        ev = torch.cuda.Event()
-        ev.record(ext)
-        torch.cuda.current_stream().wait_event(ev)
         if backend == "nccl":
-            dist.all_gather_into_tensor(dir_all, dir_local)
-            dist.all_gather_into_tensor(cnt_all, dir_count)
-        else:  # rehearsal backend: stage through the host
-            a_cpu, c_cpu = torch.zeros(world * cap * 3, dtype=torch.int32), torch.zeros(
-                world, dtype=torch.int32)
-            dist.all_gather_into_tensor(a_cpu, dir_local.cpu())
-            dist.all_gather_into_tensor(c_cpu, dir_count.cpu())
-            dir_all.copy_(a_cpu)
-            cnt_all.copy_(c_cpu)
-        ev2 = torch.cuda.Event()
-        ev2.record(torch.cuda.current_stream())
-        ext.wait_event(ev2)
+            # engine stream -> (event) -> torch stream -> RCCL all-gather -> (event) -> engine stream
+            ex.fill_from_engine_device(eng)
+        else:
+            ex.fill_from_numpy(eng.dump_directory()[1])
+        ex.all_gather()
 
     batch = eng.make_batch([t.data_ptr() for t in d_rgb], [t.data_ptr() for t in d_depth],
                            [t.data_ptr() for t in d_ht], [t.data_ptr() for t in d_lt], H, W,
@@ -516,7 +507,7 @@ def main():
                 "sharding": ("block ownership: floormod(block.x >> 2, N)" if (a.shard and world > 1) else None),
                 "directory_allgather_every_frames": len(frames) if world > 1 else None,
             },
-            "directory_blocks_all_ranks": (int(cnt_all.sum().item()) if world > 1 else None),
+            "directory_blocks_all_ranks": (int(sum(len(x) for x in ex.result())) if world > 1 else None),
             "frame": {"avg_visible_blocks": round(V, 1), "avg_updated_voxels": round(U, 1),
                       "alg_bytes": round(b_alg), "alg_gbps_whole_frame": round(b_alg * fps / world / 1e9, 1),
                       "active_blocks": stats["active_blocks"],

@@ -38,7 +38,9 @@ typedef enum ratsdf_status {
   RATSDF_ERR_POOL_EXHAUSTED = 3, /* reference: device assert(idx >= 1), voxel_mem.cu:39                 */
   RATSDF_ERR_CAPACITY = 4,       /* an internal work list overflowed (no reference counterpart)        */
   RATSDF_ERR_NO_DEVICE = 5,      /* HIP engine only: no gfx950 device / runtime available              */
-  RATSDF_ERR_NOT_IMPLEMENTED = 6
+  RATSDF_ERR_NOT_IMPLEMENTED = 6,
+  RATSDF_ERR_TIMEOUT = 7         /* an in-launch wait between workgroups expired (sticky; the map may
+                                    have been read while a queued delete was still pending)           */
 } ratsdf_status;
 
 /* CameraIntrinsics<float>, utils/cuda/camera.cuh:13-52 */
@@ -258,8 +260,10 @@ int ratsdf_group_profile_read(ratsdf_group* g, double* integrate_ms, int64_t* la
 /* ---- multi-GPU support --------------------------------------------------------------------- */
 /* Writes the compact block directory (allocated entries in ascending entry order, 12 B each) into a
  * caller-provided DEVICE buffer so it can be all-gathered with RCCL without touching the host.
- * d_count (device int32) receives the number of entries; entries beyond `capacity` are dropped.
- * Enqueued on the engine's stream.  HIP engine only. */
+ * d_count (device int32) receives the number of ALLOCATED entries, which may exceed `capacity`: only
+ * the first `capacity` of them are written, and the engine's sticky status becomes
+ * RATSDF_ERR_CAPACITY (reported by the next ratsdf_synchronize), so a truncated directory is never
+ * mistaken for a complete one.  Enqueued on the engine's stream.  HIP engine only. */
 int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t capacity,
                                    void* d_count);
 

@@ -1256,6 +1256,7 @@ const char* ratsdf_oracle_status_string(int s) {
     case RATSDF_ERR_CAPACITY: return "internal work list overflow";
     case RATSDF_ERR_NO_DEVICE: return "no device";
     case RATSDF_ERR_NOT_IMPLEMENTED: return "not implemented";
+    case RATSDF_ERR_TIMEOUT: return "in-launch wait between workgroups timed out";
     default: return "unknown status";
   }
 }

@@ -152,9 +152,13 @@ __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb,
 }
 
 // Directory readers of the next launch: make sure the queued head / chain deletes of the previous
-// frame have happened.  Workgroup 0 of the launch does them; the others wait (the launch is small
-// enough to be fully resident and workgroup 0 is dispatched first).  Uniform per workgroup.
+// frame have happened.  Workgroup 0 of the launch does them; the others wait for its flag.  The wait
+// relies on nothing HIP promises (waiters all have a higher index than workgroup 0, which the
+// dispatcher has so far always started first), so it is BOUNDED: after kGateTimeoutTicks of the
+// 100 MHz wall clock the waiter gives up, records RATSDF_ERR_TIMEOUT and goes on -- an error the
+// caller sees at the next synchronisation, never a hung GPU.  Uniform per workgroup.
 // Returns true when there was something to wait for (data read before the call may be stale then).
+constexpr unsigned long long kGateTimeoutTicks = 200000;  // 2 ms; the resolver takes microseconds
 __device__ inline bool carve_resolve_gate(const Table& tab, const CarveBufs& cb, Ctl* ctl,
                                           FrameCtl* Fprev) {
   if (Fprev->n_slow_del == 0) return false;  // the steady state
@@ -166,7 +170,14 @@ __device__ inline bool carve_resolve_gate(const Table& tab, const CarveBufs& cb,
       __hip_atomic_store(&Fprev->slow_resolved, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     if (threadIdx.x == 0) {  // relaxed polling (an acquire per poll would flush this CU's L1 each time)
-      while (ld_agent(&Fprev->slow_resolved) != 2u) __builtin_amdgcn_s_sleep(16);
+      const unsigned long long t0 = (unsigned long long)wall_clock64();
+      while (ld_agent(&Fprev->slow_resolved) != 2u) {
+        if ((unsigned long long)wall_clock64() - t0 > kGateTimeoutTicks) {
+          set_error(ctl, RATSDF_ERR_TIMEOUT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -233,17 +233,23 @@ __global__ __launch_bounds__(256) void k_download(Pool pool, const VisItem* sel,
   }
 }
 
-// compact copy of the selected directory entries (12 B each) for export / dumps
+// compact copy of the selected directory entries (12 B each) for export / dumps.  *out_count gets
+// the number of selected entries even when it exceeds `cap` (then only `cap` are written and the
+// sticky error says so: a truncated directory must not pass for a complete one).
 __global__ void k_export_entries(const VisItem* sel, const uint32_t* n_sel, Entry* out_blocks,
-                                 int32_t* out_entry_index, uint32_t cap, int32_t* out_count) {
-  uint32_t n = *n_sel;
-  if (n > cap) n = cap;
+                                 int32_t* out_entry_index, uint32_t cap, int32_t* out_count,
+                                 Ctl* ctl) {
+  const uint32_t total = *n_sel;
+  const uint32_t n = total > cap ? cap : total;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const VisItem it = sel[i];
     if (out_blocks) out_blocks[i] = Entry{it.x, it.y, it.z, it.offset, it.idx};
     if (out_entry_index) out_entry_index[i] = (int32_t)it.entry;
   }
-  if (out_count && blockIdx.x == 0 && threadIdx.x == 0) *out_count = (int32_t)n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (out_count) *out_count = (int32_t)total;
+    if (total > cap && ctl) set_error(ctl, RATSDF_ERR_CAPACITY);
+  }
 }
 
 // raw voxel storage of listed pool blocks (test hook)

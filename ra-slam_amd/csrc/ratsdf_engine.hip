@@ -1367,7 +1367,7 @@ int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t cap
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
   if (st != RATSDF_OK) return st;
   hipLaunchKernelGGL(k_export_entries, dim3(256), dim3(256), 0, e->stream, e->vis, &e->ctl->n_sel,
-                     (Entry*)d_blocks, (int32_t*)nullptr, (uint32_t)capacity, (int32_t*)d_count);
+                     (Entry*)d_blocks, (int32_t*)nullptr, (uint32_t)capacity, (int32_t*)d_count, e->ctl);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
@@ -1502,7 +1502,7 @@ int ratsdf_dump_directory(ratsdf_engine* e, int32_t** entry_index, ratsdf_block*
     HIPCHK(hipMalloc(&d_b, (size_t)cnt * 12));
     HIPCHK(hipMalloc(&d_e, (size_t)cnt * 4));
     hipLaunchKernelGGL(k_export_entries, dim3(256), dim3(256), 0, e->stream, e->vis, &e->ctl->n_sel,
-                       d_b, d_e, cnt, (int32_t*)nullptr);
+                       d_b, d_e, cnt, (int32_t*)nullptr, (Ctl*)nullptr);
     HIPCHK(hipMemcpyAsync(bl, d_b, (size_t)cnt * 12, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(ei, d_e, (size_t)cnt * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1562,6 +1562,7 @@ const char* ratsdf_status_string(int s) {
     case RATSDF_ERR_CAPACITY: return "internal work list overflow";
     case RATSDF_ERR_NO_DEVICE: return "no HIP device";
     case RATSDF_ERR_NOT_IMPLEMENTED: return "not implemented";
+    case RATSDF_ERR_TIMEOUT: return "in-launch wait between workgroups timed out";
     default: return "unknown status";
   }
 }

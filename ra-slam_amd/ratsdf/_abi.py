@@ -18,6 +18,7 @@ STATUS = {
     4: "internal work list overflow",
     5: "no device",
     6: "not implemented",
+    7: "in-launch wait timed out",
 }
 
 

@@ -24,14 +24,19 @@ class DirectoryExchange:
     """All-gather of block directories with fixed-capacity buffers.
 
     device=None -> CPU tensors (gloo); otherwise a torch cuda device (nccl/RCCL) and the engine
-    writes its directory straight into the send buffer (ratsdf_export_directory_device)."""
+    writes its directory straight into the send buffer (ratsdf_export_directory_device).
+    `capacity` defaults to the size of the engine's block pool (2^block_bits entries): a directory
+    can then never be truncated.  A smaller capacity is legal; result() raises if any rank's
+    directory did not fit (the count that travels is the true one, not the clamped one)."""
 
-    def __init__(self, capacity, device=None):
+    def __init__(self, capacity=None, device=None, engine=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        if capacity is None:
+            capacity = 1 << (engine.block_bits if engine is not None else 18)
         self.capacity = int(capacity)
         self.device = device
         kw = dict(dtype=torch.int32, device=device if device is not None else "cpu")
@@ -39,10 +44,13 @@ class DirectoryExchange:
         self.count = torch.zeros(1, **kw)
         self.recv = torch.zeros(self.world * self.capacity * 3, **kw)
         self.counts = torch.zeros(self.world, **kw)
+        self._engine_stream = None
 
     def fill_from_engine_device(self, engine):
-        """HIP engine -> send buffer, on the engine's stream (no host round trip)."""
+        """HIP engine -> send buffer, on the engine's stream (no host round trip).  The collective
+        runs on torch's current stream: all_gather() orders the two with events."""
         engine.export_directory_device(self.send.data_ptr(), self.capacity, self.count.data_ptr())
+        self._engine_stream = self.torch.cuda.ExternalStream(engine.stream(), device=self.device)
 
     def fill_from_numpy(self, blocks):
         """blocks: structured array of BLOCK_DTYPE (e.g. Engine.dump_directory()[1])."""
@@ -50,25 +58,93 @@ class DirectoryExchange:
         raw = np.zeros(self.capacity * 3, dtype=np.int32)
         raw[:n * 3] = np.ascontiguousarray(blocks[:n]).view(np.int32).reshape(-1)
         self.send.copy_(self.torch.from_numpy(raw))
-        self.count.fill_(n)
+        self.count.fill_(len(blocks))  # the true count, like the device export
+        self._engine_stream = None
 
     def all_gather(self):
+        torch = self.torch
+        es = self._engine_stream
+        if es is not None:  # engine stream -> (event) -> torch's current stream
+            ev = torch.cuda.Event()
+            ev.record(es)
+            torch.cuda.current_stream(self.device).wait_event(ev)
         if self.world == 1:
             self.recv.copy_(self.send)
             self.counts.copy_(self.count)
         else:
             self.dist.all_gather_into_tensor(self.recv, self.send)
             self.dist.all_gather_into_tensor(self.counts, self.count)
+        if es is not None:  # ... and back: the engine may not overwrite `send` before the collective read it
+            ev2 = torch.cuda.Event()
+            ev2.record(torch.cuda.current_stream(self.device))
+            es.wait_event(ev2)
 
     def result(self):
         """List (one per rank) of structured BLOCK_DTYPE arrays."""
         counts = self.counts.cpu().numpy()
+        if int(counts.max(initial=0)) > self.capacity:
+            raise OverflowError(f"block directory of rank {int(counts.argmax())} has {int(counts.max())} "
+                                f"entries, exchange capacity is {self.capacity}")
         raw = self.recv.cpu().numpy().reshape(self.world, self.capacity * 3)
         out = []
         for r in range(self.world):
             n = int(counts[r])
             out.append(raw[r, :n * 3].copy().view(BLOCK_DTYPE))
         return out
+
+
+def blocks_in_bounds(blocks, bounds, voxel_size):
+    """Which directory entries a Query with `bounds` selects: the reference scales the box to voxel
+    units with a C cast to short (BoundingCube::Scale, utils/tsdf/voxel_tsdf.cuh:19-34) and takes a
+    block iff all of its 8^3 voxels lie inside, bounds inclusive (check_bound_kernel,
+    utils/tsdf/voxel_tsdf.cu:15-26)."""
+    scale = np.float32(1.0 / voxel_size)
+    b = [int(np.trunc(np.float32(v) * scale)) for v in bounds]   # (xmin, xmax, ymin, ymax, zmin, zmax)
+    b = [((v + 32768) % 65536) - 32768 for v in b]               # wrap like the cast to short
+    gx = blocks["x"].astype(np.int64) * 8
+    gy = blocks["y"].astype(np.int64) * 8
+    gz = blocks["z"].astype(np.int64) * 8
+    return ((gx >= b[0]) & (gx + 7 <= b[1]) & (gy >= b[2]) & (gy + 7 <= b[3]) & (gz >= b[4]) &
+            (gz + 7 <= b[5]))
+
+
+def query(engine, bounds, per_rank, device=None):
+    """TSDFSystem::Query (modules/tsdf_module.cc:39-43) across the ranks of a sharded map: every rank
+    gets the records (VOXEL_TSDF_DTYPE) of all blocks inside `bounds`, whichever rank holds them.
+
+    `per_rank` is the all-gathered directory (DirectoryExchange.result()): it tells every rank,
+    without communication, how many records each rank will contribute -- so buffers are sized
+    exactly, ranks that own nothing inside the box send nothing, and a box owned by a single rank
+    needs one broadcast instead of an all-gather.  Record order: by rank, then the reference's order
+    (ascending hash-entry index) within a rank."""
+    import torch
+    import torch.distributed as dist
+    from ._abi import VOXEL_TSDF_DTYPE
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    nrec = [int(blocks_in_bounds(b, bounds, engine.voxel_size).sum()) * 512 for b in per_rank]
+    owners = [r for r in range(world) if nrec[r] > 0]
+    mine = engine.query(bounds) if nrec[rank] > 0 else np.empty(0, dtype=VOXEL_TSDF_DTYPE)
+    if len(mine) != nrec[rank]:
+        raise RuntimeError(f"rank {rank}: directory is stale ({len(mine)} records, directory says {nrec[rank]})")
+    if world == 1 or not owners:
+        return mine
+    dev = device if device is not None else "cpu"
+    if len(owners) == 1:
+        src = owners[0]
+        buf = torch.empty(nrec[src] * 4, dtype=torch.float32, device=dev)
+        if rank == src:
+            buf.copy_(torch.from_numpy(mine.view(np.float32).copy()))
+        dist.broadcast(buf, src=src)
+        return buf.cpu().numpy().view(VOXEL_TSDF_DTYPE)
+    width = max(nrec) * 4
+    send = torch.zeros(width, dtype=torch.float32, device=dev)
+    if len(mine):
+        send[:len(mine) * 4].copy_(torch.from_numpy(mine.view(np.float32).copy()))
+    recv = torch.empty(world * width, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    rows = recv.cpu().numpy().reshape(world, width)
+    return np.concatenate([rows[r, :nrec[r] * 4] for r in range(world)]).view(VOXEL_TSDF_DTYPE)
 
 
 def check_sharded_directories(per_rank, slab_bits=2):

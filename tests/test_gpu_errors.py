@@ -1,0 +1,114 @@
+"""Error paths of the HIP engine: every reachable RATSDF_ERR_* is reported as a status, nothing
+faults, and a fresh engine works afterwards."""
+import numpy as np
+import pytest
+
+from parity import assert_maps_equal
+from ratsdf import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _integrate(e, f):
+    e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+
+
+def test_resolver_capacity_is_reported_not_fatal(make_engine, make_oracle):
+    """A 512-bucket directory and a frame that asks for thousands of blocks: nearly every request
+    goes through the chained-bucket resolver, whose per-pass limits (16 384 requests, 1 024 distinct
+    blocks, 2 048 recorded locks; DESIGN "resolver limits") are exceeded -> status 4, no fault."""
+    import ratsdf
+    vs = 0.005
+    tiny = make_engine(vs, 6 * vs, bucket_bits=9)
+    f = synthetic.frame("room", 0, scale=0.5)
+    with pytest.raises(ratsdf.RatsdfError) as ei:
+        for _ in range(3):
+            _integrate(tiny, f)
+        tiny.synchronize()
+    assert ei.value.status == 4
+    # the engine object is still usable for inspection, and the error is sticky
+    assert tiny.num_active_blocks() > 0
+    with pytest.raises(ratsdf.RatsdfError):
+        tiny.synchronize()
+    tiny.close()
+    # a fresh engine with the default directory integrates the same frames like the oracle
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=8)
+    for _ in range(2):
+        _integrate(gpu, f)
+        _integrate(cpu, f)
+    assert_maps_equal(gpu, cpu)
+
+
+def test_pool_exhaustion_status_and_recovery(make_engine):
+    import ratsdf
+    vs = 0.01
+    small = make_engine(vs, 6 * vs, block_bits=6)   # 64 blocks
+    f = synthetic.frame("room", 0, scale=0.25)
+    with pytest.raises(ratsdf.RatsdfError) as ei:
+        _integrate(small, f)
+        small.synchronize()
+    assert ei.value.status == 3
+    assert small.num_active_blocks() <= 64
+
+
+def test_export_directory_reports_true_count_and_capacity_error(make_engine):
+    import torch
+    import ratsdf
+    vs = 0.02
+    gpu = make_engine(vs, 6 * vs)
+    for f in synthetic.stream("room", 2, scale=0.25):
+        _integrate(gpu, f)
+    n_true = gpu.num_active_blocks()
+    cap = 16
+    assert n_true > cap
+    buf = torch.zeros(cap * 3, dtype=torch.int32, device="cuda")
+    guard = torch.full((64,), 77, dtype=torch.int32, device="cuda")   # must stay untouched
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu.export_directory_device(buf.data_ptr(), cap, cnt.data_ptr())
+    with pytest.raises(ratsdf.RatsdfError) as ei:
+        gpu.synchronize()
+    assert ei.value.status == 4
+    assert int(cnt.item()) == n_true            # the true count, not the clamped one
+    assert int(guard.sum().item()) == 77 * 64
+    _, blocks = gpu.dump_directory()
+    from ratsdf._abi import BLOCK_DTYPE
+    assert np.array_equal(buf.cpu().numpy().view(BLOCK_DTYPE), blocks[:cap])
+
+
+def test_bad_arguments_are_rejected(make_engine):
+    import ratsdf
+    gpu = make_engine(0.02, 0.12)
+    f = synthetic.frame("room", 0, scale=0.25)
+    with pytest.raises(ratsdf.RatsdfError) as ei:
+        gpu.integrate_device(0, 0, 0, 0, 10, 10, 4.0, f["intrinsics"], f["pose"])
+    assert ei.value.status == 1
+    with pytest.raises(ratsdf.RatsdfError):
+        ratsdf.TSDFGrid(-1.0, 0.1)
+    with pytest.raises(ratsdf.RatsdfError):
+        ratsdf.TSDFGrid(0.01, 0.06, device=99)
+
+
+def test_entry_points_work_from_another_thread(make_engine, make_oracle):
+    """HIP's current device is per thread: an engine created on one thread must work when driven from
+    another (every entry point selects the engine's device itself; TSDFSystem's worker relies on it)."""
+    import threading
+    vs = 0.02
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    frames = synthetic.stream("room", 3, scale=0.25)
+    err = []
+
+    def work():
+        try:
+            for f in frames:
+                _integrate(gpu, f)
+            gpu.synchronize()
+        except Exception as ex:  # noqa: BLE001
+            err.append(ex)
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert not err, err
+    for f in frames:
+        _integrate(cpu, f)
+    assert_maps_equal(gpu, cpu)

@@ -63,6 +63,42 @@ def _worker(rank, world, port, mode, ret):
                 got |= set(zip(b["x"].tolist(), b["y"].tolist(), b["z"].tolist()))
             assert len(got ^ ref) <= 0.1 * len(ref), (len(got), len(ref), len(got ^ ref))
             assert total == len(got)
+            # Query across the shard seams == Query on the unsharded map (position-keyed: the record
+            # order is per rank), for a box with several owners, one with a single owner, an empty one
+            def keyed(rec):
+                k = np.stack([np.round(rec[c] / vs).astype(np.int64) for c in ("x", "y", "z")], axis=1)
+                o = np.lexsort((k[:, 2], k[:, 1], k[:, 0]))
+                return k[o], rec["tsdf"][o]
+            xs = np.concatenate([b["x"] for b in per_rank]).astype(np.float64) * 8 * vs
+            lo, hi = float(xs.min()), float(xs.max())
+            one_slab = float(per_rank[0]["x"][0]) * 8 * vs   # a 2-block-wide slab belongs to one rank
+            boxes = [(lo - 1, hi + 1, -5, 5, -5, 5), (-0.5, 0.5, -0.5, 0.5, 0.0, 3.0),
+                     (one_slab - 0.01, one_slab + 8 * vs + 0.01, -5, 5, -5, 5), (50, 51, 50, 51, 50, 51)]
+            seen = 0
+            for box in boxes:
+                got_rec = multi.query(eng, box, per_rank)
+                want_rec = single.query(box)
+                kg, tg = keyed(got_rec)
+                kw, tw = keyed(want_rec)
+                # blocks the sharded maps hold a frame earlier than the unsharded one (see above) can
+                # only add records: every record of the unsharded query must be there, equal
+                have = {tuple(r): float(v) for r, v in zip(kg.tolist(), tg.tolist())}
+                miss = [tuple(r) for r in kw.tolist() if tuple(r) not in have]
+                assert not miss, (box, len(miss))
+                same = sum(1 for r, v in zip(kw.tolist(), tw.tolist()) if have[tuple(r)] == float(v))
+                assert same >= 0.9 * len(kw), (box, same, len(kw))   # voxel values travel unchanged
+                assert len(kg) - len(kw) <= 0.1 * max(len(kw), 512), (box, len(kg), len(kw))
+                seen += len(kg)
+            assert seen > 0
+            # a directory that does not fit the exchange buffers is reported, not truncated
+            small = multi.DirectoryExchange(capacity=8)
+            small.fill_from_numpy(blocks)
+            small.all_gather()
+            try:
+                small.result()
+                raise AssertionError("truncated directory accepted")
+            except OverflowError:
+                pass
         else:
             counts = [len(b) for b in per_rank]
             assert counts[rank] == eng.num_active_blocks()
