@@ -18,11 +18,11 @@ def test_resolver_capacity_is_reported_not_fatal(make_engine, make_oracle):
     goes through the chained-bucket resolver, whose per-pass limits (16 384 requests, 1 024 distinct
     blocks, 2 048 recorded locks; DESIGN "resolver limits") are exceeded -> status 4, no fault."""
     import ratsdf
-    vs = 0.005
+    vs = 0.003
     tiny = make_engine(vs, 6 * vs, bucket_bits=9)
-    f = synthetic.frame("room", 0, scale=0.5)
+    f = synthetic.frame("room", 0)   # 640x480 at 3 mm: thousands of distinct blocks
     with pytest.raises(ratsdf.RatsdfError) as ei:
-        for _ in range(3):
+        for _ in range(4):  # two passes fill the home entries, then everything is a chained request
             _integrate(tiny, f)
         tiny.synchronize()
     assert ei.value.status == 4
@@ -32,10 +32,9 @@ def test_resolver_capacity_is_reported_not_fatal(make_engine, make_oracle):
         tiny.synchronize()
     tiny.close()
     # a fresh engine with the default directory integrates the same frames like the oracle
-    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=8)
-    for _ in range(2):
-        _integrate(gpu, f)
-        _integrate(cpu, f)
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+    _integrate(gpu, f)
+    _integrate(cpu, f)
     assert_maps_equal(gpu, cpu)
 
 
