@@ -7,6 +7,10 @@
 
 #include "types.hpp"
 
+#ifndef RATSDF_ABI_PREFIX
+#define RATSDF_ABI_PREFIX "ratsdf_"
+#endif
+
 namespace ratsdf {
 
 // Entry points of include/ratsdf.h resolved from one shared library.
@@ -34,8 +38,10 @@ struct Api {
   const char* (*backend)() = nullptr;
   void* handle = nullptr;
 
-  // path == nullptr: $RATSDF_LIB or libratsdf.so next to this layer; prefix: "ratsdf_"
-  static const Api& Load(const char* path = nullptr, const char* prefix = "ratsdf_");
+  // path == nullptr: $RATSDF_LIB or libratsdf.so next to this layer.  The symbol prefix is "ratsdf_"
+  // (the HIP engine); only test builds of this layer compile with another RATSDF_ABI_PREFIX to bind
+  // the CPU oracle's copy of the ABI -- the product binaries have no switch for it.
+  static const Api& Load(const char* path = nullptr, const char* prefix = RATSDF_ABI_PREFIX);
 };
 
 class TSDFGrid {

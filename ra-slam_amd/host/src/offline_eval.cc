@@ -11,7 +11,7 @@
 //     multiplied them into every pose (SURVEY 8b quirk iii, offline_eval.cc:57);
 //   * ScanNet .sens streams need a JPEG decoder and are not supported.
 //
-// usage: ratsdf_offline_eval <folder> [--lib libratsdf.so] [--prefix ratsdf_] [--voxel 0.01]
+// usage: ratsdf_offline_eval <folder> [--lib libratsdf.so] [--voxel 0.01]
 //          [--max-depth 6] [--device 0] [--frames N] [--download-all FILE] [--download-mesh PREFIX]
 //          [--reader-only] [--dump-frames DIR] [--threads N (decoder threads, default 4)]
 #include <chrono>
@@ -45,7 +45,6 @@ int main(int argc, char** argv) {
   }
   const std::string data_path = argv[1];
   const char* lib = nullptr;
-  const char* prefix = "ratsdf_";
   float voxel_size = 0.01f, max_depth = 6.f;  // offline_eval.cc:49-53
   int device = 0, max_frames = -1, threads = 4;
   std::string download_all, download_mesh, dump_dir;
@@ -60,7 +59,6 @@ int main(int argc, char** argv) {
       return argv[++i];
     };
     if (a == "--lib") lib = next();
-    else if (a == "--prefix") prefix = next();
     else if (a == "--voxel") voxel_size = strtof(next(), nullptr);
     else if (a == "--max-depth") max_depth = strtof(next(), nullptr);
     else if (a == "--device") device = atoi(next());
@@ -97,7 +95,7 @@ int main(int argc, char** argv) {
     std::unique_ptr<TSDFSystem> tsdf;
     if (!reader_only)
       tsdf = std::make_unique<TSDFSystem>(voxel_size, voxel_size * 6, max_depth, K, ext, device,
-                                          &Api::Load(lib, prefix));
+                                          &Api::Load(lib));
     fprintf(stderr, "[offline_eval] stream size %d (%dx%d)\n", n, reader.get_width(), reader.get_height());
     std::vector<float> poses;
     double t_read = 0;

@@ -22,6 +22,13 @@ def build():
     return EXE
 
 
+def build_oracle_bound():
+    """Test-only build of the harness whose host layer binds the CPU oracle's copy of the ABI
+    (RATSDF_ABI_PREFIX); the product binary has no switch for that."""
+    subprocess.run(["make", "-C", str(HOST), "test-oracle-eval"], check=True, capture_output=True)
+    return HOST / "build" / "test_offline_eval_oracle"
+
+
 def dump(folder, tmp):
     tmp.mkdir(parents=True, exist_ok=True)
     r = subprocess.run([str(build()), str(folder), "--reader-only", "--dump-frames", str(tmp)],
@@ -132,8 +139,8 @@ def test_offline_eval_on_cpu_oracle_matches_direct_integration(tmp_path, oracle_
     from ratsdf import pose as P
     write_folder(tmp_path / "ds", n=4, scale=0.1, factor=1000.0, scene="room")
     out = tmp_path / "map.bin"
-    r = subprocess.run([str(build()), str(tmp_path / "ds"), "--lib", str(oracle_lib.path), "--prefix",
-                        "ratsdf_oracle_", "--voxel", "0.04", "--max-depth", "6", "--download-all", str(out)],
+    r = subprocess.run([str(build_oracle_bound()), str(tmp_path / "ds"), "--lib", str(oracle_lib.path),
+                        "--voxel", "0.04", "--max-depth", "6", "--download-all", str(out)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     got = np.fromfile(out, dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("tsdf", "<f4"),
