@@ -217,7 +217,9 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
 #ifdef RATSDF_STAMPS
   cs[2] = clock64();
 #endif
-  __syncthreads();
+  // LDS-only barriers from here on: only the hash set and two counters are handed over, while
+  // __syncthreads() would also wait for the texel stores in flight (~1 us)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef RATSDF_STAMPS
   cs[3] = clock64();
   if (threadIdx.x == 0 && (wg & 15) == 0) {
@@ -237,7 +239,7 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
     if (i < kCandLdsSlots && L.keys[i] != kCandEmpty) pos[k] = atomicAdd(&L.n, 1u);
   }
   if (threadIdx.x == 0) L.base = reserved_at;
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   const uint32_t n = L.n;
   const uint32_t base = L.base;
   uint32_t base2 = 0;  // a second piece for a workgroup with more candidates than it reserved

@@ -109,31 +109,41 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
   const int gz = (int16_t)((int16_t)(item.z << 3) + tz);
   const float wy = (float)gy * P.vs, wz = (float)gz * P.vs;
   float phz[VPL];
-  int kk[VPL];
+  uint32_t kk[VPL];
   bool inb[VPL];
+  V3 ph[VPL];
+  bool fast = true;
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
     const int gx = (int16_t)((int16_t)(item.x << 3) + tx0 + j);         // :183-184
     const V3 pw{(float)gx * P.vs, wy, wz};                              // :187
     const V3 pc3 = se3_apply(P.T, pw);                                  // :190
-    const V3 ph = intr_mul(P.K, pc3);                                   // :193
-    // hnormalized(): two quotients with the same divisor (shared-divisor form, device_math.h; the
-    // plain IEEE divisions for a depth outside its validity range -- ph.z == 0 happens: a voxel in
-    // the camera plane -- or non-finite numerators)
+    ph[j] = intr_mul(P.K, pc3);                                         // :193
+    fast = fast && recip_safe(ph[j].z);
+  }
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    // hnormalized(): two quotients with the same divisor (shared-divisor form, device_math.h: the
+    // correctly rounded quotient for |z| in (1e-18, 1e18) and |x / z| below the overflow threshold,
+    // i.e. for every pose with coordinates below ~1e18 m); the plain IEEE divisions for a depth
+    // outside that range -- z == 0 happens: a voxel in the camera plane.  One test for the lane's
+    // voxels together.
     float qu, qv;
-    if (recip_safe(ph.z) && fabsf(ph.x) < 1e18f && fabsf(ph.y) < 1e18f) {
-      const Recip rz = make_recip(ph.z);
-      qu = div_shared(ph.x, rz);
-      qv = div_shared(ph.y, rz);
+    if (fast) {
+      const Recip rz = make_recip(ph[j].z);
+      qu = div_shared(ph[j].x, rz);
+      qv = div_shared(ph[j].y, rz);
     } else {
-      qu = ph.x / ph.z;
-      qv = ph.y / ph.z;
+      qu = ph[j].x / ph[j].z;
+      qv = ph[j].y / ph[j].z;
     }
     const int u = f2i(roundf(qu));                                      // :196-199
     const int w = f2i(roundf(qv));                                      // :202
-    inb[j] = u >= 0 && u < P.W && w >= 0 && w < P.H;                    // :205
-    kk[j] = inb[j] ? w * P.W + u : 0;
-    phz[j] = ph.z;
+    // 0 <= u < W && 0 <= w < H (:205) as two unsigned compares; no branch around the index
+    inb[j] = (uint32_t)u < (uint32_t)P.W && (uint32_t)w < (uint32_t)P.H;
+    const uint32_t k = (uint32_t)w * (uint32_t)P.W + (uint32_t)u;
+    kk[j] = inb[j] ? k : 0u;
+    phz[j] = ph[j].z;
   }
   WSTAMP(1);
   float4 ta[VPL];
@@ -269,6 +279,11 @@ __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, 
   }
 }
 
+// threads per update workgroup (VPL >= 2): 256 = one voxel block per workgroup at VPL 2
+#ifndef RATSDF_INTEG_NT
+#define RATSDF_INTEG_NT 256
+#endif
+
 // What every wave of the voxel update needs, by value (scalar registers).
 struct IntegArgs {
   uint32_t* rgbw;
@@ -293,7 +308,7 @@ struct IntegArgs {
 // candidate pass (`ahead`, kernels_cand.h): the update is bound by memory latency and leaves the
 // vector ALUs mostly idle, the candidate pass is ALU work on other inputs.
 template <int VPL>
-__global__ __launch_bounds__(VPL == 1 ? 512 : 256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
+__global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
     IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, CandJob ahead) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
   if (blockIdx.x >= n_int_wg) {

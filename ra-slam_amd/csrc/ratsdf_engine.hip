@@ -569,9 +569,9 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
                         ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid, ahead_c)
   switch (vpl) {
     case 1: RATSDF_LAUNCH_INTEGRATE(1, 512); break;
-    case 8: RATSDF_LAUNCH_INTEGRATE(8, 256); break;
-    case 4: RATSDF_LAUNCH_INTEGRATE(4, 256); break;
-    default: RATSDF_LAUNCH_INTEGRATE(2, 256);
+    case 8: RATSDF_LAUNCH_INTEGRATE(8, RATSDF_INTEG_NT); break;
+    case 4: RATSDF_LAUNCH_INTEGRATE(4, RATSDF_INTEG_NT); break;
+    default: RATSDF_LAUNCH_INTEGRATE(2, RATSDF_INTEG_NT);
   }
 #undef RATSDF_LAUNCH_INTEGRATE
 
@@ -1813,9 +1813,9 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
                         ev1, 0, engs, cur, nxt, (uint32_t)gg.grid, gg.c)
     switch (e0->vpl) {
       case 1: RATSDF_LAUNCH_INTEGRATE_G(1, 512); break;
-      case 8: RATSDF_LAUNCH_INTEGRATE_G(8, 256); break;
-      case 4: RATSDF_LAUNCH_INTEGRATE_G(4, 256); break;
-      default: RATSDF_LAUNCH_INTEGRATE_G(2, 256);
+      case 8: RATSDF_LAUNCH_INTEGRATE_G(8, RATSDF_INTEG_NT); break;
+      case 4: RATSDF_LAUNCH_INTEGRATE_G(4, RATSDF_INTEG_NT); break;
+      default: RATSDF_LAUNCH_INTEGRATE_G(2, RATSDF_INTEG_NT);
     }
 #undef RATSDF_LAUNCH_INTEGRATE_G
     if (g->profiling && g->prof_used >= 4096) {
