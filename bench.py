@@ -46,9 +46,11 @@ def parse():
     ap.add_argument("--max-depth", type=float, default=4.0)
     ap.add_argument("--cpu-frames", type=int, default=1080,
                     help="frames of the stream timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--config", default="vga5mm", choices=["vga5mm", "hd2mm"],
+    ap.add_argument("--config", default="vga5mm", choices=["vga5mm", "hd2mm", "bigmap"],
                     help="vga5mm: BASELINE metric config (640x480, 5 mm); hd2mm: 1280x720, 2 mm "
-                         "(BASELINE configs[3] workload, single GPU unless --shard)")
+                         "(BASELINE configs[3] workload, single GPU unless --shard); bigmap: hd2mm on a "
+                         "120-degree sweep whose map (> 256 MiB of voxel data, revisited only after a "
+                         "whole sweep) cannot stay in the Infinity Cache: the HBM figure of the repo")
     ap.add_argument("--shard", action="store_true",
                     help="N > 1: every rank integrates the SAME stream and owns the blocks "
                          "owner(block) == rank (spatial subvolumes, strong scaling) instead of "
@@ -82,7 +84,8 @@ def alg_bytes(W, H, tot):
 
 
 def traffic_file(config):
-    return ROOT / "profiles" / ("traffic_latest.json" if config == "vga5mm" else "traffic_hd2mm.json")
+    name = {"vga5mm": "traffic_latest.json", "hd2mm": "traffic_hd2mm.json"}.get(config, f"traffic_{config}.json")
+    return ROOT / "profiles" / name
 
 
 def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", engines=1):
@@ -256,6 +259,16 @@ def main():
             a.frames_per_step = 30
         if a.cpu_frames == 1080:
             a.cpu_frames = 60
+    if a.config == "bigmap":
+        a.cam, a.voxel = "l515_720p", 0.002
+        if a.frames_per_step == 90:
+            a.frames_per_step = 240      # 120 frames of a 1 degree/frame sweep, there and back
+        if a.steps == 60:
+            a.steps, a.warmup, a.reps = 2, 1, 3
+        if a.cpu_frames == 1080:
+            a.cpu_frames = 8             # parity on the first frames only (the CPU runs ~30 frames/s)
+        a.host_frames = 0
+        a.streams = 0
     vs = a.voxel
     B = a.frames_per_step
     half = (B + 1) // 2
@@ -512,7 +525,10 @@ def main():
                       "alg_bytes": round(b_alg), "alg_gbps_whole_frame": round(b_alg * fps / world / 1e9, 1),
                       "active_blocks": stats["active_blocks"],
                       "avg_allocated_blocks": round(tot["allocated_blocks"] / max(tot["frames"], 1), 2),
-                      "avg_deleted_blocks": round(tot["deleted_blocks"] / max(tot["frames"], 1), 2)},
+                      "avg_deleted_blocks": round(tot["deleted_blocks"] / max(tot["frames"], 1), 2),
+                      # voxel data of the map (3 pools x 512 voxels x 4 B per block): what has to
+                      # exceed the 256 MiB Infinity Cache before traffic figures mean HBM
+                      "map_voxel_bytes": stats["active_blocks"] * 6144},
             # host cost of a frame's three launches on an idle queue / GPU time per frame
             "host_enqueue_us_per_frame": round(enq_us, 2) if enq_us else None,
             "host_enqueue_frac": round(enq_us * 1e-6 / (dt / nframes), 3) if enq_us else None,
