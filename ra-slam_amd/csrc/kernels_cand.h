@@ -160,6 +160,7 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   uint32_t prev0 = kInf, prev1 = kInf;  // this lane's previous sample
   for (int i = 0; i < P.S; ++i) {       // uniform trip count: the shuffles below need every lane
     const bool act = valid && i <= steps;
+    if (!__any(act)) break;             // (uniform) no ray of the wave reaches this sample
     const int gx = (int16_t)f2i(roundf(p.x)), gy = (int16_t)f2i(roundf(p.y)),
               gz = (int16_t)f2i(roundf(p.z));                           // :163-164
     const int bx = gx >> 3, by = gy >> 3, bz = gz >> 3;

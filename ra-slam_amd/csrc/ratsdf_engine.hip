@@ -482,9 +482,10 @@ ratsdf_engine::Geom ratsdf_engine::geometry(int H, int W, bool has_next, int spl
   if (cand_parts_env) parts = cand_parts_env;
   g.parts = parts;
   g.n_front_wg = g.n_vis_wg + kCandSegs * parts + kReleaseWGs + (g.a.n_tiles + 3) / 4;
-  // more workgroups for images with several times more visible blocks than 640x480 (measured:
-  // 1280x720 / 2 mm runs 6 % faster with 8192)
-  g.grid = grid_from_env ? integrate_grid : (npix >= 600000 ? 8192u : 4096u);
+  // more workgroups for images with several times more visible blocks than 640x480: one voxel block
+  // per workgroup beats a loop over blocks (measured at 1280x720 / 2 mm, 13 k - 22 k visible blocks:
+  // 8192 -> 16384 workgroups -3 % kernel time, 24576 no better; profiles/r02_grid_sweep.txt)
+  g.grid = grid_from_env ? integrate_grid : (npix >= 600000 ? 16384u : 4096u);
   return g;
 }
 
