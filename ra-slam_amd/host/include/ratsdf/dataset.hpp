@@ -11,7 +11,7 @@
 //     <folder>/<id>_rgb.png            8-bit colour, returned in RGB order (folder_reader.cc:68-70)
 //     <folder>/<id>_depth.png          16-bit grey, returned unchanged (cv::IMREAD_UNCHANGED, :60)
 //
-// PNG decoding is a small zlib-based reader (png.cc) restricted to what cv::imread produces for such
+// PNG decoding is a small zlib-based reader (dataset.cc) restricted to what cv::imread produces for such
 // files: non-interlaced, colour types 0 / 2 / 3 / 4 / 6, bit depth 8 or 16.  Colour reads follow
 // cv::imread's default flag (8-bit 3 channels: grey is replicated, alpha dropped, 16-bit samples
 // keep their high byte), depth reads keep 16-bit samples as they are.
@@ -48,6 +48,18 @@ class YamlLite {
   std::map<std::string, std::string> values_;
 };
 
+// 8-bit RGB image, row-major
+struct RgbImage {
+  int width = 0, height = 0;
+  std::vector<uint8_t> data;
+};
+// Baseline / extended-sequential Huffman JPEG (jpeg.cc): output identical to the IJG library's default
+// decoding path (accurate integer IDCT, fancy upsampling).  Throws std::runtime_error naming `name`.
+RgbImage decode_jpeg(const uint8_t* data, size_t size, const std::string& name);
+// cv::resize(src CV_8UC3, dst, cv::Size(out_w, out_h)) with its default INTER_LINEAR, as OpenCV
+// evaluates it for 8-bit images (11-bit fixed-point coefficients; see oracle/segmentation_oracle.py)
+RgbImage resize_rgb_linear(const RgbImage& src, int out_w, int out_h);
+
 struct LogEntry {  // folder_reader.h:31-34
   int id;
   SE3<float> cam_T_world;
@@ -57,18 +69,34 @@ struct LogEntry {  // folder_reader.h:31-34
 // cv::Mat::convertTo(CV_32FC1, 1. / factor) = (float)sample * (float)(1.0 / factor)
 std::vector<float> depth_to_metres(const PngImage& depth, float depthmap_factor);
 
-class folder_reader {  // same member names as the reference class
+// utils/offline_data_provider/offline_data_provider.h:21-94 (same member names; const, and PngImage
+// in place of cv::Mat)
+class offline_data_provider {
+ public:
+  virtual ~offline_data_provider() = default;
+  virtual CameraIntrinsics<float> get_camera_intrinsics() const = 0;
+  virtual SE3<float> get_camera_extrinsics() const = 0;
+  virtual float get_depth_map_factor() const = 0;
+  virtual void get_depth_frame_by_id(PngImage* depth_img, int frame_idx) const = 0;  // 16-bit, as stored
+  virtual void get_color_frame_by_id(PngImage* rgb_img, int frame_idx) const = 0;    // 8-bit RGB
+  virtual SE3<float> get_camera_pose_by_id(int frame_idx) const = 0;
+  virtual int get_size() const = 0;
+  virtual int get_width() const = 0;
+  virtual int get_height() const = 0;
+};
+
+class folder_reader : public offline_data_provider {  // same member names as the reference class
  public:
   explicit folder_reader(const std::string& folder_path);
-  CameraIntrinsics<float> get_camera_intrinsics() const;
-  SE3<float> get_camera_extrinsics() const;
-  float get_depth_map_factor() const { return depth_factor_; }
-  void get_depth_frame_by_id(PngImage* depth_img, int frame_idx) const;  // as stored
-  void get_color_frame_by_id(PngImage* rgb_img, int frame_idx) const;    // 8-bit RGB
-  SE3<float> get_camera_pose_by_id(int frame_idx) const;
-  int get_size() const { return size_; }
-  int get_width() const { return width_; }
-  int get_height() const { return height_; }
+  CameraIntrinsics<float> get_camera_intrinsics() const override;
+  SE3<float> get_camera_extrinsics() const override;
+  float get_depth_map_factor() const override { return depth_factor_; }
+  void get_depth_frame_by_id(PngImage* depth_img, int frame_idx) const override;  // as stored
+  void get_color_frame_by_id(PngImage* rgb_img, int frame_idx) const override;    // 8-bit RGB
+  SE3<float> get_camera_pose_by_id(int frame_idx) const override;
+  int get_size() const override { return size_; }
+  int get_width() const override { return width_; }
+  int get_height() const override { return height_; }
 
  private:
   std::vector<LogEntry> parse_log_entries() const;
@@ -77,6 +105,44 @@ class folder_reader {  // same member names as the reference class
   std::vector<LogEntry> log_entries_;
   int size_ = 0, width_ = 0, height_ = 0;
   float depth_factor_ = 1.f;
+};
+
+// ScanNet .sens stream (third_party/scannet/sensorData.hpp: version 4 container, JPEG or raw colour,
+// zlib or raw 16-bit depth) behind the reference's reader interface
+// (utils/offline_data_provider/scannet_sens_reader.{h,cc}:8-82): intrinsics of the DEPTH camera,
+// identity extrinsics (asserted by the reference, checked here), depth as stored (16-bit, to be
+// divided by get_depth_map_factor() = m_depthShift), colour decoded and resized to 640 x 480 like
+// the depth (scannet_sens_reader.cc:61-62), pose = inverse of the stored camera-to-world matrix.
+class scannet_sens_reader : public offline_data_provider {
+ public:
+  explicit scannet_sens_reader(const std::string& sens_filepath);
+  CameraIntrinsics<float> get_camera_intrinsics() const override;
+  SE3<float> get_camera_extrinsics() const override;
+  float get_depth_map_factor() const override { return depth_shift_; }
+  void get_depth_frame_by_id(PngImage* depth_img, int frame_idx) const override;  // 16-bit, 1 channel
+  void get_color_frame_by_id(PngImage* rgb_img, int frame_idx) const override;    // 8-bit RGB, 640 x 480
+  SE3<float> get_camera_pose_by_id(int frame_idx) const override;
+  int get_size() const override { return (int)frames_.size(); }
+  int get_width() const override { return 640; }    // scannet_sens_reader.cc:78-81
+  int get_height() const override { return 480; }
+  // beyond the reference: what the header says
+  int color_width() const { return (int)color_w_; }
+  int color_height() const { return (int)color_h_; }
+  int depth_width() const { return (int)depth_w_; }
+  int depth_height() const { return (int)depth_h_; }
+
+ private:
+  struct FrameRec {
+    float cam_to_world[16];
+    size_t color_off, color_size, depth_off, depth_size;
+  };
+  std::string path_;
+  std::vector<uint8_t> file_;  // the whole stream (ScanNet scenes: a few hundred MB to a few GB)
+  float color_intr_[16], color_extr_[16], depth_intr_[16], depth_extr_[16];
+  int32_t color_type_ = -1, depth_type_ = -1;
+  uint32_t color_w_ = 0, color_h_ = 0, depth_w_ = 0, depth_h_ = 0;
+  float depth_shift_ = 1000.f;
+  std::vector<FrameRec> frames_;
 };
 
 // Frames of a folder in order, decoded ahead of the consumer by a few threads (a 640x480 PNG pair
@@ -90,7 +156,7 @@ struct Frame {
 
 class FramePrefetcher {
  public:
-  FramePrefetcher(const folder_reader& reader, int n_frames, int threads);
+  FramePrefetcher(const offline_data_provider& reader, int n_frames, int threads);
   ~FramePrefetcher();
   bool next(Frame* out);  // false after the last frame; rethrows a decoding error of that frame
 
@@ -101,7 +167,7 @@ class FramePrefetcher {
     int ready_for = -1;
   };
   void work();
-  const folder_reader& reader_;
+  const offline_data_provider& reader_;
   const int n_;
   std::vector<Slot> slots_;
   std::vector<std::thread> workers_;

@@ -327,7 +327,7 @@ std::vector<LogEntry> folder_reader::parse_log_entries() const {  // :86-105
 }
 
 // ---- prefetching frame source -----------------------------------------------------------------
-FramePrefetcher::FramePrefetcher(const folder_reader& reader, int n_frames, int threads)
+FramePrefetcher::FramePrefetcher(const offline_data_provider& reader, int n_frames, int threads)
     : reader_(reader), n_(n_frames), slots_((size_t)std::max(2, 2 * std::max(1, threads))) {
   for (int t = 0; t < std::max(1, threads); ++t) workers_.emplace_back([this] { work(); });
 }

@@ -9,7 +9,8 @@
 //     the last Integrate, which drops whatever is still queued (SURVEY 8b quirk i);
 //   * kept as is: the reader's extrinsics are passed to TSDFSystem although folder_reader has already
 //     multiplied them into every pose (SURVEY 8b quirk iii, offline_eval.cc:57);
-//   * ScanNet .sens streams need a JPEG decoder and are not supported.
+//   * <folder> may be a ScanNet .sens stream (scannet_sens_reader, as examples/scannet_evaluation/
+//     eval_one.cc:41-87 uses it).
 //
 // usage: ratsdf_offline_eval <folder> [--lib libratsdf.so] [--voxel 0.01]
 //          [--max-depth 6] [--device 0] [--frames N] [--download-all FILE] [--download-mesh PREFIX]
@@ -73,12 +74,12 @@ int main(int argc, char** argv) {
       return 2;
     }
   }
-  if (data_path.size() > 5 && data_path.substr(data_path.size() - 5) == ".sens") {
-    fprintf(stderr, "ScanNet .sens streams are not supported (they need a JPEG decoder)\n");
-    return 3;
-  }
+  const bool is_sens = data_path.size() > 5 && data_path.substr(data_path.size() - 5) == ".sens";
   try {
-    folder_reader reader(data_path);
+    std::unique_ptr<offline_data_provider> provider;
+    if (is_sens) provider = std::make_unique<scannet_sens_reader>(data_path);
+    else provider = std::make_unique<folder_reader>(data_path);
+    const offline_data_provider& reader = *provider;
     int n = reader.get_size();
     if (max_frames >= 0 && max_frames < n) n = max_frames;
     const CameraIntrinsics<float> K = reader.get_camera_intrinsics();

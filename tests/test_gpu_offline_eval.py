@@ -45,3 +45,37 @@ def test_offline_eval_on_hip_engine(tmp_path, make_oracle):
     t = np.fromfile(tmp_path / "mesh_indices.bin", dtype="<i4").reshape(-1, 3)
     p = np.fromfile(tmp_path / "mesh_vertices_prob.bin", dtype="<f4")
     assert len(v) > 0 and len(p) == len(v) and t.min() >= 0 and t.max() < len(v)
+
+
+def test_offline_eval_on_a_sens_stream(tmp_path, make_oracle):
+    """A ScanNet .sens stream (committed fixture tests/golden/tiny.sens) through the harness on the HIP
+    engine == the CPU oracle fed with the frames as Python decodes them (PIL JPEG + numpy resize)."""
+    import io
+    import make_sens as M
+    import segmentation_oracle as S
+    from PIL import Image
+    from ratsdf import pose as P
+    from test_dataset_reader import build
+    frames = M.synthetic_frames(3, color_hw=(97, 130))          # what tiny.sens was written from
+    kw = dict(quality=85, subsampling="4:2:0")
+    out = tmp_path / "map.bin"
+    lib = ROOT / "ra-slam_amd" / "csrc" / "build" / "libratsdf.so"
+    r = subprocess.run([str(build()), str(ROOT / "tests" / "golden" / "tiny.sens"), "--lib", str(lib), "--voxel",
+                        "0.02", "--max-depth", "4", "--download-all", str(out)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(out, dtype=REC)
+    cpu = make_oracle(0.02, 0.12)
+    K = tuple(float(np.float32(v)) for v in (577.87, 577.87, 319.5, 239.5))
+    for f in frames:
+        full = np.asarray(Image.open(io.BytesIO(M.encode_jpeg(f["rgb"], **kw))).convert("RGB"))
+        rgb = S.resize_u8_linear(full, 480, 640)
+        depth = f["depth"].astype(np.float32) * np.float32(1.0 / 1000.0)
+        cpu.integrate(rgb, depth, None, None, 4.0, K, P.invert(P.pose_from_matrix(f["cam_to_world"])))
+    exp = cpu.gather_valid_semantic()
+    assert len(got) == len(exp) and len(got) > 1000
+    key = lambda a: np.lexsort((a["z"], a["y"], a["x"]))
+    g, e = got[key(got)], exp[key(exp)]
+    for k in ("x", "y", "z"):
+        assert np.array_equal(g[k], e[k]), k
+    assert np.max(np.abs(g["tsdf"] - e["tsdf"])) <= 1e-4
