@@ -128,7 +128,7 @@ def test_bad_inputs_fail_loudly(tmp_path):
     r = subprocess.run([str(build()), str(folder), "--reader-only"], capture_output=True, text=True)
     assert r.returncode == 1 and "camera_config.yaml" in r.stderr
     r = subprocess.run([str(build()), "scene.sens"], capture_output=True, text=True)
-    assert r.returncode == 3 and "not supported" in r.stderr
+    assert r.returncode == 1 and "could not open" in r.stderr     # .sens streams: tests/test_sens_reader.py
 
 
 def test_offline_eval_on_cpu_oracle_matches_direct_integration(tmp_path, oracle_lib, make_oracle):
