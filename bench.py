@@ -103,6 +103,9 @@ def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", en
             traffic = None
     return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src,
+                launch_also_hosts=("60 % of the NEXT frame's candidate pass (its workgroups come first "
+                                   "in the grid; engine default at 640x480)" if config == "vga5mm" and
+                                   engines == 1 else None),
                 alg_bytes_per_launch=round(b_alg_per_launch), avg_launch_us=round(k_avg_s * 1e6, 2),
                 launches=k_n)
 

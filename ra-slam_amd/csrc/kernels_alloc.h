@@ -27,7 +27,13 @@
 
 namespace ratsdf {
 
-__device__ inline void set_error(Ctl* ctl, uint32_t code) { atomicCAS(&ctl->error, 0u, code); }
+// (the operands are pinned to the call site: hoisted out of a hot loop as loop invariants they were
+// the first thing the register allocator spilled to scratch memory, for a path that is never taken)
+__device__ inline void set_error(Ctl* ctl, uint32_t code) {
+  uint32_t expect = 0u, value = code;
+  asm volatile("" : "+v"(expect), "+v"(value));
+  atomicCAS(&ctl->error, expect, value);
+}
 // one thread: the words of a FrameCtl that are in use
 __device__ inline void zero_frame_ctl(FrameCtl* F) {
   uint32_t* z = reinterpret_cast<uint32_t*>(F);

@@ -308,16 +308,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_ca
 // voxel update of several engines (kernels_integrate.h: integrate_body)
 template <int VPL>
 __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate_g(
-    EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_int_wg, AheadGeom ag) {
+    EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_int_wg, uint32_t n_ahead_wg, AheadGeom ag) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
   EnginePtr E = engs + blockIdx.y;
-  if (blockIdx.x >= n_int_wg) {
+  if (blockIdx.x < n_ahead_wg) {  // look-ahead workgroups first (k_integrate)
     if (VPL != 1) {
       const CandJob ahead = make_cand_job(E, nxt + blockIdx.y, ag);
-      cand_pixels_role(ahead, blockIdx.x - n_int_wg, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
+      cand_pixels_role(ahead, blockIdx.x, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
     }
     return;
   }
+  const uint32_t ibid = blockIdx.x - n_ahead_wg;
   JobPtr J = cur + blockIdx.y;
   const uint32_t par = J->par;
   IntegArgs A;

@@ -249,7 +249,7 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
 template <int WPB>
 __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, const VisItem& item,
                                     bool active, float m, uint32_t nupd, uint32_t wv, uint32_t part,
-                                    uint32_t lane, uint32_t phase, float (*smin)[8],
+                                    uint32_t lane, uint32_t phase, uint32_t counter, float (*smin)[8],
                                     uint32_t (*supd)[8]) {
   m = wave_min(m);
   nupd = wave_sum(nupd);
@@ -270,7 +270,7 @@ __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, 
     }
   }
   if (fin) {
-    if (nupd) atomicAdd(&upd_wg[blockIdx.x & (kUpdCounters - 1)], nupd);
+    if (nupd) atomicAdd(&upd_wg[counter & (kUpdCounters - 1)], nupd);
     if (m >= .9f) {  // rare: operands come from the engine record, not from registers held all along
       const Table tab = ld_const(&E->tab);
       const CarveBufs cb = ld_const(&E->cb);
@@ -309,12 +309,16 @@ struct IntegArgs {
 // vector ALUs mostly idle, the candidate pass is ALU work on other inputs.
 template <int VPL>
 __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
-    IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, CandJob ahead) {
+    IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, uint32_t n_ahead_wg, CandJob ahead) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
-  if (blockIdx.x >= n_int_wg) {
-    if (VPL != 1) cand_pixels_role(ahead, blockIdx.x - n_int_wg, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
+  // the look-ahead workgroups come FIRST in the grid (a multiple of 8 of them, so that the update
+  // workgroups keep their list <-> XCD mapping): they start at once and are done before the last
+  // update workgroups are, instead of extending the launch at its end
+  if (blockIdx.x < n_ahead_wg) {
+    if (VPL != 1) cand_pixels_role(ahead, blockIdx.x, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
     return;
   }
+  const uint32_t ibid = blockIdx.x - n_ahead_wg;
 #include "integrate_body.inc"
 }
 

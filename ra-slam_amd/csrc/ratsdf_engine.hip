@@ -94,8 +94,8 @@ struct ratsdf_engine {
   unsigned parity = 0;                   // which texel buffer / candidate set the NEXT frame uses
   bool cand_ready = false;               // that frame's candidate pass has already been enqueued
   bool cand_split_env = false;
-  unsigned cand_split = 60;              // percent of the look-ahead pass placed in k_front,
-  unsigned cand_split_b = 40;            // in k_alloc_rank; the rest rides in k_integrate
+  unsigned cand_split = 40;              // percent of the look-ahead pass placed in k_front,
+  unsigned cand_split_b = 0;             // in k_alloc_rank; the rest rides in k_integrate
   unsigned cand_parts_env = 0;           // RATSDF_CAND_PARTS: consumer workgroups per candidate list
   unsigned cand_wgs = 248;               // look-ahead workgroups per host kernel (about one per CU)
   // dynamic LDS of k_alloc_rank: the serial role needs kSerialLdsBytes; asking for more than half a
@@ -503,10 +503,13 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     const CandJob job = cand_job(cur, P, par);
     hipLaunchKernelGGL(k_cand, dim3((job.n_tiles + 3) / 4), dim3(256), 0, stream, job, ctl);
   }
-  // share of k_front: 60 % at 640x480; larger images leave k_alloc_rank's 1024-thread workgroups
-  // more than one round of tiles, so k_front takes more (measured at 1280x720)
-  const int split = (int)(cand_split_env ? cand_split : (npix >= 600000 ? 80u : cand_split));
-  const int split_b = (int)(cand_split_env ? cand_split_b : 100u - (unsigned)split);
+  // Where the NEXT frame's candidate pass rides (interleaved A/B, profiles/r02_split_ab.txt): at
+  // 640x480 40 % in k_front and the rest at the head of k_integrate's grid (+6.6 % frames/s over
+  // 60 % / 40 % in k_front / k_alloc_rank: the serial launch stays short, and the pass overlaps the
+  // memory-latency-bound voxel update); at 1280x720 all of it in k_front (differences below 1.5 %,
+  // and k_integrate stays the pure voxel update its roofline figure is about)
+  const int split = (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
+  const int split_b = (int)(cand_split_env ? cand_split_b : 0u);
   const Geom g = geometry(H, W, next != nullptr, split, split_b);
   // shares of the next frame's candidate pass: k_front, k_alloc_rank, k_integrate
   CandJob ahead_a, ahead_b, ahead_c;
@@ -554,7 +557,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // hipExtLaunchKernelGGL attaches the two events to the dispatch itself: their difference is the
   // kernel's own start-to-end time (what rocprofv3 reports), without the barrier packets that
   // hipEventRecord before / after a launch would add (~3 us here).  Null events = a plain launch.
-  const unsigned extra_c = (ahead_c.n_tiles + 3) / 4;
+  const unsigned extra_c = ((ahead_c.n_tiles + 3) / 4 + 7u) & ~7u;  // whole groups of 8 (XCD mapping)
   IntegArgs ia;
   ia.rgbw = pool.rgbw;
   ia.tsdf = pool.tsdf;
@@ -567,7 +570,8 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   ia.upd_wg = upd_wg;
 #define RATSDF_LAUNCH_INTEGRATE(V, NT)                                                              \
   hipExtLaunchKernelGGL(k_integrate<V>, dim3(integrate_grid + extra_c), dim3(NT), 0, stream, ev0,   \
-                        ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid, ahead_c)
+                        ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid, (uint32_t)extra_c,      \
+                        ahead_c)
   switch (vpl) {
     case 1: RATSDF_LAUNCH_INTEGRATE(1, 512); break;
     case 8: RATSDF_LAUNCH_INTEGRATE(8, RATSDF_INTEG_NT); break;
@@ -1808,10 +1812,10 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
       ev1 = g->prof_events[g->prof_used].second;
       ++g->prof_used;
     }
-    const unsigned extra_c = (gg.c.n_tiles + 3) / 4;
+    const unsigned extra_c = ((gg.c.n_tiles + 3) / 4 + 7u) & ~7u;
 #define RATSDF_LAUNCH_INTEGRATE_G(V, NT)                                                            \
   hipExtLaunchKernelGGL(k_integrate_g<V>, dim3(gg.grid + extra_c, S), dim3(NT), 0, g->stream, ev0,  \
-                        ev1, 0, engs, cur, nxt, (uint32_t)gg.grid, gg.c)
+                        ev1, 0, engs, cur, nxt, (uint32_t)gg.grid, (uint32_t)extra_c, gg.c)
     switch (e0->vpl) {
       case 1: RATSDF_LAUNCH_INTEGRATE_G(1, 512); break;
       case 8: RATSDF_LAUNCH_INTEGRATE_G(8, RATSDF_INTEG_NT); break;
