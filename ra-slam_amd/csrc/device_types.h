@@ -204,7 +204,7 @@ struct RankBufs {
 struct EngineDev {
   Table tab;
   Pool pool;
-  CarveBufs cb;
+  CarveBufs cb[2];  // per frame parity
   RankBufs rb;
   Ctl* ctl;
   ratsdf_frame_stats* stats;

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fr
   const RankBufs rb = ld_const(&E->rb);
   front_body(ld_const(&E->tab), ld_const(&J->P), n_vis_wg, ld_const(&E->cand[par]), cand_parts, rb.req,
              rb.req_cap, E->slow, E->slow_cap, E->vis, E->seg_cap, ld_const(&E->pool),
-             ld_const(&E->cb), E->ctl, par, [&]() { return make_cand_job(E, nxt + blockIdx.y, ag); },
+             ld_const(&E->cb[par ^ 1u]), E->ctl, par, [&]() { return make_cand_job(E, nxt + blockIdx.y, ag); },
              role_lds);
 }
 
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(1024) void k_alloc_rank_g(EnginePtr engs, JobPtr cu
   RankBufs rb = ld_const(&E->rb);
   const FrameParams P = ld_const(&cur[blockIdx.y].P);
   rb.nwords = ((uint32_t)(P.W * P.H) * (uint32_t)P.S + 31u) / 32u;
-  serial_frame_role(ld_const(&E->tab), ld_const(&E->pool), rb, ld_const(&E->cb), E->ctl, par, E->stats,
+  serial_frame_role(ld_const(&E->tab), ld_const(&E->pool), rb, ld_const(&E->cb[par ^ 1u]), E->ctl, par, E->stats,
                     skeys);
 }
 
@@ -330,7 +330,8 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((am
   A.vis = E->vis;
   A.seg_cap = E->seg_cap;
   A.F = &E->ctl->fr[par];
-  A.upd_wg = E->cb.upd_wg;
+  A.upd_wg = E->cb[par].upd_wg;
+  A.par = par;
   const FrameParams P = ld_const(&J->P);
 #include "integrate_body.inc"
 }

@@ -247,7 +247,8 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
 // smin / supd: [2][8] words, used alternately by consecutive calls (`phase` = call parity), so one
 // LDS-only barrier per call is enough: a wave can only be one call ahead of the slowest reader.
 template <int WPB>
-__device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, const VisItem& item,
+__device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, uint32_t par,
+                                    const VisItem& item,
                                     bool active, float m, uint32_t nupd, uint32_t wv, uint32_t part,
                                     uint32_t lane, uint32_t phase, uint32_t counter, float (*smin)[8],
                                     uint32_t (*supd)[8]) {
@@ -273,7 +274,7 @@ __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, 
     if (nupd) atomicAdd(&upd_wg[counter & (kUpdCounters - 1)], nupd);
     if (m >= .9f) {  // rare: operands come from the engine record, not from registers held all along
       const Table tab = ld_const(&E->tab);
-      const CarveBufs cb = ld_const(&E->cb);
+      const CarveBufs cb = ld_const(&E->cb[par]);
       carve_candidate(tab, cb, E->ctl, F, item);
     }
   }
@@ -295,6 +296,7 @@ struct IntegArgs {
   uint32_t seg_cap;
   FrameCtl* F;
   uint32_t* upd_wg;
+  uint32_t par;  // frame parity: which of the engine's two counter / list sets the frame uses
 };
 
 // Work lists: `vis` is kNumLists segments of seg_cap items holding the visible blocks that existed

@@ -121,8 +121,9 @@ struct ratsdf_engine {
   uint32_t* wg_count = nullptr;         // selected entries per kVisWG-word workgroup
   uint32_t nwg = 0;
   VisItem* vis = nullptr;
-  DelItem* del_list = nullptr;     // slot-0 deletes of the last pass (pool release pending)
-  uint32_t* upd_wg = nullptr;      // voxels updated per k_integrate workgroup
+  // per frame parity (frame f appends while the end of frame f-1's carve pass still reads its own):
+  DelItem* del_list[2] = {nullptr, nullptr};  // slot-0 deletes of a pass (pool release pending)
+  uint32_t* upd_wg[2] = {nullptr, nullptr};   // voxels updated, per k_integrate workgroup (mod 1024)
   bool pending = false;            // the last pass still owes its carve_finalize (kernels_carve.h)
   uint32_t* dbitmap = nullptr;   // delete bitmap indexed by hash entry (self-cleaning)
   uint32_t* dsummary = nullptr;
@@ -131,7 +132,7 @@ struct ratsdf_engine {
   uint32_t vis_cap = 0;   // total items of `vis`
   uint32_t seg_cap = 0;   // items per work list (vis holds kNumLists + 1 segments)
   uint32_t dwords = 0;
-  SlowDelete* slowdel = nullptr;
+  SlowDelete* slowdel[2] = {nullptr, nullptr};
 
   // query-side download buffers (grow-only)
   void* dl_dev = nullptr;
@@ -163,7 +164,7 @@ struct ratsdf_engine {
   int alloc_rank(uint32_t nranks, unsigned par, const CandJob* next = nullptr, bool frame = false);
   int settle();
   void abandon_pipeline();
-  CarveBufs carve_bufs() const;
+  CarveBufs carve_bufs(unsigned par) const;
   int select(int mode, const GridBounds& gb, uint32_t* count_slot);
   struct FrameIn {
     const void *rgb, *depth, *ht, *lt;
@@ -209,8 +210,8 @@ int ratsdf_engine::free_all() {
                   d_stats, d_eng, texA[0], texA[1], texB[0], texB[1], cand[0].list, cand[1].list, cand_count,
                   req, req_k, win_ranks, abitmap, asummary, aprefix,
                   slow, xlocks,
-                  distinct, sort_scratch, masks, wg_count, vis, del_list, upd_wg, tab.dclaim, dbitmap, dsummary, dprefix,
-                  slowdel, d_stage, d_mc};
+                  distinct, sort_scratch, masks, wg_count, vis, del_list[0], del_list[1], upd_wg[0],
+                  upd_wg[1], tab.dclaim, dbitmap, dsummary, dprefix, slowdel[0], slowdel[1], d_stage, d_mc};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h_stage) (void)hipHostFree(h_stage);
@@ -253,7 +254,8 @@ EngineDev ratsdf_engine::record() const {
   memset(&r, 0, sizeof(r));
   r.tab = tab;
   r.pool = pool;
-  r.cb = carve_bufs();
+  r.cb[0] = carve_bufs(0);
+  r.cb[1] = carve_bufs(1);
   r.rb = rank_bufs((uint32_t)cur_nranks);
   r.ctl = ctl;
   r.stats = d_stats;
@@ -347,13 +349,13 @@ int ratsdf_engine::ensure_stage(size_t npix) {
 
 // rank kernel (resolve + mark + scan) on a rank space of `nranks`; the commit itself happens inside
 // k_integrate for frames and in k_commit_only for the stand-alone test hook
-CarveBufs ratsdf_engine::carve_bufs() const {
+CarveBufs ratsdf_engine::carve_bufs(unsigned par) const {
   CarveBufs cb;
-  cb.del = del_list;
+  cb.del = del_list[par & 1u];
   cb.del_cap = (uint32_t)tab.num_block;
-  cb.slow = slowdel;
+  cb.slow = slowdel[par & 1u];
   cb.slow_cap = kSlowDelCap;
-  cb.upd_wg = upd_wg;
+  cb.upd_wg = upd_wg[par & 1u];
   cb.bitmap = dbitmap;
   cb.summary = dsummary;
   cb.prefix = dprefix;
@@ -367,7 +369,7 @@ int ratsdf_engine::alloc_rank(uint32_t nranks, unsigned par, const CandJob* next
   const unsigned extra = job.n_tiles ? (job.n_tiles + job.tiles_per_wg - 1) / job.tiles_per_wg : 0;
   const RankBufs rb = rank_bufs(nranks);
   hipLaunchKernelGGL(k_alloc_rank, dim3(1 + extra), dim3(1024),
-                     serial_lds, stream, tab, pool, rb, carve_bufs(), ctl,
+                     serial_lds, stream, tab, pool, rb, carve_bufs(par ^ 1u), ctl,
                      (uint32_t)par, d_stats, frame ? cand[par].count : (uint32_t*)nullptr, job);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
@@ -389,7 +391,7 @@ void ratsdf_engine::abandon_pipeline() {
 // Everything but a following frame needs the last frame's carve pass completed first.
 int ratsdf_engine::settle() {
   if (!pending) return RATSDF_OK;
-  hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, stream, tab, pool, carve_bufs(), ctl,
+  hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, stream, tab, pool, carve_bufs(parity ^ 1u), ctl,
                      (uint32_t)(parity ^ 1u), d_stats);
   HIPCHK(hipGetLastError());
   pending = false;
@@ -535,7 +537,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
   hipLaunchKernelGGL(k_front, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
-                     (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(),
+                     (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(par ^ 1u),
                      ctl, (uint32_t)par, ahead_a);
   st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
   if (st != RATSDF_OK) return st;
@@ -567,7 +569,8 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   ia.vis = vis;
   ia.seg_cap = seg_cap;
   ia.F = &ctl->fr[par];
-  ia.upd_wg = upd_wg;
+  ia.upd_wg = upd_wg[par];
+  ia.par = par;
 #define RATSDF_LAUNCH_INTEGRATE(V, NT)                                                              \
   hipExtLaunchKernelGGL(k_integrate<V>, dim3(integrate_grid + extra_c), dim3(NT), 0, stream, ev0,   \
                         ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid, (uint32_t)extra_c,      \
@@ -709,10 +712,13 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   e->seg_cap = (uint32_t)t.num_block;              // any list can hold every block
   e->vis_cap = (kNumLists + 1) * e->seg_cap;       // 8 per-XCD lists + this frame's new blocks
   CREATE_CHK(hipMalloc(&e->vis, (size_t)e->vis_cap * sizeof(VisItem)));
-  CREATE_CHK(hipMalloc(&e->del_list, (size_t)t.num_block * sizeof(DelItem)));
+  for (int i = 0; i < 2; ++i) {
+    CREATE_CHK(hipMalloc(&e->del_list[i], (size_t)t.num_block * sizeof(DelItem)));
+    CREATE_CHK(hipMalloc(&e->upd_wg[i], kUpdCounters * 4));
+    CREATE_CHK(hipMemsetAsync(e->upd_wg[i], 0, kUpdCounters * 4, e->stream));
+    CREATE_CHK(hipMalloc(&e->slowdel[i], (size_t)kSlowDelCap * sizeof(SlowDelete)));
+  }
   CREATE_CHK(hipMalloc(&e->win_ranks, (size_t)kSmallRank * 4));
-  CREATE_CHK(hipMalloc(&e->upd_wg, kUpdCounters * 4));
-  CREATE_CHK(hipMemsetAsync(e->upd_wg, 0, kUpdCounters * 4, e->stream));
   CREATE_CHK(hipMalloc(&t.dclaim, (size_t)t.num_bucket * 4));
   CREATE_CHK(hipMemsetAsync(t.dclaim, 0xFF, (size_t)t.num_bucket * 4, e->stream));
   e->dwords = (e->dwords + kGroupWords - 1) / kGroupWords * kGroupWords;
@@ -720,7 +726,6 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->dbitmap, (size_t)e->dwords * 4));
   CREATE_CHK(hipMalloc(&e->dsummary, (size_t)dsum_words * 4));
   CREATE_CHK(hipMalloc(&e->dprefix, (size_t)e->dwords * 4));
-  CREATE_CHK(hipMalloc(&e->slowdel, (size_t)kSlowDelCap * sizeof(SlowDelete)));
   CREATE_CHK(hipMalloc(&e->cand_count, 2 * kCandSegs * kCandCountStride * 4));
   CREATE_CHK(hipMemsetAsync(e->cand_count, 0, 2 * kCandSegs * kCandCountStride * 4, e->stream));
   for (int i = 0; i < 2; ++i) e->cand[i].count = e->cand_count + i * kCandSegs * kCandCountStride;
@@ -1404,7 +1409,7 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   hipLaunchKernelGGL(k_commit_only, dim3(256), dim3(256), 0, e->stream, e->tab, e->pool, e->req,
                      e->req_cap, e->req_k, e->win_ranks, e->ctl, par);
   // no deletes in this pass; k_settle just zeroes the counters again
-  hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, e->stream, e->tab, e->pool, e->carve_bufs(),
+  hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, e->stream, e->tab, e->pool, e->carve_bufs(par),
                      e->ctl, par, (ratsdf_frame_stats*)nullptr);
   const int st2 = e->sticky();
   (void)hipFree(d);
@@ -1432,8 +1437,8 @@ int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   if (st != RATSDF_OK) return st;
   const uint32_t par = e->parity;
   hipLaunchKernelGGL(k_delete_list, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->tab, d, m,
-                     e->carve_bufs(), e->ctl, par);
-  hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, e->stream, e->tab, e->pool, e->carve_bufs(),
+                     e->carve_bufs(par), e->ctl, par);
+  hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, e->stream, e->tab, e->pool, e->carve_bufs(par),
                      e->ctl, par, (ratsdf_frame_stats*)nullptr);
   const int st2 = e->sticky();
   (void)hipFree(d);
