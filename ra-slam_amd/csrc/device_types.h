@@ -73,7 +73,9 @@ struct FrameCtl {
   uint32_t n_winlist;      // > 0: the winners' raster ranks are listed in win_ranks[0, n_winlist) and
                            // k_integrate derives each winner's order from the list (few winners);
                            // 0: req_k holds the order (many winners, rank bitmap path)
-  uint32_t pad[23];
+  uint32_t serial_done;    // the frame's serial role has published its results (only consulted when
+                           // that role runs inside k_integrate, beside the voxel update)
+  uint32_t pad[22];
   // visible blocks per XCD list (image-tile buckets): list l counts in n_list[l * kListStride], one
   // 128-byte line per counter (they take ~2000 atomics per frame; sharing a line serialises them)
   uint32_t n_list[8 * 32];
@@ -212,6 +214,7 @@ struct EngineDev {
   uint32_t slow_cap;
   uint32_t seg_cap;
   VisItem* vis;
+  uint32_t* serial_scratch;  // 40 KiB: scratch of the serial role's rare paths when it has no LDS to spare
   float4* texA[2];
   uint32_t* texB[2];
   CandSet cand[2];

@@ -38,7 +38,7 @@ __device__ inline void set_error(Ctl* ctl, uint32_t code) {
 __device__ inline void zero_frame_ctl(FrameCtl* F) {
   uint32_t* z = reinterpret_cast<uint32_t*>(F);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) z[i] = 0;
+  for (int i = 0; i < 10; ++i) z[i] = 0;
 #pragma unroll
   for (int l = 0; l < kNumLists; ++l) F->n_list[l * kListStride] = 0;
 }
@@ -640,7 +640,8 @@ __device__ inline bool commit_request(const Table& tab, const Pool& pool, const 
     }
     return false;
   }
-  const int32_t idx = pool.heap[alloc_base - 1 - k];
+  // agent-scope load: in a fused frame the serial role may have pushed this index moments ago
+  const int32_t idx = __hip_atomic_load(&pool.heap[alloc_base - 1 - k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (writer) {
     if (!placed) {
       pe[0] = key0(r.x, r.y);

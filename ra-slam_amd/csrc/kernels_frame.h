@@ -308,32 +308,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_ca
 // voxel update of several engines (kernels_integrate.h: integrate_body)
 template <int VPL>
 __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate_g(
-    EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_int_wg, uint32_t n_ahead_wg, AheadGeom ag) {
+    EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_int_wg, uint32_t n_serial_wg, uint32_t n_ahead_wg,
+    uint32_t commit_rot, AheadGeom ag) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
   EnginePtr E = engs + blockIdx.y;
-  if (blockIdx.x < n_ahead_wg) {  // look-ahead workgroups first (k_integrate)
+  JobPtr J = cur + blockIdx.y;
+  const uint32_t par = J->par;
+  if (__builtin_expect(blockIdx.x >= n_serial_wg + n_ahead_wg, 1)) {  // role order as in k_integrate
+    const uint32_t ibid = blockIdx.x - n_serial_wg - n_ahead_wg;
+    const bool fused = n_serial_wg != 0;
+    IntegArgs A;
+    A.rgbw = E->pool.rgbw;
+    A.tsdf = E->pool.tsdf;
+    A.segm = E->pool.segm;
+    A.texA = E->texA[par];
+    A.texB = E->texB[par];
+    A.vis = E->vis;
+    A.seg_cap = E->seg_cap;
+    A.F = &E->ctl->fr[par];
+    A.upd_wg = E->cb[par].upd_wg;
+    A.par = par;
+    const FrameParams P = ld_const(&J->P);
+#include "integrate_body.inc"
+    return;
+  }
+  if (blockIdx.x >= n_serial_wg) {  // look-ahead workgroups
     if (VPL != 1) {
       const CandJob ahead = make_cand_job(E, nxt + blockIdx.y, ag);
-      cand_pixels_role(ahead, blockIdx.x, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
+      cand_pixels_role(ahead, blockIdx.x - n_serial_wg, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
     }
     return;
   }
-  const uint32_t ibid = blockIdx.x - n_ahead_wg;
-  JobPtr J = cur + blockIdx.y;
-  const uint32_t par = J->par;
-  IntegArgs A;
-  A.rgbw = E->pool.rgbw;
-  A.tsdf = E->pool.tsdf;
-  A.segm = E->pool.segm;
-  A.texA = E->texA[par];
-  A.texB = E->texB[par];
-  A.vis = E->vis;
-  A.seg_cap = E->seg_cap;
-  A.F = &E->ctl->fr[par];
-  A.upd_wg = E->cb[par].upd_wg;
-  A.par = par;
-  const FrameParams P = ld_const(&J->P);
-#include "integrate_body.inc"
+  if (blockIdx.x == 0) {  // the frame's serial role
+    const uint32_t nwords = ((uint32_t)(J->P.W * J->P.H) * (uint32_t)J->P.S + 31u) / 32u;
+    serial_workgroup(E, par, nwords, role_lds);
+  }
 }
 
 }  // namespace ratsdf

@@ -74,6 +74,213 @@ struct VecIO<1> {
   static __device__ inline void store(uint32_t* p, const uint32_t (&v)[1]) { p[0] = v[0]; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// The frame's serial role INSIDE k_integrate (256 threads, workgroup 0 of the launch).
+//
+// As a launch of its own (k_alloc_rank, kernels_frame.h) the role costs the frame ~5 us in which one
+// workgroup walks two dependent memory round trips and 255 CUs idle, plus a launch boundary.  Nothing
+// the voxel update of the blocks that already exist needs comes out of it: only the commit of this
+// frame's NEW blocks does (pool indices = order of the winners), and in frames that touch chained
+// buckets the deletes of space carving (the resolver edits the directory).  So the role runs beside
+// the update, publishes F->serial_done, and only those two consumers wait for it (bounded, like
+// carve_resolve_gate).
+// Hand-off WITHOUT cache maintenance in the ordinary frame: a release fence here would write back the
+// whole L2 of this XCD (which the update workgroups next door keep filling with dirty voxel lines), an
+// acquire in every committing workgroup would drop theirs.  Instead the few words the commit needs
+// (winner flags, winners' ranks, alloc_base / n_win / n_winlist) are written with agent-scope stores
+// (write-through), drained (vmcnt) before the flag goes out the same way, and read with agent-scope
+// loads.  The general path stores plainly; it publishes serial_done = 2 after a real release and its
+// consumers add an acquire.  What the previous frame still owes (carve_finalize) reads that frame's own
+// lists and counters (per-parity buffers), never the ones this frame's update appends to.
+// Same results as serial_frame_role / alloc_rank_role / carve_finalize: the fast path below is the
+// 1024-thread one re-cut for 256 threads; everything unusual calls the general functions with their
+// scratch in device memory instead of LDS (rare: first frames of a view, chained buckets).
+// ---------------------------------------------------------------------------------------------
+// A safety net, not a deadline: the role's general path with every capacity exhausted (16 384 chained
+// requests sorted in device memory by 256 threads) takes tens of milliseconds.
+constexpr unsigned long long kSerialWaitTicks = 200000000;  // 2 s of the 100 MHz wall clock
+
+__device__ inline void st_agent(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline Request ld_agent_request(const Request* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  unsigned long long w[2];
+  w[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  w[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  Request r;
+  __builtin_memcpy(&r, w, sizeof(r));
+  return r;
+}
+
+// A wave waits until the frame's serial role has published (one lane polls; bounded, sticky error on
+// expiry); after the general path (serial_done == 2) the caller's plain loads need an acquire.
+__device__ inline void wait_serial_done(FrameCtl* F, Ctl* ctl) {
+  uint32_t v = 0;
+  if ((threadIdx.x & 63u) == 0) {
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    while ((v = ld_agent(&F->serial_done)) == 0u) {
+      if ((unsigned long long)wall_clock64() - t0 > kSerialWaitTicks) {
+        set_error(ctl, RATSDF_ERR_TIMEOUT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  if (v != 1u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // uniform
+}
+
+// returns 1 (ordinary frame: agent-scope stores only) or 2 (general path: plain stores)
+// The general paths.  Their operands are read from the engine record where they are used (references
+// into constant memory, not local copies): held in registers all along, the ~30 pointers pushed scalar
+// spills into scratch memory, and a kernel that uses scratch pays for it in every wave it launches
+// (-25% on the whole frame).
+__device__ __forceinline__ void serial_general(EnginePtr E, uint32_t par, uint32_t nwords, int32_t nf) {
+  Ctl* ctl = E->ctl;
+  const Table& tab = *(const Table*)(&E->tab);
+  const RankBufs& rb = *(const RankBufs*)(&E->rb);
+  const CarveBufs& cb = *(const CarveBufs*)(&E->cb[par ^ 1u]);
+  const Pool& pool = *(const Pool*)(&E->pool);
+  uint32_t* scratch = E->serial_scratch;
+  nf += (int32_t)carve_finalize(tab, pool, cb, ctl, &ctl->fr[par ^ 1u], E->stats, nf, scratch);
+  alloc_rank_role(tab, rb.req, rb.req_cap, rb.req_k, rb.slow, rb.slow_cap, rb.xlocks, rb.distinct,
+                  rb.bitmap, rb.summary, rb.prefix, nwords, rb.sort_scratch, ctl, &ctl->fr[par], nf,
+                  reinterpret_cast<unsigned long long*>(scratch));
+}
+
+// word 1 of a request = z | flags << 16: the winner flag as one agent-scope word store
+__device__ inline void mark_winner(Request* p, const Request& r) {
+  st_agent(reinterpret_cast<uint32_t*>(p) + 1, (uint32_t)(uint16_t)r.z | ((uint32_t)kReqWinner << 16));
+}
+
+__device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, uint32_t nwords,
+                                      uint32_t* lds /* >= 8 words */) {
+  constexpr uint32_t NT = 256;
+  constexpr uint32_t UPT = kUpdCounters / NT;  // update counters per thread
+  const uint32_t tid = threadIdx.x;
+  Ctl* ctl = E->ctl;
+  FrameCtl* Fp = &ctl->fr[par ^ 1u];
+  FrameCtl* F = &ctl->fr[par];
+  const Table tab = ld_const(&E->tab);
+  const RankBufs rb = ld_const(&E->rb);
+  const CarveBufs cb = ld_const(&E->cb[par ^ 1u]);  // the PREVIOUS frame's lists and counters
+  ratsdf_frame_stats* stats = E->stats;
+  // the frame's candidate lists have been consumed by k_front: empty them for the frame after next
+  if (tid < kCandSegs) E->cand[par].count[tid * kCandCountStride] = 0;
+
+  // ---- one round of loads ----
+  const int32_t nf0 = ctl->num_free;
+  const uint32_t pend = Fp->pending;
+  uint32_t nd = Fp->n_delcand, ns = Fp->n_slow_del;
+  const uint32_t p_win = Fp->n_win, p_slow = Fp->n_slow;
+  uint32_t nv = p_win;
+#pragma unroll
+  for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l * kListStride];
+  const uint32_t n_slow = F->n_slow;
+  uint32_t n = F->n_req;
+  Request r0 = rb.req[tid < rb.req_cap ? tid : 0];  // the first requests ride in the first round
+  Request r1 = rb.req[tid + NT < rb.req_cap ? tid + NT : 0];
+  if (nd > cb.del_cap) nd = cb.del_cap;
+  if (ns > cb.slow_cap) ns = cb.slow_cap;
+  if (n > rb.req_cap) n = rb.req_cap;
+
+  const bool fast = (!pend || nd + ns <= kSmallCarve) && n_slow == 0 && n <= kSmallRank;
+  if (__builtin_expect(!fast, 0)) {  // uniform: the general functions, scratch in device memory
+#ifndef RATSDF_FAST_ONLY  // (a measurement build: what the general paths' presence costs the kernel)
+    serial_general(E, par, nwords, nf0);
+#endif
+    return 2u;
+  }
+
+  // second dependent round: the claim of every request's bucket (two requests per thread at once;
+  // further batches only for frames with more than 512 requests)
+  // (the previous frame's update counters ride in this round: nothing depends on them but a sum)
+  uint4 u = make_uint4(0, 0, 0, 0);
+  static_assert(UPT == 4, "one uint4 of update counters per thread");
+  if (pend) u = reinterpret_cast<const uint4*>(cb.upd_wg)[tid];
+  if (tid < 3) lds[tid] = 0;  // [0] slow deletes that happened, [1] winners, [2] voxels updated
+  lds_barrier();
+  for (uint32_t base = 0; base < n; base += 2 * NT) {  // uniform
+    const uint32_t i0 = base + tid, i1 = base + NT + tid;
+    if (base != 0) {
+      if (i0 < n) r0 = rb.req[i0];
+      if (i1 < n) r1 = rb.req[i1];
+    }
+    uint32_t c0 = kInf, c1 = kInf;
+    if (i0 < n) c0 = tab.claim[block_hash(r0.x, r0.y, r0.z, tab.bucket_mask)];
+    if (i1 < n) c1 = tab.claim[block_hash(r1.x, r1.y, r1.z, tab.bucket_mask)];
+    // the winners' ranks go to a compact list; the committing waves turn a rank into the winner's
+    // position in raster order (= order of the AquireBlock calls) by counting the smaller ones
+    if (i0 < n && c0 == r0.rank) {
+      mark_winner(rb.req + i0, r0);
+      st_agent(&rb.win_ranks[atomicAdd(&lds[1], 1u)], r0.rank);
+    }
+    if (i1 < n && c1 == r1.rank) {
+      mark_winner(rb.req + i1, r1);
+      st_agent(&rb.win_ranks[atomicAdd(&lds[1], 1u)], r1.rank);
+    }
+  }
+  if (pend) {  // previous frame: count of its head / chain deletes, voxels-updated sum
+    for (uint32_t j = tid; j < ns; j += NT)
+      if (cb.slow[j].state == 2) atomicAdd(&lds[0], 1u);
+    uint32_t up = u.x + u.y + u.z + u.w;
+    if (up) reinterpret_cast<uint4*>(cb.upd_wg)[tid] = make_uint4(0, 0, 0, 0);
+    up = wave_sum(up);
+    if ((tid & 63) == 0 && up) atomicAdd(&lds[2], up);
+  }
+  lds_barrier();
+  const uint32_t n_del = pend ? nd + lds[0] : 0u;
+  const uint32_t total = lds[1];
+  const uint32_t upd = lds[2];
+  const int32_t nf = nf0 + (int32_t)n_del;
+  if (tid == 0) {
+    if (pend) {
+      if (stats) {
+        stats->visible_blocks = (int32_t)nv;
+        stats->updated_voxels = (int32_t)upd;
+        stats->allocated_blocks = (int32_t)p_win;
+        stats->deleted_blocks = (int32_t)n_del;
+        stats->active_blocks = tab.num_block - nf;
+        stats->slow_requests = (int32_t)p_slow;
+        // fire-and-forget adds: nobody else touches the totals while a frame is in flight
+        atomicAdd(&ctl->totals[0], 1ull);
+        atomicAdd(&ctl->totals[1], (unsigned long long)nv);
+        atomicAdd(&ctl->totals[2], (unsigned long long)upd);
+        atomicAdd(&ctl->totals[3], (unsigned long long)p_win);
+        atomicAdd(&ctl->totals[4], (unsigned long long)n_del);
+      }
+      zero_frame_ctl(Fp);  // counters ready for the frame after next
+    }
+    uint32_t take = total;
+    if ((int64_t)total > (int64_t)nf) {  // voxel_mem.cu:39 assert(idx >= 1)
+      set_error(ctl, RATSDF_ERR_POOL_EXHAUSTED);
+      take = (uint32_t)nf;
+    }
+    st_agent(&F->alloc_base, (uint32_t)nf);
+    st_agent(&F->n_win, take);
+    st_agent(&F->n_winlist, total);
+    F->pending = 1;  // this frame now owes a carve_finalize
+    ctl->num_free = nf - (int32_t)take;
+  }
+  return 1u;
+}
+
+// workgroup 0 of a fused launch: the role, then the hand-off (every storing wave drained, barrier,
+// one agent-scope release, the flag)
+__device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint32_t nwords, uint32_t* lds) {
+  const uint32_t how = serial_role256(E, par, nwords, lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (how != 1u) {  // uniform
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    st_agent(&E->ctl->fr[par].serial_done, how);
+  }
+}
+
 // round-half-away-from-zero of a NON-NEGATIVE float (roundf for x >= 0, NaN stays NaN); the generic
 // roundf additionally restores the sign (v_bfi)
 __device__ inline float round_nonneg(float x) {
@@ -311,17 +518,25 @@ struct IntegArgs {
 // vector ALUs mostly idle, the candidate pass is ALU work on other inputs.
 template <int VPL>
 __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
-    IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, uint32_t n_ahead_wg, CandJob ahead) {
+    IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, uint32_t n_serial_wg, uint32_t n_ahead_wg,
+    uint32_t commit_rot, CandJob ahead) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
-  // the look-ahead workgroups come FIRST in the grid (a multiple of 8 of them, so that the update
-  // workgroups keep their list <-> XCD mapping): they start at once and are done before the last
-  // update workgroups are, instead of extending the launch at its end
-  if (blockIdx.x < n_ahead_wg) {
-    if (VPL != 1) cand_pixels_role(ahead, blockIdx.x, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
+  // Grid: [n_serial_wg: 0, or 8 of which the first is the frame's serial role][n_ahead_wg look-ahead
+  // workgroups of the next frame's candidate pass][n_int_wg update workgroups].  The first two groups
+  // are multiples of 8, so that the update workgroups keep their list <-> XCD mapping, and they come
+  // FIRST: they start at once and are done before the last update workgroups are.
+  if (__builtin_expect(blockIdx.x >= n_serial_wg + n_ahead_wg, 1)) {
+    const uint32_t ibid = blockIdx.x - n_serial_wg - n_ahead_wg;
+    const bool fused = n_serial_wg != 0;
+#include "integrate_body.inc"
     return;
   }
-  const uint32_t ibid = blockIdx.x - n_ahead_wg;
-#include "integrate_body.inc"
+  if (blockIdx.x >= n_serial_wg) {
+    if (VPL != 1) cand_pixels_role(ahead, blockIdx.x - n_serial_wg, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
+    return;
+  }
+  if (blockIdx.x == 0)
+    serial_workgroup(E, A.par, ((uint32_t)(P.W * P.H) * (uint32_t)P.S + 31u) / 32u, role_lds);
 }
 
 }  // namespace ratsdf

@@ -96,6 +96,16 @@ struct ratsdf_engine {
   bool cand_split_env = false;
   unsigned cand_split = 40;              // percent of the look-ahead pass placed in k_front,
   unsigned cand_split_b = 0;             // in k_alloc_rank; the rest rides in k_integrate
+  bool fused_serial = true;              // the frame's serial role rides in k_integrate (no k_alloc_rank)
+  int commit_rot_env = -1;               // RATSDF_COMMIT_ROT: first committing workgroup (measurements)
+  // With the serial role in the launch: which update workgroups take the frame's commits.  A grid of
+  // at most two rounds of resident workgroups (256 CUs x 8): the first ones, which wait for the role
+  // after their first block (anything later is the tail).  More rounds: the second round.
+  uint32_t commit_rotation(unsigned grid) const {
+    if (commit_rot_env >= 0) return (uint32_t)commit_rot_env < grid ? (uint32_t)commit_rot_env : 0u;
+    return grid >= 8192u ? 3072u : 0u;  // profiles/r02_commit_rot_sweep.txt
+  }
+  uint32_t* serial_scratch = nullptr;    // its scratch for the general paths (kSerialLdsBytes)
   unsigned cand_parts_env = 0;           // RATSDF_CAND_PARTS: consumer workgroups per candidate list
   unsigned cand_wgs = 248;               // look-ahead workgroups per host kernel (about one per CU)
   // dynamic LDS of k_alloc_rank: the serial role needs kSerialLdsBytes; asking for more than half a
@@ -211,7 +221,7 @@ int ratsdf_engine::free_all() {
                   req, req_k, win_ranks, abitmap, asummary, aprefix,
                   slow, xlocks,
                   distinct, sort_scratch, masks, wg_count, vis, del_list[0], del_list[1], upd_wg[0],
-                  upd_wg[1], tab.dclaim, dbitmap, dsummary, dprefix, slowdel[0], slowdel[1], d_stage, d_mc};
+                  upd_wg[1], tab.dclaim, dbitmap, dsummary, dprefix, slowdel[0], slowdel[1], d_stage, d_mc, serial_scratch};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h_stage) (void)hipHostFree(h_stage);
@@ -260,6 +270,7 @@ EngineDev ratsdf_engine::record() const {
   r.ctl = ctl;
   r.stats = d_stats;
   r.slow = slow;
+  r.serial_scratch = serial_scratch;
   r.slow_cap = kSlowCap;
   r.seg_cap = seg_cap;
   r.vis = vis;
@@ -511,7 +522,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // memory-latency-bound voxel update); at 1280x720 all of it in k_front (differences below 1.5 %,
   // and k_integrate stays the pure voxel update its roofline figure is about)
   const int split = (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
-  const int split_b = (int)(cand_split_env ? cand_split_b : 0u);
+  const int split_b = (fused_serial && vpl != 1) ? 0 : (int)(cand_split_env ? cand_split_b : 0u);
   const Geom g = geometry(H, W, next != nullptr, split, split_b);
   // shares of the next frame's candidate pass: k_front, k_alloc_rank, k_integrate
   CandJob ahead_a, ahead_b, ahead_c;
@@ -539,8 +550,11 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   hipLaunchKernelGGL(k_front, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
                      (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(par ^ 1u),
                      ctl, (uint32_t)par, ahead_a);
-  st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
-  if (st != RATSDF_OK) return st;
+  const bool fused = fused_serial && vpl != 1;
+  if (!fused) {
+    st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
+    if (st != RATSDF_OK) return st;
+  }
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   const bool timed = profiling && (prof_frame++ % 4 == 0);  // sample: events perturb the stream
@@ -560,6 +574,8 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // kernel's own start-to-end time (what rocprofv3 reports), without the barrier packets that
   // hipEventRecord before / after a launch would add (~3 us here).  Null events = a plain launch.
   const unsigned extra_c = ((ahead_c.n_tiles + 3) / 4 + 7u) & ~7u;  // whole groups of 8 (XCD mapping)
+  const uint32_t n_serial_wg = fused ? 8u : 0u;  // the first of them works
+  const uint32_t commit_rot = fused ? commit_rotation(integrate_grid) : 0u;
   IntegArgs ia;
   ia.rgbw = pool.rgbw;
   ia.tsdf = pool.tsdf;
@@ -572,9 +588,9 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   ia.upd_wg = upd_wg[par];
   ia.par = par;
 #define RATSDF_LAUNCH_INTEGRATE(V, NT)                                                              \
-  hipExtLaunchKernelGGL(k_integrate<V>, dim3(integrate_grid + extra_c), dim3(NT), 0, stream, ev0,   \
-                        ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid, (uint32_t)extra_c,      \
-                        ahead_c)
+  hipExtLaunchKernelGGL(k_integrate<V>, dim3(integrate_grid + n_serial_wg + extra_c), dim3(NT), 0, \
+                        stream, ev0, ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid,    \
+                        n_serial_wg, (uint32_t)extra_c, commit_rot, ahead_c)
   switch (vpl) {
     case 1: RATSDF_LAUNCH_INTEGRATE(1, 512); break;
     case 8: RATSDF_LAUNCH_INTEGRATE(8, RATSDF_INTEG_NT); break;
@@ -656,6 +672,8 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     const int x = atoi(v);
     if (x >= 1 && x <= 64) e->cand_parts_env = (unsigned)x;
   }
+  if (const char* v = getenv("RATSDF_COMMIT_ROT")) e->commit_rot_env = atoi(v);
+  if (const char* v = getenv("RATSDF_FUSED_SERIAL")) e->fused_serial = atoi(v) != 0;  // 0: k_alloc_rank launch
   if (const char* v = getenv("RATSDF_SERIAL_LDS")) {
     const int x = atoi(v);
     if (x >= kSerialLdsBytes && x <= 160 * 1024) e->serial_lds = (unsigned)x;
@@ -707,6 +725,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->xlocks, (size_t)kXLockCap * sizeof(XLock)));
   CREATE_CHK(hipMalloc(&e->distinct, (size_t)kSlowDistinctCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->sort_scratch, (size_t)kSlowSortCap * sizeof(unsigned long long)));
+  CREATE_CHK(hipMalloc(&e->serial_scratch, (size_t)kSerialLdsBytes));
   CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * kVisWG * 8));
   CREATE_CHK(hipMalloc(&e->wg_count, (size_t)e->nwg * 4));
   e->seg_cap = (uint32_t)t.num_block;              // any list can hold every block
@@ -1786,7 +1805,10 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
 
   // ---- launches ----
   EnginePtr engs = (EnginePtr)g->d_engs;
-  const ratsdf_engine::Geom g1 = e0->geometry(height, width, true, g->split_a, g->split_b);
+  const bool fused = e0->fused_serial && e0->vpl != 1;
+  const uint32_t n_serial_wg = fused ? 8u : 0u;
+  const uint32_t commit_rot = fused ? e0->commit_rotation(e0->geometry(height, width, false, 0, 0).grid) : 0u;
+  const ratsdf_engine::Geom g1 = e0->geometry(height, width, true, g->split_a, fused ? 0 : g->split_b);
   const ratsdf_engine::Geom g0 = e0->geometry(height, width, false, 0, 0);
   {  // nobody looked ahead for the first frame: its candidate pass runs in line
     AheadGeom all = g0.a;
@@ -1802,9 +1824,11 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
     JobPtr nxt = (JobPtr)(g->d_jobs + (size_t)(has_next ? f + 1 : f) * S);
     hipLaunchKernelGGL(k_front_g, dim3(gg.n_front_wg, S), dim3(256), 0, g->stream, engs, cur, nxt,
                        (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, gg.a);
-    const unsigned extra_b = gg.b.n_tiles ? (gg.b.n_tiles + gg.b.tiles_per_wg - 1) / gg.b.tiles_per_wg : 0;
-    hipLaunchKernelGGL(k_alloc_rank_g, dim3(1 + extra_b, S), dim3(1024), kSerialLdsBytes, g->stream,
-                       engs, cur, nxt, gg.b);
+    if (!fused) {
+      const unsigned extra_b = gg.b.n_tiles ? (gg.b.n_tiles + gg.b.tiles_per_wg - 1) / gg.b.tiles_per_wg : 0;
+      hipLaunchKernelGGL(k_alloc_rank_g, dim3(1 + extra_b, S), dim3(1024), kSerialLdsBytes, g->stream,
+                         engs, cur, nxt, gg.b);
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g->profiling && (g->prof_frame++ % 4 == 0)) {
       if (g->prof_used == g->prof_events.size()) {
@@ -1819,8 +1843,9 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
     }
     const unsigned extra_c = ((gg.c.n_tiles + 3) / 4 + 7u) & ~7u;
 #define RATSDF_LAUNCH_INTEGRATE_G(V, NT)                                                            \
-  hipExtLaunchKernelGGL(k_integrate_g<V>, dim3(gg.grid + extra_c, S), dim3(NT), 0, g->stream, ev0,  \
-                        ev1, 0, engs, cur, nxt, (uint32_t)gg.grid, (uint32_t)extra_c, gg.c)
+  hipExtLaunchKernelGGL(k_integrate_g<V>, dim3(gg.grid + n_serial_wg + extra_c, S), dim3(NT), 0,    \
+                        g->stream, ev0, ev1, 0, engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg,     \
+                        (uint32_t)extra_c, commit_rot, gg.c)
     switch (e0->vpl) {
       case 1: RATSDF_LAUNCH_INTEGRATE_G(1, 512); break;
       case 8: RATSDF_LAUNCH_INTEGRATE_G(8, RATSDF_INTEG_NT); break;

@@ -99,6 +99,27 @@ def test_chained_buckets_in_the_pipeline(bucket_bits, make_engine, make_oracle):
     assert slow_seen > 0  # the configuration really exercises the chained-bucket paths
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(bucket_bits=9, block_bits=13)])
+def test_serial_role_as_a_launch_of_its_own(kw, monkeypatch, make_engine, make_oracle):
+    """RATSDF_FUSED_SERIAL=0 (read when the engine is created): the frame's allocation-order role runs
+    as k_alloc_rank between k_front and k_integrate instead of inside k_integrate -- the layout the
+    stand-alone test hooks use, kept for A/B measurements.  Same map either way."""
+    monkeypatch.setenv("RATSDF_FUSED_SERIAL", "0")
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs, **kw), make_oracle(vs, 6 * vs, **kw)
+    monkeypatch.delenv("RATSDF_FUSED_SERIAL")
+    frames = synthetic.stream("room", 12, scale=0.25, noise=True, holes=True)
+    dev = device_frames(frames)
+    lo = 0
+    for n in (1, 5, 6):
+        gpu.integrate_device_batch(make_batch(gpu, frames, dev, lo, lo + n, md))
+        oracle_run(cpu, frames[lo:lo + n], md)
+        lo += n
+        assert_maps_equal(gpu, cpu)
+        assert_stats_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+
+
 def test_no_semantics_batch(make_engine, make_oracle):
     vs, md = 0.02, 4.0
     gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
