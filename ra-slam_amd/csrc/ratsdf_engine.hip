@@ -101,9 +101,12 @@ struct ratsdf_engine {
   // With the serial role in the launch: which update workgroups take the frame's commits.  A grid of
   // at most two rounds of resident workgroups (256 CUs x 8): the first ones, which wait for the role
   // after their first block (anything later is the tail).  More rounds: the second round.
-  uint32_t commit_rotation(unsigned grid) const {
+  // (`launch_wgs`: update workgroups of the whole launch -- S slices of `grid` for a group, whose
+  // later slices start on a full machine whatever their size.)
+  uint32_t commit_rotation(unsigned grid, unsigned launch_wgs) const {
     if (commit_rot_env >= 0) return (uint32_t)commit_rot_env < grid ? (uint32_t)commit_rot_env : 0u;
-    return grid >= 8192u ? 3072u : 0u;  // profiles/r02_commit_rot_sweep.txt
+    if (launch_wgs < 8192u) return 0u;
+    return grid > 4096u ? 3072u : grid / 4u * 3u;  // profiles/r02_commit_rot_sweep.txt
   }
   uint32_t* serial_scratch = nullptr;    // its scratch for the general paths (kSerialLdsBytes)
   unsigned cand_parts_env = 0;           // RATSDF_CAND_PARTS: consumer workgroups per candidate list
@@ -575,7 +578,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // hipEventRecord before / after a launch would add (~3 us here).  Null events = a plain launch.
   const unsigned extra_c = ((ahead_c.n_tiles + 3) / 4 + 7u) & ~7u;  // whole groups of 8 (XCD mapping)
   const uint32_t n_serial_wg = fused ? 8u : 0u;  // the first of them works
-  const uint32_t commit_rot = fused ? commit_rotation(integrate_grid) : 0u;
+  const uint32_t commit_rot = fused ? commit_rotation(integrate_grid, integrate_grid) : 0u;
   IntegArgs ia;
   ia.rgbw = pool.rgbw;
   ia.tsdf = pool.tsdf;
@@ -1807,7 +1810,8 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
   EnginePtr engs = (EnginePtr)g->d_engs;
   const bool fused = e0->fused_serial && e0->vpl != 1;
   const uint32_t n_serial_wg = fused ? 8u : 0u;
-  const uint32_t commit_rot = fused ? e0->commit_rotation(e0->geometry(height, width, false, 0, 0).grid) : 0u;
+  const unsigned grid0 = e0->geometry(height, width, false, 0, 0).grid;
+  const uint32_t commit_rot = fused ? e0->commit_rotation(grid0, grid0 * (unsigned)S) : 0u;
   const ratsdf_engine::Geom g1 = e0->geometry(height, width, true, g->split_a, fused ? 0 : g->split_b);
   const ratsdf_engine::Geom g0 = e0->geometry(height, width, false, 0, 0);
   {  // nobody looked ahead for the first frame: its candidate pass runs in line
