@@ -88,7 +88,8 @@ def traffic_file(config):
     return ROOT / "profiles" / name
 
 
-def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", engines=1):
+def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", engines=1, whole_frame_gbps=None):
+    """`frac` prices the dominant launch alone; `frame_frac` the whole frame (all launches and gaps)."""
     if not k_n:
         return None
     k_avg_s = k_ms / k_n / 1e3
@@ -103,9 +104,12 @@ def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", en
             traffic = None
     return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src,
-                launch_also_hosts=("60 % of the NEXT frame's candidate pass (its workgroups come first "
-                                   "in the grid; engine default at 640x480)" if config == "vga5mm" and
-                                   engines == 1 else None),
+                launch_also_hosts=("the frame's serial allocation-order role (workgroup 0; the commit of the "
+                                   "frame's new blocks waits for it inside the launch)" +
+                                   ("; 80 % of the NEXT frame's candidate pass (its workgroups come first in "
+                                    "the grid; engine default at 640x480)" if config == "vga5mm" and
+                                    engines == 1 else "")),
+                frame_frac=(round(whole_frame_gbps / HBM_PEAK_GBPS, 4) if whole_frame_gbps else None),
                 alg_bytes_per_launch=round(b_alg_per_launch), avg_launch_us=round(k_avg_s * 1e6, 2),
                 launches=k_n)
 
@@ -155,8 +159,9 @@ def bench_streams(ratsdf, torch, dev, dev_index, S, scene, cam, vs, md, nfr, ste
                us_per_frame_step=round(dt / (steps * n) * 1e6, 2), frames_per_step=n, steps=steps, reps=reps,
                alg_gbps_whole_frame=round(b_alg / frames_total * fps / 1e9, 1),
                roofline=roofline_block(b_alg / frames_total * S, k_ms, k_n, "vga5mm", kernel="k_integrate_g",
+                                       whole_frame_gbps=b_alg / frames_total * fps / 1e9,
                                        engines=S),
-               note="one k_front_g / k_alloc_rank_g / k_integrate_g launch per frame step serves all "
+               note="one k_front_g / k_integrate_g launch pair per frame step serves all "
                     "streams (one grid slice per stream); a k_integrate_g launch = S frames")
     grp.close()
     for e in engines:
@@ -220,7 +225,7 @@ def bench_secondary(ratsdf, torch, dev, dev_index, md, cpu_threads):
                frame=dict(avg_visible_blocks=round(tot["visible_blocks"] / tot["frames"], 1),
                           avg_updated_voxels=round(tot["updated_voxels"] / tot["frames"], 1),
                           alg_bytes=round(b_alg)),
-               roofline=roofline_block(b_alg, k_ms, k_n, "hd2mm"),
+               roofline=roofline_block(b_alg, k_ms, k_n, "hd2mm", whole_frame_gbps=b_alg * fps / 1e9),
                cpu_frames_per_s=round(len(frames) / t_cpu, 1), cpu_threads=cpu_threads,
                parity=dict(frames=len(frames), max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"],
                            directory="bit-exact"))
@@ -496,7 +501,7 @@ def main():
         V = tot["visible_blocks"] / max(tot["frames"], 1)
         U = tot["updated_voxels"] / max(tot["frames"], 1)
         b_alg = 15.0 * W * H + 12.0 * V + 24.0 * U
-        roof = roofline_block(b_alg, k_ms, k_n, a.config)
+        roof = roofline_block(b_alg, k_ms, k_n, a.config, whole_frame_gbps=b_alg * fps / world / 1e9)
         out = {
             "metric": ("depth+semantic frames/sec integrated @640x480, 5mm voxels" if a.config == "vga5mm"
                        else f"depth+semantic frames/sec integrated @{W}x{H}, {vs * 1e3:g}mm voxels"),

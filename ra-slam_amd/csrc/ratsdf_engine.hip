@@ -94,7 +94,7 @@ struct ratsdf_engine {
   unsigned parity = 0;                   // which texel buffer / candidate set the NEXT frame uses
   bool cand_ready = false;               // that frame's candidate pass has already been enqueued
   bool cand_split_env = false;
-  unsigned cand_split = 40;              // percent of the look-ahead pass placed in k_front,
+  unsigned cand_split = 20;              // percent of the look-ahead pass placed in k_front,
   unsigned cand_split_b = 0;             // in k_alloc_rank; the rest rides in k_integrate
   bool fused_serial = true;              // the frame's serial role rides in k_integrate (no k_alloc_rank)
   int commit_rot_env = -1;               // RATSDF_COMMIT_ROT: first committing workgroup (measurements)
@@ -520,10 +520,10 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     hipLaunchKernelGGL(k_cand, dim3((job.n_tiles + 3) / 4), dim3(256), 0, stream, job, ctl);
   }
   // Where the NEXT frame's candidate pass rides (interleaved A/B, profiles/r02_split_ab.txt): at
-  // 640x480 40 % in k_front and the rest at the head of k_integrate's grid (+6.6 % frames/s over
-  // 60 % / 40 % in k_front / k_alloc_rank: the serial launch stays short, and the pass overlaps the
-  // memory-latency-bound voxel update); at 1280x720 all of it in k_front (differences below 1.5 %,
-  // and k_integrate stays the pure voxel update its roofline figure is about)
+  // 640x480 20 % in k_front and the rest at the head of k_integrate's grid (10-30 % measure the same,
+  // 0 and 40 % are ~2.5 % slower: k_front is a chain of dependent round trips that a few riders do not
+  // lengthen, the voxel update hides the rest); at 1280x720 all of it in k_front (best by 1-3 %, and
+  // k_integrate stays the pure voxel update its roofline figure is about)
   const int split = (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
   const int split_b = (fused_serial && vpl != 1) ? 0 : (int)(cand_split_env ? cand_split_b : 0u);
   const Geom g = geometry(H, W, next != nullptr, split, split_b);
