@@ -131,7 +131,6 @@ __device__ inline bool block_visible(int bx, int by, int bz, const FrameParams& 
 // placement), so the per-pixel texels of a tile are pulled into ONE XCD's L2 instead of all eight.
 // Placement only affects speed: any list is a correct home for any block.
 __device__ inline int block_list_of(int bx, int by, int bz, const FrameParams& P) {
-  if (RATSDF_DBG(P, 13)) return (bx * 73 + by * 19 + bz * 7) & 7;  // diagnostic: no image locality
   const V3 pw{(float)(bx * 8 + 4) * P.vs, (float)(by * 8 + 4) * P.vs, (float)(bz * 8 + 4) * P.vs};
   const V3 pc = se3_apply(P.T, pw);
   const V3 ph = intr_mul(P.K, pc);

@@ -73,31 +73,15 @@ struct FrameCtl {
   uint32_t n_winlist;      // > 0: the winners' raster ranks are listed in win_ranks[0, n_winlist) and
                            // k_integrate derives each winner's order from the list (few winners);
                            // 0: req_k holds the order (many winners, rank bitmap path)
-  uint32_t unused0;
-  // One-launch frames (k_frame): roles that run side by side in the launch count themselves in here
-  // when their stores are out; the serial role starts when all three are complete.
-  uint32_t consume_done;   // candidate-consumer workgroups finished (requests filed)
-  uint32_t release_done;   // pool-release workgroups finished (previous frame's indices pushed)
-  uint32_t scan_done;      // visible-list workgroups finished (lists complete)
-  uint32_t pad[19];
+  uint32_t serial_done;    // the frame's serial role has published its results (only consulted when
+                           // that role runs inside k_integrate, beside the voxel update)
+  uint32_t pad[22];
   // visible blocks per XCD list (image-tile buckets): list l counts in n_list[l * kListStride], one
   // 128-byte line per counter (they take ~2000 atomics per frame; sharing a line serialises them)
   uint32_t n_list[8 * 32];
-  // Flags that workgroups of the same launch POLL, on lines of their own and in 8 copies (a poller
-  // reads copy blockIdx.x & 7): hundreds of waves polling the line of the counters above starve the
-  // very atomics they are waiting for (measured: 3.4x on the whole frame).
-  //   serial_done: the frame's serial role has published (1; 2 = through the general paths, whose
-  //                plain stores the reader must acquire)
-  //   scan_go:     all visible-list workgroups of a one-launch frame have finished
-  //   req_go:      one-launch frame, the candidate consumers have finished: bit 31 | (bit 30 if the
-  //                frame has chained-bucket requests, which the resolver may still add to) | n_req
-  uint32_t serial_done[8 * 32];
-  uint32_t scan_go[8 * 32];
-  uint32_t req_go[8 * 32];
 };
 constexpr int kListStride = 32;
-constexpr int kFlagCopies = 8, kFlagStride = 32;
-static_assert(sizeof(FrameCtl) == 128 + 4 * 1024, "frame counters: one line + one line per list counter / flag copy");
+static_assert(sizeof(FrameCtl) == 128 + 1024, "frame counters: one line + one line per list counter");
 
 // Device-resident control block.
 struct Ctl {

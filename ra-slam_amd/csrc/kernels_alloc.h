@@ -35,39 +35,12 @@ __device__ inline void set_error(Ctl* ctl, uint32_t code) {
   atomicCAS(&ctl->error, expect, value);
 }
 // one thread: the words of a FrameCtl that are in use
-// Store that is written THROUGH this XCD's L2 (agent scope), in 8- and 4-byte pieces: for the few
-// records a role hands to another role of the same launch (k_frame).  The alternative, a release
-// fence per producer workgroup, writes back everything dirty in that L2 -- the texels of the
-// candidate pass running next door -- once per workgroup.
-template <typename T>
-__device__ inline void st_through(T* p, const T& v) {
-  static_assert(sizeof(T) % 4 == 0 && sizeof(T) <= 16, "record of 1-4 words");
-  constexpr int n = sizeof(T) / 4;
-  uint32_t w[n];
-  __builtin_memcpy(w, &v, sizeof(T));
-  uint32_t* q = reinterpret_cast<uint32_t*>(p);
-  int i = 0;
-  if (sizeof(T) == 16 || sizeof(T) == 8) {  // (8-byte aligned records)
-    for (; i + 1 < n; i += 2)
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(q + i),
-                         (unsigned long long)w[i] | ((unsigned long long)w[i + 1] << 32), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-  }
-  for (; i < n; ++i) __hip_atomic_store(q + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 __device__ inline void zero_frame_ctl(FrameCtl* F) {
   uint32_t* z = reinterpret_cast<uint32_t*>(F);
 #pragma unroll
-  for (int i = 0; i < 13; ++i) z[i] = 0;
+  for (int i = 0; i < 10; ++i) z[i] = 0;
 #pragma unroll
   for (int l = 0; l < kNumLists; ++l) F->n_list[l * kListStride] = 0;
-#pragma unroll
-  for (int c = 0; c < kFlagCopies; ++c) {
-    F->serial_done[c * kFlagStride] = 0;
-    F->scan_go[c * kFlagStride] = 0;
-    F->req_go[c * kFlagStride] = 0;
-  }
 }
 __device__ inline uint32_t ld_agent_u32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -154,7 +127,7 @@ __device__ inline void alloc_request(const Table& t, int x, int y, int z, uint32
   } else {
     const uint32_t slot = atomicAdd(&F->n_slow, 1u);
     if (slot < slow_cap) {
-      st_through(&slow[slot], SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank});
+      slow[slot] = SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank};
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
     }
@@ -222,7 +195,7 @@ __device__ inline void alloc_request_absent_wave(bool want, const Table& t, int 
       if (in_lds) {
         B.item[slot] = r;
       } else if (slot < req_cap) {
-        st_through(&req[slot], r);
+        req[slot] = r;
       } else {
         set_error(ctl, RATSDF_ERR_CAPACITY);
       }
@@ -231,7 +204,7 @@ __device__ inline void alloc_request_absent_wave(bool want, const Table& t, int 
   if (want && special) {
     const uint32_t slot = atomicAdd(&F->n_slow, 1u);
     if (slot < slow_cap) {
-      st_through(&slow[slot], SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank});
+      slow[slot] = SlowRequest{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank};
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
     }
@@ -248,7 +221,7 @@ __device__ inline void req_buf_flush(ReqBuf& B, Request* req, uint32_t req_cap, 
   const uint32_t base = B.base;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     if (base + i < req_cap) {
-      st_through(&req[base + i], B.item[i]);
+      req[base + i] = B.item[i];
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
     }

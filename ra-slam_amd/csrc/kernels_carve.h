@@ -249,7 +249,7 @@ __device__ inline void carve_release_role(const Pool& pool, const CarveBufs& cb,
     k += __shfl_xor(k, 2);
     k += __shfl_xor(k, 4);
     k += __shfl_xor(k, 8);
-    if (sub == 0 && item < n) st_through(&pool.heap[(uint32_t)nf + k], del_pool[item]);
+    if (sub == 0 && item < n) pool.heap[(uint32_t)nf + k] = del_pool[item];
   }
 }
 

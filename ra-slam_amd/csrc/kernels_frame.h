@@ -329,7 +329,6 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((am
     A.upd_wg = E->cb[par].upd_wg;
     A.par = par;
     const FrameParams P = ld_const(&J->P);
-    constexpr bool one_launch = false;
 #include "integrate_body.inc"
     return;
   }
@@ -344,125 +343,6 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((am
     const uint32_t nwords = ((uint32_t)(J->P.W * J->P.H) * (uint32_t)J->P.S + 31u) / 32u;
     serial_workgroup(E, par, nwords, role_lds);
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_frame: a whole frame in ONE launch.
-//
-// k_front is a chain of three dependent memory round trips (occupancy word -> directory entries ->
-// list append) that a launch of its own stretches to 8-9 us with a launch boundary on either side,
-// a third of the frame at 640x480.  Here its roles are workgroups at the head of the voxel update's
-// grid, ordered by completion counters in the frame's control block instead of launch boundaries:
-//
-//   gate (workgroup 0, only if the previous frame queued head / chain deletes; the others wait)
-//     -> { consume: requests from the frame's candidates | release: pool indices of the previous
-//          frame | scan: visible lists }          each counts itself done after a release
-//     -> serial role (workgroup 0: waits for all three, acquire)      publishes serial_done
-//     -> commit of the new blocks (update workgroups, after their visible share)
-//   scan -> voxel update of the listed blocks (update workgroups wait for scan_done, then read the
-//          lists with agent-scope loads: no cache invalidation while the update is running)
-//   carve (a block's min |tsdf| >= 0.9, after its update) waits for serial_done: the consumers and the
-//          resolver must have read the directory as it was before the frame's deletes.
-//
-// Every wait is for workgroups EARLIER in the grid (the dispatcher starts workgroups in order, so they
-// are resident or finished), and bounded (RATSDF_ERR_TIMEOUT).  The scan finishing before the serial
-// role publishes also means no commit can add a block to a directory that is still being listed.
-// Grid: [8: serial + 7 idle][n_cons_wg][kReleaseWGs][n_scan_wg][n_ahead_wg look-ahead][n_int_wg update].
-// ---------------------------------------------------------------------------------------------
-struct FrameGeom {
-  uint32_t cand_parts;   // consumer workgroups per candidate list (n_cons_wg = kCandSegs * cand_parts)
-  uint32_t n_scan_wg;    // visible-list workgroups (one occupancy word per lane)
-  uint32_t n_ahead_wg;   // look-ahead workgroups (the next frame's candidate pass)
-  uint32_t n_int_wg;     // update workgroups
-  uint32_t commit_rot;   // first update workgroup with a commit share
-};
-constexpr uint32_t kFrameSerialWGs = 8;
-
-template <int VPL, typename Ahead>
-__device__ __forceinline__ void frame_head_roles(EnginePtr E, const FrameParams& P, uint32_t par,
-                                                 const FrameGeom& G, Ahead ahead, uint32_t* role_lds) {
-  const uint32_t b = blockIdx.x;
-  const uint32_t n_cons_wg = kCandSegs * G.cand_parts;
-  const uint32_t first_cons = kFrameSerialWGs, first_rel = first_cons + n_cons_wg,
-                 first_scan = first_rel + kReleaseWGs, first_ahead = first_scan + G.n_scan_wg;
-  if (b >= first_ahead) {
-    const CandJob job = ahead();
-    cand_pixels_role(job, b - first_ahead, E->ctl, *reinterpret_cast<CandLds*>(role_lds));
-    return;
-  }
-  if (b != 0 && b < first_cons) return;
-  Ctl* ctl = E->ctl;
-  FrameCtl* F = &ctl->fr[par];
-  FrameCtl* Fp = &ctl->fr[par ^ 1u];
-  const Table tab = ld_const(&E->tab);
-  const CarveBufs cbp = ld_const(&E->cb[par ^ 1u]);
-  auto gate = [&]() { return carve_resolve_gate(tab, cbp, ctl, Fp); };  // uniform per workgroup
-  if (b == 0) {
-    (void)gate();  // workgroup 0 is the resolver of the previous frame's queued deletes
-    serial_workgroup(E, par, ((uint32_t)(P.W * P.H) * (uint32_t)P.S + 31u) / 32u, role_lds, n_cons_wg,
-                     kReleaseWGs, G.n_scan_wg);
-  } else if (b < first_rel) {
-    const uint32_t c = b - first_cons;
-    const RankBufs rb = ld_const(&E->rb);
-    cand_consume_role(tab, P, ld_const(&E->cand[par]), c % kCandSegs, c / kCandSegs, G.cand_parts, rb.req,
-                      rb.req_cap, E->slow, E->slow_cap, ctl, F, gate, *reinterpret_cast<ReqBuf*>(role_lds));
-    role_done(&F->consume_done);
-  } else if (b < first_scan) {
-    (void)gate();
-    carve_release_role(ld_const(&E->pool), cbp, ctl, Fp, b - first_rel, role_lds);
-    role_done(&F->release_done);
-  } else {
-    visible_append_role(tab, P, b - first_scan, E->vis, E->seg_cap, ctl, F, gate, role_lds);
-    role_done(&F->scan_done, G.n_scan_wg, F->scan_go);
-  }
-}
-
-template <int VPL>
-__global__ __launch_bounds__(RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_frame(
-    IntegArgs A, FrameParams P, EnginePtr E, FrameGeom G, CandJob ahead) {
-  __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
-  const uint32_t first_int = kFrameSerialWGs + kCandSegs * G.cand_parts + kReleaseWGs + G.n_scan_wg + G.n_ahead_wg;
-  if (__builtin_expect(blockIdx.x >= first_int, 1)) {
-    const uint32_t ibid = blockIdx.x - first_int;
-    const uint32_t n_int_wg = G.n_int_wg, commit_rot = G.commit_rot;
-    constexpr bool fused = true;
-    constexpr bool one_launch = true;
-#include "integrate_body.inc"
-    return;
-  }
-  frame_head_roles<VPL>(E, P, A.par, G, [&]() { return ahead; }, role_lds);
-}
-
-// the same for several engines (one grid slice per engine, blockIdx.y)
-template <int VPL>
-__global__ __launch_bounds__(RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_frame_g(
-    EnginePtr engs, JobPtr cur, JobPtr nxt, FrameGeom G, AheadGeom ag) {
-  __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
-  EnginePtr E = engs + blockIdx.y;
-  JobPtr J = cur + blockIdx.y;
-  const uint32_t par = J->par;
-  const FrameParams P = ld_const(&J->P);
-  const uint32_t first_int = kFrameSerialWGs + kCandSegs * G.cand_parts + kReleaseWGs + G.n_scan_wg + G.n_ahead_wg;
-  if (__builtin_expect(blockIdx.x >= first_int, 1)) {
-    const uint32_t ibid = blockIdx.x - first_int;
-    const uint32_t n_int_wg = G.n_int_wg, commit_rot = G.commit_rot;
-    constexpr bool fused = true;
-    constexpr bool one_launch = true;
-    IntegArgs A;
-    A.rgbw = E->pool.rgbw;
-    A.tsdf = E->pool.tsdf;
-    A.segm = E->pool.segm;
-    A.texA = E->texA[par];
-    A.texB = E->texB[par];
-    A.vis = E->vis;
-    A.seg_cap = E->seg_cap;
-    A.F = &E->ctl->fr[par];
-    A.upd_wg = E->cb[par].upd_wg;
-    A.par = par;
-#include "integrate_body.inc"
-    return;
-  }
-  frame_head_roles<VPL>(E, P, par, G, [&]() { return make_cand_job(E, nxt + blockIdx.y, ag); }, role_lds);
 }
 
 }  // namespace ratsdf

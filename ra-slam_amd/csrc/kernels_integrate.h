@@ -100,43 +100,6 @@ struct VecIO<1> {
 // requests sorted in device memory by 256 threads) takes tens of milliseconds.
 constexpr unsigned long long kSerialWaitTicks = 200000000;  // 2 s of the 100 MHz wall clock
 
-// One wave waits until *p reaches `target` (one lane polls; bounded, sticky error on expiry).
-__device__ inline void wait_counter(const uint32_t* p, uint32_t target, Ctl* ctl) {
-  if ((threadIdx.x & 63u) == 0) {
-    const unsigned long long t0 = (unsigned long long)wall_clock64();
-    while (ld_agent(p) < target) {
-      if ((unsigned long long)wall_clock64() - t0 > kSerialWaitTicks) {
-        set_error(ctl, RATSDF_ERR_TIMEOUT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(16);
-    }
-  }
-}
-__device__ inline VisItem ld_agent_item(const VisItem* p) {
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  unsigned long long w[2];
-  w[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  w[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  VisItem r;
-  __builtin_memcpy(&r, w, sizeof(r));
-  return r;
-}
-// A role of a one-launch frame is complete: its records were written through (st_through) and the
-// barrier has seen every wave's stores acknowledged; now it is counted.
-// `go` (optional): flag copies the LAST of `n_wg` workgroups raises for the pollers.
-__device__ inline void role_done(uint32_t* counter, uint32_t n_wg = 0, uint32_t* go = nullptr) {
-  __syncthreads();  // (waits for the stores of every wave to be acknowledged)
-  if (threadIdx.x == 0) {
-    const uint32_t before = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (go && before + 1u == n_wg) {
-#pragma unroll
-      for (int c = 0; c < kFlagCopies; ++c)
-        __hip_atomic_store(&go[c * kFlagStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 __device__ inline void st_agent(uint32_t* p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -156,8 +119,7 @@ __device__ inline void wait_serial_done(FrameCtl* F, Ctl* ctl) {
   uint32_t v = 0;
   if ((threadIdx.x & 63u) == 0) {
     const unsigned long long t0 = (unsigned long long)wall_clock64();
-    const uint32_t* flag = &F->serial_done[(blockIdx.x & (kFlagCopies - 1)) * kFlagStride];
-    while ((v = ld_agent(flag)) == 0u) {
+    while ((v = ld_agent(&F->serial_done)) == 0u) {
       if ((unsigned long long)wall_clock64() - t0 > kSerialWaitTicks) {
         set_error(ctl, RATSDF_ERR_TIMEOUT);
         break;
@@ -193,49 +155,8 @@ __device__ inline void mark_winner(Request* p, const Request& r) {
 }
 
 __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, uint32_t nwords,
-                                      uint32_t* lds /* >= 8 words */, uint32_t n_cons_wg = 0,
-                                      uint32_t n_rel_wg = 0, uint32_t n_scan_wg = 0) {
+                                      uint32_t* lds /* >= 8 words */) {
   constexpr uint32_t NT = 256;
-  if (n_cons_wg != 0) {  // uniform: a one-launch frame -- the roles whose results this one reads run
-    // beside it.  Requests filed (consume), the previous frame's pool indices pushed (release), and
-    // the visible lists complete (scan: so that no commit can add a block to a directory that is
-    // still being listed).
-    FrameCtl* Fw = &E->ctl->fr[par];
-#ifdef RATSDF_STAMPS  // timeline of a one-launch frame, 10 ns ticks since this workgroup started
-    unsigned long long* st = E->ctl->stamps;
-    unsigned long long t0 = 0;
-    if (threadIdx.x == 0) {
-      t0 = wall_clock64();
-      if (st[26]) {  // the previous frame's marks (absolute) against its own start
-        st[25] += st[27] - st[26];
-        st[30] += st[29] - st[26];
-        st[31] += st[28] - st[26];
-      }
-      st[26] = t0;
-      st[27] = 0;
-    }
-#define FSTAMP(i) do { if (threadIdx.x == 0) st[i] += wall_clock64() - t0; } while (0)
-#else
-#define FSTAMP(i) do { } while (0)
-#endif
-    if (threadIdx.x < 64) {
-      wait_counter(&Fw->consume_done, n_cons_wg, E->ctl);
-      FSTAMP(20);
-      if (threadIdx.x == 0) {  // the request count is final unless the resolver has work: tell the
-        // update workgroups now whether they have a commit share (most do not and can leave)
-        const uint32_t nr = ld_agent(&Fw->n_req), nsl = ld_agent(&Fw->n_slow);
-        const uint32_t word = 0x80000000u | (nsl ? 0x40000000u : 0u) | (nr & 0x3FFFFFFFu);
-#pragma unroll
-        for (int c = 0; c < kFlagCopies; ++c) st_agent(&Fw->req_go[c * kFlagStride], word);
-      }
-      wait_counter(&Fw->release_done, n_rel_wg, E->ctl);
-      FSTAMP(21);
-      wait_counter(&Fw->scan_done, n_scan_wg, E->ctl);
-      FSTAMP(22);
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
   constexpr uint32_t UPT = kUpdCounters / NT;  // update counters per thread
   const uint32_t tid = threadIdx.x;
   Ctl* ctl = E->ctl;
@@ -347,10 +268,8 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
 
 // workgroup 0 of a fused launch: the role, then the hand-off (every storing wave drained, barrier,
 // one agent-scope release, the flag)
-__device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint32_t nwords, uint32_t* lds,
-                                                 uint32_t n_cons_wg = 0, uint32_t n_rel_wg = 0,
-                                                 uint32_t n_scan_wg = 0) {
-  const uint32_t how = serial_role256(E, par, nwords, lds, n_cons_wg, n_rel_wg, n_scan_wg);
+__device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint32_t nwords, uint32_t* lds) {
+  const uint32_t how = serial_role256(E, par, nwords, lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -358,14 +277,7 @@ __device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#pragma unroll
-    for (int c = 0; c < kFlagCopies; ++c) st_agent(&E->ctl->fr[par].serial_done[c * kFlagStride], how);
-#ifdef RATSDF_STAMPS
-    if (n_cons_wg) {
-      E->ctl->stamps[23] += wall_clock64() - E->ctl->stamps[26];
-      E->ctl->stamps[24] += 1;
-    }
-#endif
+    st_agent(&E->ctl->fr[par].serial_done, how);
   }
 }
 
@@ -543,7 +455,7 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
 // LDS-only barrier per call is enough: a wave can only be one call ahead of the slowest reader.
 template <int WPB>
 __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, uint32_t par,
-                                    bool carve_after_serial, const VisItem& item,
+                                    const VisItem& item,
                                     bool active, float m, uint32_t nupd, uint32_t wv, uint32_t part,
                                     uint32_t lane, uint32_t phase, uint32_t counter, float (*smin)[8],
                                     uint32_t (*supd)[8]) {
@@ -568,9 +480,6 @@ __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, 
   if (fin) {
     if (nupd) atomicAdd(&upd_wg[counter & (kUpdCounters - 1)], nupd);
     if (m >= .9f) {  // rare: operands come from the engine record, not from registers held all along
-      // one-launch frame: the candidate consumers (and the resolver) read the directory as it is
-      // BEFORE the frame's carving; the serial role publishes after all of them
-      if (carve_after_serial) wait_serial_done(F, E->ctl);
       const Table tab = ld_const(&E->tab);
       const CarveBufs cb = ld_const(&E->cb[par]);
       carve_candidate(tab, cb, E->ctl, F, item);
@@ -619,7 +528,6 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((am
   if (__builtin_expect(blockIdx.x >= n_serial_wg + n_ahead_wg, 1)) {
     const uint32_t ibid = blockIdx.x - n_serial_wg - n_ahead_wg;
     const bool fused = n_serial_wg != 0;
-    constexpr bool one_launch = false;
 #include "integrate_body.inc"
     return;
   }

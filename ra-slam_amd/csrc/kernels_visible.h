@@ -151,7 +151,7 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
         v.y = ew.w1;
         v.z = (uint32_t)ew.idx;
         v.w = e;
-        st_through(reinterpret_cast<uint4*>(vis) + ((size_t)l * seg_cap + pos), v);
+        reinterpret_cast<uint4*>(vis)[(size_t)l * seg_cap + pos] = v;
       }
     }
     if (!again) break;  // uniform

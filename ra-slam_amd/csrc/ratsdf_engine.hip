@@ -98,7 +98,6 @@ struct ratsdf_engine {
   unsigned cand_split_b = 0;             // in k_alloc_rank; the rest rides in k_integrate
   bool fused_serial = true;              // the frame's serial role rides in k_integrate (no k_alloc_rank)
   int commit_rot_env = -1;               // RATSDF_COMMIT_ROT: first committing workgroup (measurements)
-  bool one_launch = false;               // 1: a frame is ONE launch (k_frame); 0: k_front + k_integrate
   // With the serial role in the launch: which update workgroups take the frame's commits.  A grid of
   // at most two rounds of resident workgroups (256 CUs x 8): the first ones, which wait for the role
   // after their first block (anything later is the tail).  More rounds: the second round.
@@ -525,10 +524,8 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // 0 and 40 % are ~2.5 % slower: k_front is a chain of dependent round trips that a few riders do not
   // lengthen, the voxel update hides the rest); at 1280x720 all of it in k_front (best by 1-3 %, and
   // k_integrate stays the pure voxel update its roofline figure is about)
-  const bool fused = fused_serial && vpl != 1;
-  const bool one = one_launch && fused;  // the whole frame in k_frame: the look-ahead pass rides there
-  const int split = one ? 0 : (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
-  const int split_b = fused ? 0 : (int)(cand_split_env ? cand_split_b : 0u);
+  const int split = (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
+  const int split_b = (fused_serial && vpl != 1) ? 0 : (int)(cand_split_env ? cand_split_b : 0u);
   const Geom g = geometry(H, W, next != nullptr, split, split_b);
   // shares of the next frame's candidate pass: k_front, k_alloc_rank, k_integrate
   CandJob ahead_a, ahead_b, ahead_c;
@@ -553,10 +550,10 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   cand_ready = next != nullptr;
 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
-  if (!one)
   hipLaunchKernelGGL(k_front, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
                      (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(par ^ 1u),
                      ctl, (uint32_t)par, ahead_a);
+  const bool fused = fused_serial && vpl != 1;
   if (!fused) {
     st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
     if (st != RATSDF_OK) return st;
@@ -597,24 +594,6 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   hipExtLaunchKernelGGL(k_integrate<V>, dim3(integrate_grid + n_serial_wg + extra_c), dim3(NT), 0, \
                         stream, ev0, ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid,    \
                         n_serial_wg, (uint32_t)extra_c, commit_rot, ahead_c)
-  FrameGeom fg;
-  fg.cand_parts = g.parts;
-  fg.n_scan_wg = g.n_vis_wg;
-  fg.n_ahead_wg = extra_c;
-  fg.n_int_wg = integrate_grid;
-  fg.commit_rot = commit_rot;
-  const unsigned frame_grid = kFrameSerialWGs + kCandSegs * g.parts + kReleaseWGs + g.n_vis_wg + extra_c +
-                              integrate_grid;
-#define RATSDF_LAUNCH_FRAME(V)                                                                      \
-  hipExtLaunchKernelGGL(k_frame<V>, dim3(frame_grid), dim3(RATSDF_INTEG_NT), 0, stream, ev0, ev1, 0, \
-                        ia, P, (EnginePtr)d_eng, fg, ahead_c)
-  if (one) {
-    switch (vpl) {
-      case 8: RATSDF_LAUNCH_FRAME(8); break;
-      case 4: RATSDF_LAUNCH_FRAME(4); break;
-      default: RATSDF_LAUNCH_FRAME(2);
-    }
-  } else
   switch (vpl) {
     case 1: RATSDF_LAUNCH_INTEGRATE(1, 512); break;
     case 8: RATSDF_LAUNCH_INTEGRATE(8, RATSDF_INTEG_NT); break;
@@ -622,7 +601,6 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     default: RATSDF_LAUNCH_INTEGRATE(2, RATSDF_INTEG_NT);
   }
 #undef RATSDF_LAUNCH_INTEGRATE
-#undef RATSDF_LAUNCH_FRAME
 
   HIPCHK(hipGetLastError());
   pending = true;
@@ -698,7 +676,6 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     if (x >= 1 && x <= 64) e->cand_parts_env = (unsigned)x;
   }
   if (const char* v = getenv("RATSDF_COMMIT_ROT")) e->commit_rot_env = atoi(v);
-  if (const char* v = getenv("RATSDF_ONE_LAUNCH")) e->one_launch = atoi(v) != 0;  // 0: k_front + k_integrate
   if (const char* v = getenv("RATSDF_FUSED_SERIAL")) e->fused_serial = atoi(v) != 0;  // 0: k_alloc_rank launch
   if (const char* v = getenv("RATSDF_SERIAL_LDS")) {
     const int x = atoi(v);
@@ -1122,11 +1099,6 @@ extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
     const double m = t[17] ? (double)t[17] : 1.0;
     fprintf(stderr, "[stamps] candidate pass, thread 0 of sampled workgroups (shader cycles): first barrier %.0f | pixel work %.0f | wait for the workgroup %.0f | compaction + stores %.0f\n",
             (double)t[14] / m, (double)t[15] / m, (double)t[16] / m, (double)t[18] / m);
-  }
-  if (t[24]) {
-    const double k = 0.01 / (double)t[24];  // 10 ns ticks -> us per frame
-    fprintf(stderr, "[stamps] one-launch frame, us after workgroup 0 started: consumers done %.2f | releases done %.2f | scan done %.2f | serial published %.2f | first update workgroup let go %.2f | last update workgroup starts %.2f | last block updated %.2f\n",
-            t[20] * k, t[21] * k, t[22] * k, t[23] * k, t[30] * k, t[31] * k, t[25] * k);
   }
   return RATSDF_OK;
 }

@@ -14,17 +14,10 @@ H, W = frames[0]["depth"].shape
 dd = [(torch.from_numpy(f["rgb"]).to(dev), torch.from_numpy(f["depth"]).to(dev),
        torch.from_numpy(f["ht"]).to(dev), torch.from_numpy(f["lt"]).to(dev)) for f in frames]
 eng = ratsdf.TSDFGrid(0.005, 0.03)
-if os.environ.get("STAMPS_BATCH"):  # the pipelined path (look-ahead riders), as bench.py drives it
-    b = eng.make_batch([d[0].data_ptr() for d in dd], [d[1].data_ptr() for d in dd], [d[2].data_ptr() for d in dd],
-                       [d[3].data_ptr() for d in dd], H, W, 4.0, [f["intrinsics"] for f in frames],
-                       [f["pose"] for f in frames])
-    for rep in range(4):
-        eng.integrate_device_batch(b)
-else:
-    for rep in range(4):
-        for f, d in zip(frames, dd):
-            eng.integrate_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), H, W,
-                                 4.0, f["intrinsics"], f["pose"])
+for rep in range(4):
+    for f, d in zip(frames, dd):
+        eng.integrate_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), H, W,
+                             4.0, f["intrinsics"], f["pose"])
 eng.synchronize()
 ws = eng.lib.dll.ratsdf_debug_wave_stamps
 ws.argtypes = [ctypes.c_void_p, ctypes.c_int]
