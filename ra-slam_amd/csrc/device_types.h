@@ -66,22 +66,29 @@ struct FrameCtl {
   uint32_t n_slow;         // slow (chained-bucket) requests appended this pass
   uint32_t n_win;          // winners of the allocation pass
   uint32_t alloc_base;     // num_free at the start of the allocation pass
-  uint32_t n_delcand;      // slot-0 deletes done by k_integrate (pool release pending)
-  uint32_t n_slow_del;     // head / chain deletes waiting for carve_resolve_slow
   uint32_t pending;        // this frame's carve pass has not been finalised yet
-  uint32_t slow_resolved;  // carve_resolve_slow has run for this frame
   uint32_t n_winlist;      // > 0: the winners' raster ranks are listed in win_ranks[0, n_winlist) and
                            // k_integrate derives each winner's order from the list (few winners);
                            // 0: req_k holds the order (many winners, rank bitmap path)
-  uint32_t serial_done;    // the frame's serial role has published its results (only consulted when
-                           // that role runs inside k_integrate, beside the voxel update)
-  uint32_t pad[22];
+  uint32_t pad[26];
   // visible blocks per XCD list (image-tile buckets): list l counts in n_list[l * kListStride], one
   // 128-byte line per counter (they take ~2000 atomics per frame; sharing a line serialises them)
   uint32_t n_list[8 * 32];
+  // The frame's serial role has published its results (1; 2 = through the general paths, whose plain
+  // stores the reader must acquire).  Only consulted when that role runs inside k_integrate.  On a
+  // line of its own: the committing workgroups POLL it, and waves polling the line of the counters
+  // above slow down the very atomics and loads (requests, deletes) that share it.
+  uint32_t serial_done;
+  uint32_t pad2[31];
+  // Counters of the carve pass, which k_integrate bumps with atomics while every one of its
+  // workgroups reads the first line when it starts: a line of their own as well.
+  uint32_t n_delcand;      // slot-0 deletes done by k_integrate (pool release pending)
+  uint32_t n_slow_del;     // head / chain deletes waiting for carve_resolve_slow
+  uint32_t slow_resolved;  // carve_resolve_slow has run for this frame
+  uint32_t pad3[29];
 };
 constexpr int kListStride = 32;
-static_assert(sizeof(FrameCtl) == 128 + 1024, "frame counters: one line + one line per list counter");
+static_assert(sizeof(FrameCtl) == 128 + 1024 + 2 * 128, "frame counters: one line + one line per list counter + flag line");
 
 // Device-resident control block.
 struct Ctl {

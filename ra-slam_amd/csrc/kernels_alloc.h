@@ -36,9 +36,16 @@ __device__ inline void set_error(Ctl* ctl, uint32_t code) {
 }
 // one thread: the words of a FrameCtl that are in use
 __device__ inline void zero_frame_ctl(FrameCtl* F) {
-  uint32_t* z = reinterpret_cast<uint32_t*>(F);
-#pragma unroll
-  for (int i = 0; i < 10; ++i) z[i] = 0;
+  F->n_req = 0;
+  F->n_slow = 0;
+  F->n_win = 0;
+  F->alloc_base = 0;
+  F->pending = 0;
+  F->n_winlist = 0;
+  F->serial_done = 0;
+  F->n_delcand = 0;
+  F->n_slow_del = 0;
+  F->slow_resolved = 0;
 #pragma unroll
   for (int l = 0; l < kNumLists; ++l) F->n_list[l * kListStride] = 0;
 }
