@@ -14,7 +14,8 @@
 //   cand_consume_role  per candidate: directory lookup, frustum test, atomicMin(claim[bucket], rank)
 //                      for ordinary buckets ("first requester in raster order wins the bucket
 //                      lock"), append to a small slow list for chained / full buckets (k_front)
-//   serial_frame_role  one workgroup (k_alloc_rank, kernels_frame.h): (a) replays the slow list in
+//   serial_frame_role  one workgroup (workgroup 0 of k_integrate as serial_role256, kernels_integrate.h;
+//                      k_alloc_rank, kernels_frame.h, as a launch of its own): (a) replays the slow list in
 //                      rank order against the claim table (time-dependent lock / fill queries), so
 //                      chain appends lock, link and defeat later claims exactly as the sequential
 //                      code would; (b) winners = requests whose rank equals their bucket's claim;

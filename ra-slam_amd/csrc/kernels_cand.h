@@ -7,7 +7,7 @@
 // wave and touches no map state, so it does not have to sit on the frame's critical path: when the
 // caller hands over a batch of frames (ratsdf_integrate_device_batch = the queue of
 // TSDFSystem::Run, modules/tsdf_module.cc:88-115), the candidate pass of frame f+1 runs as extra
-// workgroups inside frame f's k_front and k_alloc_rank, which leave most of the chip idle.  A single
+// workgroups inside frame f's k_front and k_integrate (kernels_frame.h).  A single
 // frame (ratsdf_integrate_device) runs it as its own launch.
 //
 // Output of the pass = the frame's candidate list: (block, raster rank = pixel * S + sample) pairs,

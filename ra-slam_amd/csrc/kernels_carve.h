@@ -14,7 +14,7 @@
 //                        other directory readers of that launch wait for it)
 //                        one winner per home bucket = the first in entry order (the bucket lock of
 //                        voxel_hash.cu:125-158); winners unlink; claims are released (ResetLocks)
-//   carve_finalize       (in the next k_alloc_rank, before its own pass; or k_settle when no frame
+//   carve_finalize       (in the next frame's serial role, before its own pass; or k_settle when no frame
 //                        follows) ReleaseBlock in ascending entry order of the deleted blocks:
 //                          few deletes (the steady state): entries in an LDS list, every delete
 //                          counts the smaller ones; many deletes: entry-indexed bitmap + popcount
@@ -190,7 +190,7 @@ __device__ inline bool carve_resolve_gate(const Table& tab, const CarveBufs& cb,
 // delete w goes to heap[num_free + (number of deleted entries below its own)].  Every workgroup
 // holds the whole list of deleted entries in LDS; 16 lanes share a delete and each scans a 16th of
 // the list.  num_free is the value the frame's own allocation pass left (nothing changes it until
-// the next k_alloc_rank, which adds the number of releases).  The slow (head / chain) deletes of the
+// the next frame's serial role, which adds the number of releases).  The slow (head / chain) deletes of the
 // frame have been resolved before this runs (carve_resolve_gate).
 constexpr uint32_t kReleaseWGs = 16;
 

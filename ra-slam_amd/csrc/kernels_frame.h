@@ -1,15 +1,21 @@
-// kernels_frame.h -- the launches of a frame besides k_integrate.  A frame is three launches:
+// kernels_frame.h -- the launches of a frame besides k_integrate.  A frame is TWO launches:
 //
 //   k_front(f)       reads the directory: visible list (visible_append_role) + allocation requests
 //                    from the frame's candidate set (cand_consume_role); first makes sure the queued
-//                    head / chain deletes of frame f-1 have happened (carve_resolve_gate)
-//   k_alloc_rank(f)  ONE workgroup does the serial bookkeeping: pool releases and statistics of frame
-//                    f-1 (carve_finalize), then this frame's allocation order (alloc_rank_role)
-//   k_integrate(f)   commit of the winners + voxel update + start of the carve pass
+//                    head / chain deletes of frame f-1 have happened (carve_resolve_gate); pool
+//                    releases of frame f-1 (carve_release_role)
+//   k_integrate(f)   workgroup 0: the frame's serial role (statistics of frame f-1, allocation order
+//                    of frame f; kernels_integrate.h: serial_role256); everybody else: voxel update of
+//                    the visible blocks, then -- once the serial role has published -- commit and
+//                    first update of the new blocks; start of the carve pass
 //
-// Both k_front and k_alloc_rank leave most of the chip idle, so when the caller has already handed
-// over frame f+1 (ratsdf_integrate_device_batch) its directory-independent candidate pass
+// k_front leaves most of the chip idle and k_integrate is latency-bound, so when the caller has already
+// handed over frame f+1 (ratsdf_integrate_device_batch) its directory-independent candidate pass
 // (cand_pixels_role) rides along as extra workgroups: `ahead` describes the share each launch takes.
+//
+// k_alloc_rank is the serial role as a launch of its own (1024 threads, its scratch in LDS): what the
+// stand-alone test hooks run, and RATSDF_FUSED_SERIAL=0 puts it back between the two launches for A/B
+// measurements (RATSDF_VPL=1 as well).
 #pragma once
 #include "kernels_integrate.h"
 

@@ -23,7 +23,7 @@ def main():
     fr = [i for i, (a, b, n) in enumerate(rows) if n == "k_front"]
     gaps = [(rows[fr[i + 1]][0] - rows[fr[i]][0]) / 1e3 for i in range(len(fr) - 1)]
     # a batch boundary = a gap that contains something else than the frame's own launches
-    own = {"k_front", "k_alloc_rank", "k_integrate<2>"}
+    own = {"k_front", "k_alloc_rank", "k_integrate<2>"}  # (k_alloc_rank: only with RATSDF_FUSED_SERIAL=0)
     inner, boundary = [], []
     for i in range(len(fr) - 1):
         names = {rows[j][2] for j in range(fr[i], fr[i + 1])}
