@@ -267,7 +267,8 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
                                              const SlowRequest* slow, uint32_t slow_cap,
                                              XLock* xlocks, SlowRequest* distinct, Ctl* ctl,
                                              FrameCtl* F, unsigned long long* lds_keys,
-                                             unsigned long long* global_keys) {
+                                             unsigned long long* global_keys,
+                                             uint32_t lds_cap = (uint32_t)kSlowLdsCap) {
   uint32_t n = F->n_slow;
   if (n > slow_cap) n = slow_cap;
   if (n > (uint32_t)kSlowSortCap) {
@@ -276,7 +277,7 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
   }
   // few keys (always, with the default directory size): LDS; many: a global scratch buffer, which is
   // coherent inside one workgroup (same CU, write-through L1, __syncthreads() drains the stores)
-  unsigned long long* skeys = n <= (uint32_t)kSlowLdsCap ? lds_keys : global_keys;
+  unsigned long long* skeys = n <= lds_cap ? lds_keys : global_keys;
   uint32_t m = 1;
   while (m < n) m <<= 1;
   for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
@@ -318,13 +319,20 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
     if (c != kInf && c > time) tab.claim[bucket] = kInf;  // a later leader finds the lock taken
   };
   auto place = [&](uint32_t e, const SlowRequest& s) {
+    // (agent-scope stores: when this role runs inside k_integrate, the committing and carving
+    // workgroups of the same launch read these words past their own L2)
     uint32_t* p = reinterpret_cast<uint32_t*>(tab.entries + e);
-    p[0] = key0(s.x, s.y);
-    p[1] = key1(s.z);  // offset 0
-    p[2] = (uint32_t)kPlaceholderIdx;
+    __hip_atomic_store(&p[0], key0(s.x, s.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p[1], key1(s.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // offset 0
+    __hip_atomic_store(&p[2], (uint32_t)kPlaceholderIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t slot = atomicAdd(&F->n_req, 1u);
     if (slot < req_cap) {
-      req[slot] = Request{s.x, s.y, s.z, (uint16_t)(kReqWinner | kReqPlaced), s.rank, e};
+      const Request r{s.x, s.y, s.z, (uint16_t)(kReqWinner | kReqPlaced), s.rank, e};
+      unsigned long long w[2];
+      __builtin_memcpy(w, &r, sizeof(r));
+      unsigned long long* q = reinterpret_cast<unsigned long long*>(req + slot);
+      __hip_atomic_store(q, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(q + 1, w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
     }
@@ -384,7 +392,8 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
         const uint32_t wrap = next > last ? 0u : tab.num_entry;
         uint32_t* pl = reinterpret_cast<uint32_t*>(tab.entries + last);
         const int16_t link = (int16_t)(next + wrap - last);             // :98-99
-        pl[1] = (pl[1] & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16);
+        __hip_atomic_store(&pl[1], (pl[1] & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
         place(next, s);
       }
     }
@@ -546,13 +555,13 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
                                        XLock* xlocks, SlowRequest* distinct, uint32_t* bitmap,
                                        uint32_t* summary, uint32_t* prefix, uint32_t nwords,
                                        unsigned long long* sort_scratch, Ctl* ctl, FrameCtl* F,
-                                       int32_t nf, unsigned long long* skeys) {
+                                       int32_t nf, unsigned long long* skeys, bool resolved = false) {
   uint32_t* lds = reinterpret_cast<uint32_t*>(skeys);  // [0,32): scan scratch, [32]: counter
   uint32_t* lds_rank = lds + 64;                       // kSmallRank words
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   RATSDF_STAMP(ctl->stamps, 8);
   const uint32_t n_slow = F->n_slow;
-  if (n_slow != 0) {  // uniform
+  if (n_slow != 0 && !resolved) {  // uniform
     resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, distinct, ctl, F, skeys,
                           sort_scratch);
     __syncthreads();

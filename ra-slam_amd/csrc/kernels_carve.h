@@ -267,10 +267,6 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
   uint32_t nd = F->n_delcand, ns = F->n_slow_del;
   if (nd > cb.del_cap) nd = cb.del_cap;
   if (ns > cb.slow_cap) ns = cb.slow_cap;
-  const uint32_t n_win = F->n_win, n_slow_req = F->n_slow;
-  uint32_t nv = n_win;
-#pragma unroll
-  for (int l = 0; l < kNumLists; ++l) nv += F->n_list[l * kListStride];
   // voxels updated: per-workgroup counters of k_integrate (consumed here)
   uint32_t upd_part = 0;
   for (uint32_t i = tid; i < kUpdCounters; i += nt) {
@@ -330,6 +326,12 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
   uint32_t upd = 0;
   (void)block_exclusive_scan(upd_part, lds, &upd);
   if (tid == 0) {
+    // (the frame's counters are read here, not at the top: ten values held across the bitmap passes
+    // pushed the kernels that inline this function into scratch memory)
+    const uint32_t n_win = F->n_win, n_slow_req = F->n_slow;
+    uint32_t nv = n_win;
+#pragma unroll
+    for (int l = 0; l < kNumLists; ++l) nv += F->n_list[l * kListStride];
     if (stats) {
       stats->visible_blocks = (int32_t)nv;
       stats->updated_voxels = (int32_t)upd;

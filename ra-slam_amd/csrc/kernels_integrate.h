@@ -96,6 +96,8 @@ struct VecIO<1> {
 // 1024-thread one re-cut for 256 threads; everything unusual calls the general functions with their
 // scratch in device memory instead of LDS (rare: first frames of a view, chained buckets).
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kFusedSlowCap = 512;  // chained-bucket requests resolved with their keys in the role's LDS
+
 // A safety net, not a deadline: the role's general path with every capacity exhausted (16 384 chained
 // requests sorted in device memory by 256 threads) takes tens of milliseconds.
 constexpr unsigned long long kSerialWaitTicks = 200000000;  // 2 s of the 100 MHz wall clock
@@ -136,7 +138,8 @@ __device__ inline void wait_serial_done(FrameCtl* F, Ctl* ctl) {
 // into constant memory, not local copies): held in registers all along, the ~30 pointers pushed scalar
 // spills into scratch memory, and a kernel that uses scratch pays for it in every wave it launches
 // (-25% on the whole frame).
-__device__ __forceinline__ void serial_general(EnginePtr E, uint32_t par, uint32_t nwords, int32_t nf) {
+__device__ __forceinline__ void serial_general(EnginePtr E, uint32_t par, uint32_t nwords, int32_t nf,
+                                               bool resolved) {
   Ctl* ctl = E->ctl;
   const Table& tab = *(const Table*)(&E->tab);
   const RankBufs& rb = *(const RankBufs*)(&E->rb);
@@ -146,7 +149,7 @@ __device__ __forceinline__ void serial_general(EnginePtr E, uint32_t par, uint32
   nf += (int32_t)carve_finalize(tab, pool, cb, ctl, &ctl->fr[par ^ 1u], E->stats, nf, scratch);
   alloc_rank_role(tab, rb.req, rb.req_cap, rb.req_k, rb.slow, rb.slow_cap, rb.xlocks, rb.distinct,
                   rb.bitmap, rb.summary, rb.prefix, nwords, rb.sort_scratch, ctl, &ctl->fr[par], nf,
-                  reinterpret_cast<unsigned long long*>(scratch));
+                  reinterpret_cast<unsigned long long*>(scratch), resolved);
 }
 
 // word 1 of a request = z | flags << 16: the winner flag as one agent-scope word store
@@ -170,25 +173,54 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
   if (tid < kCandSegs) E->cand[par].count[tid * kCandCountStride] = 0;
 
   // ---- one round of loads ----
-  const int32_t nf0 = ctl->num_free;
-  const uint32_t pend = Fp->pending;
-  uint32_t nd = Fp->n_delcand, ns = Fp->n_slow_del;
-  const uint32_t p_win = Fp->n_win, p_slow = Fp->n_slow;
-  uint32_t nv = p_win;
+  int32_t nf0;
+  uint32_t pend, nd, ns, p_win, p_slow, nv, n;
+  Request r0, r1;
+  auto first_round = [&](auto after_resolver) {
+    nf0 = ctl->num_free;
+    pend = Fp->pending;
+    nd = Fp->n_delcand;
+    ns = Fp->n_slow_del;
+    p_win = Fp->n_win;
+    p_slow = Fp->n_slow;
+    nv = p_win;
 #pragma unroll
-  for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l * kListStride];
+    for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l * kListStride];
+    const Request* q0 = rb.req + (tid < rb.req_cap ? tid : 0);  // the first requests ride in the first round
+    const Request* q1 = rb.req + (tid + NT < rb.req_cap ? tid + NT : 0);
+    if (decltype(after_resolver)::value) {  // what it appended: past this CU's L1
+      n = ld_agent(&F->n_req);
+      r0 = ld_agent_request(q0);
+      r1 = ld_agent_request(q1);
+    } else {
+      n = F->n_req;
+      r0 = *q0;
+      r1 = *q1;
+    }
+  };
   const uint32_t n_slow = F->n_slow;
-  uint32_t n = F->n_req;
-  Request r0 = rb.req[tid < rb.req_cap ? tid : 0];  // the first requests ride in the first round
-  Request r1 = rb.req[tid + NT < rb.req_cap ? tid + NT : 0];
+  first_round(std::false_type{});
+  // Chained-bucket requests (a map of tens of thousands of blocks has a few in most frames): the
+  // resolver replays them in rank order against the claim table and appends what it places to the
+  // request list as winners; with its sort keys in the workgroup's LDS it costs a few dependent loads
+  // per request, and the rest of the frame is the ordinary one below.  (With its scratch in device
+  // memory and the LDS ranking of alloc_rank_role behind it, this took ~300 us per frame at 1280x720 /
+  // 2 mm on a 400 MB map: the general path is for frames that are unusual in size, not in kind.)
+  if (__builtin_expect(n_slow != 0, 0)) {  // uniform; the resolver's one call site in this role
+    resolve_slow_requests(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, rb.distinct, ctl, F,
+                          reinterpret_cast<unsigned long long*>(lds + 8), rb.sort_scratch, kFusedSlowCap);
+    __syncthreads();
+    first_round(std::true_type{});  // again rather than held in registers across the resolver (what it
+                                    // placed sits behind the frame's own requests)
+  }
   if (nd > cb.del_cap) nd = cb.del_cap;
   if (ns > cb.slow_cap) ns = cb.slow_cap;
   if (n > rb.req_cap) n = rb.req_cap;
 
-  const bool fast = (!pend || nd + ns <= kSmallCarve) && n_slow == 0 && n <= kSmallRank;
+  const bool fast = (!pend || nd + ns <= kSmallCarve) && n <= kSmallRank;
   if (__builtin_expect(!fast, 0)) {  // uniform: the general functions, scratch in device memory
 #ifndef RATSDF_FAST_ONLY  // (a measurement build: what the general paths' presence costs the kernel)
-    serial_general(E, par, nwords, nf0);
+    serial_general(E, par, nwords, nf0, true);
 #endif
     return 2u;
   }
@@ -203,21 +235,23 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
   lds_barrier();
   for (uint32_t base = 0; base < n; base += 2 * NT) {  // uniform
     const uint32_t i0 = base + tid, i1 = base + NT + tid;
-    if (base != 0) {
-      if (i0 < n) r0 = rb.req[i0];
-      if (i1 < n) r1 = rb.req[i1];
+    if (base != 0) {  // (agent scope: requests the resolver appended are read past this CU's L1)
+      if (i0 < n) r0 = ld_agent_request(rb.req + i0);
+      if (i1 < n) r1 = ld_agent_request(rb.req + i1);
     }
     uint32_t c0 = kInf, c1 = kInf;
     if (i0 < n) c0 = tab.claim[block_hash(r0.x, r0.y, r0.z, tab.bucket_mask)];
     if (i1 < n) c1 = tab.claim[block_hash(r1.x, r1.y, r1.z, tab.bucket_mask)];
     // the winners' ranks go to a compact list; the committing waves turn a rank into the winner's
-    // position in raster order (= order of the AquireBlock calls) by counting the smaller ones
-    if (i0 < n && c0 == r0.rank) {
-      mark_winner(rb.req + i0, r0);
+    // position in raster order (= order of the AquireBlock calls) by counting the smaller ones.
+    // A request the resolver placed is a winner as it stands (its bucket's claim is not its own).
+    const bool p0 = i0 < n && (r0.flags & kReqPlaced), p1 = i1 < n && (r1.flags & kReqPlaced);
+    if (i0 < n && (p0 || c0 == r0.rank)) {
+      if (!p0) mark_winner(rb.req + i0, r0);
       st_agent(&rb.win_ranks[atomicAdd(&lds[1], 1u)], r0.rank);
     }
-    if (i1 < n && c1 == r1.rank) {
-      mark_winner(rb.req + i1, r1);
+    if (i1 < n && (p1 || c1 == r1.rank)) {
+      if (!p1) mark_winner(rb.req + i1, r1);
       st_agent(&rb.win_ranks[atomicAdd(&lds[1], 1u)], r1.rank);
     }
   }
@@ -455,7 +489,7 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
 // LDS-only barrier per call is enough: a wave can only be one call ahead of the slowest reader.
 template <int WPB>
 __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, uint32_t par,
-                                    const VisItem& item,
+                                    bool carve_after_serial, const VisItem& item,
                                     bool active, float m, uint32_t nupd, uint32_t wv, uint32_t part,
                                     uint32_t lane, uint32_t phase, uint32_t counter, float (*smin)[8],
                                     uint32_t (*supd)[8]) {
@@ -480,6 +514,9 @@ __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, 
   if (fin) {
     if (nupd) atomicAdd(&upd_wg[counter & (kUpdCounters - 1)], nupd);
     if (m >= .9f) {  // rare: operands come from the engine record, not from registers held all along
+      // the resolver of this frame's chained-bucket requests (serial role, possibly still running
+      // beside this update) reads and edits the directory as it was BEFORE the frame's carving
+      if (carve_after_serial) wait_serial_done(F, E->ctl);
       const Table tab = ld_const(&E->tab);
       const CarveBufs cb = ld_const(&E->cb[par]);
       carve_candidate(tab, cb, E->ctl, F, item);

@@ -2,7 +2,7 @@
 """GPU box: per-frame statistics of the bench stream in its steady state (which frames leave the serial
 role's fast path: more than 2048 requests or deletes, or any chained-bucket request).
 
-    python tools/frame_stats_probe.py [--config vga5mm|hd2mm]
+    python tools/frame_stats_probe.py [--config vga5mm|hd2mm|bigmap]
 """
 import argparse
 import json
@@ -24,7 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="vga5mm")
     a = ap.parse_args()
-    cam, vs, B = ("scannet", 0.005, 90) if a.config == "vga5mm" else ("l515_720p", 0.002, 30)
+    cam, vs, B = {"vga5mm": ("scannet", 0.005, 90), "hd2mm": ("l515_720p", 0.002, 30),
+                  "bigmap": ("l515_720p", 0.002, 240)}[a.config]
     frames = make_stream("room", cam, (B + 1) // 2, phase=0)[:B]
     dev = torch.device("cuda", 0)
     t = [{k: torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")} for f in frames]
