@@ -335,11 +335,12 @@ def main():
     if world > 1:
         from ratsdf import multi
         if backend == "nccl":
-            # 2^16 entries (768 KiB per rank and step); a larger directory raises in result(), it is
-            # never truncated silently
-            ex = multi.DirectoryExchange(capacity=1 << 16, device=dev)
+            # deltas of the block directories: what a rank added / deleted since the previous
+            # step, at most 2^16 entries per rank and step (a larger directory or delta raises, it is
+            # never truncated silently); every rank keeps replicas of all directories
+            ex = multi.DirectoryDeltaExchange(capacity=1 << 16, device=dev)
         else:  # rehearsal backend (gloo): stage through the host
-            ex = multi.DirectoryExchange(capacity=1 << 16)
+            ex = multi.DirectoryDeltaExchange(capacity=1 << 16)
 
     def exchange():
         if backend == "nccl":
@@ -529,6 +530,7 @@ def main():
                 "directory_allgather_every_frames": len(frames) if world > 1 else None,
             },
             "directory_blocks_all_ranks": (int(sum(len(x) for x in ex.result())) if world > 1 else None),
+            "directory_delta_entries_last_step_rank0": (list(ex.last_sent) if world > 1 else None),
             "frame": {"avg_visible_blocks": round(V, 1), "avg_updated_voxels": round(U, 1),
                       "alg_bytes": round(b_alg), "alg_gbps_whole_frame": round(b_alg * fps / world / 1e9, 1),
                       "active_blocks": stats["active_blocks"],

@@ -8,7 +8,9 @@ modules/tsdf_module.h:152-164); this is the new design of SURVEY 8e:
 * frame-batched streams: every rank integrates its own stream into its own map.
 * in both modes the ranks periodically ALL-GATHER their block directories (12-byte entries) so any
   rank can tell which rank holds which block (queries across seams, global statistics).  Messages
-  are small (10^3..10^5 entries), so one fixed-capacity all-gather + one count all-gather is used.
+  are small (10^3..10^5 entries), so one fixed-capacity all-gather + one count all-gather is used:
+  DirectoryExchange sends whole directories, DirectoryDeltaExchange only what changed since the
+  previous exchange (every rank keeps replicas).
 """
 import numpy as np
 
@@ -91,6 +93,115 @@ class DirectoryExchange:
             n = int(counts[r])
             out.append(raw[r, :n * 3].copy().view(BLOCK_DTYPE))
         return out
+
+
+class DirectoryDeltaExchange(DirectoryExchange):
+    """The same exchange carrying only what CHANGED since the previous one ("all-gather of
+    the block directory delta ... every N frames"): a rank sends the entries it has added (or whose
+    pool index changed) and the positions it has deleted; every rank keeps a replica of every rank's
+    directory and applies the deltas.  The first exchange is a full one by construction (everything
+    is new).  Wire format per rank: counts {added, deleted}, then `capacity` 12-byte entries
+    (the added ones first, then the deleted ones: position only).  result() returns the replicas in
+    DirectoryExchange.result()'s form (entries sorted by position), so multi.query() takes either.
+
+    The engine still exports its whole directory into a device buffer per exchange (one small
+    kernel); the set differences are torch ops on that device, only the deltas travel."""
+
+    def __init__(self, capacity=None, device=None, engine=None):
+        super().__init__(capacity, device, engine)
+        torch = self.torch
+        dev = device if device is not None else "cpu"
+        self.count = torch.zeros(2, dtype=torch.int32, device=dev)            # {added, deleted}
+        self.counts = torch.zeros(self.world * 2, dtype=torch.int32, device=dev)
+        self.full = torch.zeros(self.capacity * 3, dtype=torch.int32, device=dev)  # export target
+        self.full_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._prev = torch.zeros((0, 3), dtype=torch.int32, device=dev)       # my directory as last sent
+        self._replica = [torch.zeros((0, 3), dtype=torch.int32, device=dev) for _ in range(self.world)]
+        self.last_sent = (0, 0)
+
+    def _pos_key(self, rows):
+        """int64 key of the block position (x, y, z int16 in the first 6 bytes of an entry)."""
+        i64 = self.torch.int64
+        return ((rows[:, 1].to(i64) & 0xFFFF) << 32) | (rows[:, 0].to(i64) & 0xFFFFFFFF)
+
+    def fill_from_engine_device(self, engine):
+        engine.export_directory_device(self.full.data_ptr(), self.capacity, self.full_count.data_ptr())
+        self._engine_stream = self.torch.cuda.ExternalStream(engine.stream(), device=self.device)
+        self._pending_full = True
+
+    def fill_from_numpy(self, blocks):
+        n = len(blocks)
+        if n > self.capacity:
+            raise OverflowError(f"block directory has {n} entries, exchange capacity is {self.capacity}")
+        raw = np.zeros(self.capacity * 3, dtype=np.int32)
+        raw[:n * 3] = np.ascontiguousarray(blocks).view(np.int32).reshape(-1)
+        self.full.copy_(self.torch.from_numpy(raw))
+        self.full_count.fill_(n)
+        self._engine_stream = None
+        self._pending_full = True
+
+    def _make_delta(self):
+        """send / count from (current export) minus (previous export)."""
+        torch = self.torch
+        n = int(self.full_count.item())
+        if n > self.capacity:
+            raise OverflowError(f"block directory has {n} entries, exchange capacity is {self.capacity}")
+        now = self.full[:n * 3].reshape(n, 3)
+        kn, kp = self._pos_key(now), self._pos_key(self._prev)
+        order = torch.argsort(kn)
+        now, kn = now[order], kn[order]
+        if len(kp):
+            at = torch.searchsorted(kp, kn).clamp_(max=len(kp) - 1)
+            same_pos = kp[at] == kn
+            unchanged = same_pos & (self._prev[at, 2] == now[:, 2]) & (self._prev[at, 1] == now[:, 1])
+            added = now[~unchanged]
+            at2 = torch.searchsorted(kn, kp).clamp_(max=max(len(kn) - 1, 0))
+            gone = self._prev[~(kn[at2] == kp)] if len(kn) else self._prev
+        else:
+            added, gone = now, self._prev
+        na, nd = len(added), len(gone)
+        if na + nd > self.capacity:
+            raise OverflowError(f"directory delta of {na} + {nd} entries, exchange capacity is {self.capacity}")
+        self.send.zero_()
+        self.send[:na * 3] = added.reshape(-1)
+        self.send[na * 3:(na + nd) * 3] = gone.reshape(-1)
+        self.count[0] = na
+        self.count[1] = nd
+        self._prev = now.clone()
+        self.last_sent = (na, nd)
+
+    def all_gather(self):
+        torch = self.torch
+        es = self._engine_stream
+        if es is not None:  # engine stream -> (event) -> torch's current stream
+            ev = torch.cuda.Event()
+            ev.record(es)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        self._make_delta()
+        if self.world == 1:
+            self.recv.copy_(self.send)
+            self.counts.copy_(self.count)
+        else:
+            self.dist.all_gather_into_tensor(self.recv, self.send)
+            self.dist.all_gather_into_tensor(self.counts, self.count)
+        if es is not None:  # the engine may not overwrite the export buffer before the delta was taken
+            ev2 = torch.cuda.Event()
+            ev2.record(torch.cuda.current_stream(self.device))
+            es.wait_event(ev2)
+        counts = self.counts.reshape(self.world, 2).cpu()
+        rows = self.recv.reshape(self.world, self.capacity, 3)
+        for r in range(self.world):
+            na, nd = int(counts[r, 0]), int(counts[r, 1])
+            rep = self._replica[r]
+            drop = torch.cat([rows[r, :na], rows[r, na:na + nd]])  # replaced and deleted positions
+            if len(rep) and len(drop):
+                rep = rep[~torch.isin(self._pos_key(rep), self._pos_key(drop))]
+            rep = torch.cat([rep, rows[r, :na]])
+            self._replica[r] = rep[torch.argsort(self._pos_key(rep))]
+
+    def result(self):
+        """List (one per rank) of structured BLOCK_DTYPE arrays, sorted by block position."""
+        return [np.ascontiguousarray(rep.cpu().numpy()).reshape(-1).view(BLOCK_DTYPE) for rep in self._replica]
 
 
 def blocks_in_bounds(blocks, bounds, voxel_size):

@@ -110,6 +110,29 @@ def test_export_directory_device(make_engine):
     assert np.array_equal(got, blocks)
 
 
+def test_directory_delta_exchange_on_the_device(make_engine):
+    """multi.DirectoryDeltaExchange fed by the engine on the device (the path bench.py --gpus N takes
+    with RCCL; here one rank): the replica built from deltas is the engine's directory at every step,
+    and after the first exchange only what changed is sent."""
+    import torch
+    from ratsdf import multi
+    vs = 0.02
+    gpu = make_engine(vs, 6 * vs)
+    dx = multi.DirectoryDeltaExchange(capacity=4096, device=torch.device("cuda", 0))
+    frames = synthetic.stream("room", 8, scale=0.25, noise=True)
+    by_pos = lambda b: b[np.lexsort((b["z"], b["y"], b["x"]))]
+    sent = []
+    for step in range(4):
+        for f in frames[2 * step:2 * step + 2]:
+            gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+        dx.fill_from_engine_device(gpu)
+        dx.all_gather()
+        _, blocks = gpu.dump_directory()
+        assert np.array_equal(by_pos(dx.result()[0]), by_pos(blocks)), step
+        sent.append((sum(dx.last_sent), len(blocks)))
+    assert sent[0][0] == sent[0][1] and all(0 < d < 0.7 * n for d, n in sent[1:]), sent
+
+
 def test_raycast_matches_oracle(make_engine, make_oracle):
     """TSDFGrid::RayCast / TSDFSystem::Render (voxel_tsdf.cu:278-374): rgba + normal images of a
     virtual view.  Voxel weights must reach 10 before a surface is rendered, so integrate enough

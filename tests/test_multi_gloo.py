@@ -102,6 +102,27 @@ def _worker(rank, world, port, mode, ret):
         else:
             counts = [len(b) for b in per_rank]
             assert counts[rank] == eng.num_active_blocks()
+            # The delta exchange: replicas built from deltas == the full directories, at
+            # every step of a map that keeps growing and carving; after the first (full) exchange only
+            # a fraction of the directory travels.
+            def by_pos(b):
+                return b[np.lexsort((b["z"], b["y"], b["x"]))]
+            dx = multi.DirectoryDeltaExchange(capacity=4096)
+            more = [synthetic.frame("room", 20 * rank + 4 + i, scale=0.25) for i in range(6)]
+            sent = []
+            for step in range(4):
+                _, mine = eng.dump_directory()
+                dx.fill_from_numpy(mine)
+                dx.all_gather()
+                ex.fill_from_numpy(mine)
+                ex.all_gather()
+                for got, want in zip(dx.result(), ex.result()):
+                    assert np.array_equal(by_pos(got), by_pos(want)), step
+                sent.append((sum(dx.last_sent), len(mine)))
+                for f in more[step:step + 2]:   # the map moves on between exchanges
+                    eng.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+            assert sent[0][0] == sent[0][1]                      # first exchange: everything is new
+            assert all(0 < d < 0.7 * n for d, n in sent[1:]), sent   # then only what changed
         dist.barrier()
         ret[rank] = "ok"
     finally:
