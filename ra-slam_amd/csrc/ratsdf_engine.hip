@@ -524,7 +524,8 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // 0 and 40 % are ~2.5 % slower: k_front is a chain of dependent round trips that a few riders do not
   // lengthen, the voxel update hides the rest); at 1280x720 all of it in k_front (best by 1-3 %, and
   // k_integrate stays the pure voxel update its roofline figure is about)
-  const int split = (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
+  // (k_integrate<1> runs 512-thread workgroups and hosts no look-ahead: everything in k_front then)
+  const int split = vpl == 1 ? 100 : (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
   const int split_b = (fused_serial && vpl != 1) ? 0 : (int)(cand_split_env ? cand_split_b : 0u);
   const Geom g = geometry(H, W, next != nullptr, split, split_b);
   // shares of the next frame's candidate pass: k_front, k_alloc_rank, k_integrate
@@ -1812,7 +1813,8 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
   const uint32_t n_serial_wg = fused ? 8u : 0u;
   const unsigned grid0 = e0->geometry(height, width, false, 0, 0).grid;
   const uint32_t commit_rot = fused ? e0->commit_rotation(grid0, grid0 * (unsigned)S) : 0u;
-  const ratsdf_engine::Geom g1 = e0->geometry(height, width, true, g->split_a, fused ? 0 : g->split_b);
+  const ratsdf_engine::Geom g1 = e0->geometry(height, width, true, e0->vpl == 1 ? 100 : g->split_a,
+                                              (fused || e0->vpl == 1) ? 0 : g->split_b);
   const ratsdf_engine::Geom g0 = e0->geometry(height, width, false, 0, 0);
   {  // nobody looked ahead for the first frame: its candidate pass runs in line
     AheadGeom all = g0.a;
