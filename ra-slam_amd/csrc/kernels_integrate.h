@@ -406,15 +406,97 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
 #endif
   WSTAMP(2);
   if (fresh) {  // AquireBlock initial values, voxel_mem.cu:43-51 (rgb stays as found)
+    // (materialised here: hoisted out of the block loop the two constants took registers the update
+    // needs, and were spilled to scratch memory instead of being re-created)
+    uint32_t minus_one = __float_as_uint(-1.f), half = __float_as_uint(.5f);
+    asm volatile("" : "+v"(minus_one), "+v"(half));
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
-      tv[j] = __float_as_uint(-1.f);
-      sv[j] = __float_as_uint(.5f);
+      tv[j] = minus_one;
+      sv[j] = half;
       cv[j] = (cv[j] & 0x00FFFFFFu) | 0x01000000u;
     }
   }
   uint32_t nupd = 0;
   const Recip rtrunc = make_recip(P.trunc);
+  if (VPL == 2 && !RATSDF_DBG(P, 14)) {
+    // The lane's two voxels side by side in 2-wide vectors: the same operations in the same order as
+    // the loop below (the results are bit-identical), but as packed FP32 instructions (v_pk_mul /
+    // v_pk_add / v_pk_fma_f32: two lanes of arithmetic per issue slot), which halves the instruction
+    // count of the blend -- the kernel is bound by VALU issue, not by bytes.  Both voxels are computed
+    // whenever either updates; what does not update is not stored.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    auto fma2 = [](v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); };
+    auto div2 = [&](v2f a, v2f d, v2f r1) {  // div_shared (device_math.h), two quotients at once
+      const v2f q0 = a * r1;
+      const v2f e2 = fma2(-d, q0, a);
+      const v2f q1 = fma2(e2, r1, q0);
+      const v2f e3 = fma2(-d, q1, a);
+      return fma2(e3, r1, q1);
+    };
+    const v2f d = {ta[0].x, ta[1].x};
+    const v2f sdf = v2f{ta[0].y, ta[1].y} * (d - v2f{phz[0], phz[1]});            // :216
+    bool upd[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)  // (colour-word test: see the loop below)
+      upd[j] = inb[j] && !(d[j] == 0 || d[j] > P.md) && sdf[j] > -P.trunc && tb[j] != 0xFFFFFFFFu;  // :211,217
+    if (upd[0] || upd[1]) {
+      v2f ts = div2(sdf, v2f{rtrunc.d, rtrunc.d}, v2f{rtrunc.r1, rtrunc.r1});    // :218
+      ts = v2f{fminf(1, ts[0]), fminf(1, ts[1])};
+      const v2f wn = {ta[0].w, ta[1].w};                                          // :226 (per pixel)
+      const uint32_t c0 = cv[0], c1 = cv[1];
+      const v2f wo = {(float)(c0 >> 24), (float)(c1 >> 24)};                      // :227
+      const v2f wc = wo + wn;                                                     // :228
+      const uint32_t n0 = tb[0], n1 = tb[1];
+      // make_recip(wc)
+      const v2f r0 = {__builtin_amdgcn_rcpf(wc[0]), __builtin_amdgcn_rcpf(wc[1])};
+      const v2f e = fma2(-wc, r0, v2f{1.f, 1.f});
+      const v2f r1 = fma2(e, r0, r0);
+      // one colour channel at a time, packed into the output words at once (short live ranges: the
+      // kernel has 64 VGPRs)
+      uint32_t o0 = 0, o1 = 0;
+      {
+        const v2f r_old = {(float)(c0 & 0xFFu), (float)(c1 & 0xFFu)};
+        const v2f r_new = {(float)(n0 & 0xFFu), (float)(n1 & 0xFFu)};
+        const v2f q = div2(r_old * wo + r_new * wn, wc, r1);                       // :234-235
+        o0 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[0]), 0, o0);            // :239-240
+        o1 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[1]), 0, o1);
+      }
+      {
+        const v2f g_old = {(float)((c0 >> 8) & 0xFFu), (float)((c1 >> 8) & 0xFFu)};
+        const v2f g_new = {(float)((n0 >> 8) & 0xFFu), (float)((n1 >> 8) & 0xFFu)};
+        const v2f q = div2(g_old * wo + g_new * wn, wc, r1);
+        o0 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[0]), 1, o0);
+        o1 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[1]), 1, o1);
+      }
+      {
+        const v2f b_old = {(float)((c0 >> 16) & 0xFFu), (float)((c1 >> 16) & 0xFFu)};
+        const v2f b_new = {(float)((n0 >> 16) & 0xFFu), (float)((n1 >> 16) & 0xFFu)};
+        const v2f q = div2(b_old * wo + b_new * wn, wc, r1);
+        o0 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[0]), 2, o0);
+        o1 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[1]), 2, o1);
+      }
+      o0 = __builtin_amdgcn_cvt_pk_u8_f32(fminf(round_nonneg(wc[0]), 40), 3, o0);  // :238
+      o1 = __builtin_amdgcn_cvt_pk_u8_f32(fminf(round_nonneg(wc[1]), 40), 3, o1);
+      const v2f t_old = {__uint_as_float(tv[0]), __uint_as_float(tv[1])};
+      const v2f t_new = div2(t_old * wo + ts * wn, wc, r1);                        // :236
+      const uint32_t ow[2] = {o0, o1};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (!upd[j]) continue;
+        tv[j] = __float_as_uint(t_new[j]);
+        cv[j] = ow[j];
+        // probability: see the loop below
+        const float pr = __uint_as_float(sv[j]);
+        const float odds = pr * __builtin_amdgcn_rcpf(1.f - pr);
+        const float L = __builtin_amdgcn_logf(odds) * 0.69314718f;
+        const float x = (wo[j] * L + wn[j] * ta[j].z) * r1[j];
+        const float ex = __builtin_amdgcn_exp2f(x * -1.44269504f);
+        sv[j] = __float_as_uint(__builtin_amdgcn_rcpf(1.f + ex));
+        ++nupd;
+      }
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
     const float d = ta[j].x;
@@ -466,6 +548,7 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
       }
       ++nupd;
     }
+  }
   }
   WSTAMP(3);
   if ((nupd || fresh) && !RATSDF_DBG(P, 5) && !RATSDF_DBG(P, 7)) {
@@ -525,6 +608,9 @@ __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, 
 }
 
 // threads per update workgroup (VPL >= 2): 256 = one voxel block per workgroup at VPL 2
+#ifndef RATSDF_INTEG_SGPR
+#define RATSDF_INTEG_SGPR 80
+#endif
 #ifndef RATSDF_INTEG_NT
 #define RATSDF_INTEG_NT 256
 #endif
@@ -554,7 +640,7 @@ struct IntegArgs {
 // candidate pass (`ahead`, kernels_cand.h): the update is bound by memory latency and leaves the
 // vector ALUs mostly idle, the candidate pass is ALU work on other inputs.
 template <int VPL>
-__global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
+__global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(RATSDF_INTEG_SGPR), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
     IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, uint32_t n_serial_wg, uint32_t n_ahead_wg,
     uint32_t commit_rot, CandJob ahead) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
