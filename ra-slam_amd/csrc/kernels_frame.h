@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_ca
 
 // voxel update of several engines (kernels_integrate.h: integrate_body)
 template <int VPL>
-__global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(RATSDF_INTEG_SGPR), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate_g(
+__global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate_g(
     EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_int_wg, uint32_t n_serial_wg, uint32_t n_ahead_wg,
     uint32_t commit_rot, AheadGeom ag) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];

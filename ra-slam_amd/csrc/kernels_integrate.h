@@ -608,9 +608,6 @@ __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, 
 }
 
 // threads per update workgroup (VPL >= 2): 256 = one voxel block per workgroup at VPL 2
-#ifndef RATSDF_INTEG_SGPR
-#define RATSDF_INTEG_SGPR 80
-#endif
 #ifndef RATSDF_INTEG_NT
 #define RATSDF_INTEG_NT 256
 #endif
@@ -640,7 +637,7 @@ struct IntegArgs {
 // candidate pass (`ahead`, kernels_cand.h): the update is bound by memory latency and leaves the
 // vector ALUs mostly idle, the candidate pass is ALU work on other inputs.
 template <int VPL>
-__global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(RATSDF_INTEG_SGPR), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
+__global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
     IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, uint32_t n_serial_wg, uint32_t n_ahead_wg,
     uint32_t commit_rot, CandJob ahead) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
