@@ -354,16 +354,70 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
   bool inb[VPL];
   V3 ph[VPL];
   bool fast = true;
+  if (VPL == 2 && !RATSDF_DBG(P, 14)) {
+    // The lane's two voxels differ in x only: quat_rotate / se3_apply / intr_mul (device_math.h)
+    // written out on 2-wide vectors, operation for operation (same association, no contraction), so
+    // that the pair goes through packed FP32 instructions without the shuffles of automatic
+    // vectorisation.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const Quat q = P.T.q;
+    const int gx0 = (int16_t)((int16_t)(item.x << 3) + tx0), gx1 = (int16_t)((int16_t)(item.x << 3) + tx0 + 1);
+    const v2f vx = v2f{(float)gx0, (float)gx1} * P.vs;                  // :183-187
+    // uv = 2 * cross(q.xyz, v)
+    float uvx = q.y * wz - q.z * wy;
+    v2f uvy = q.z * vx - q.x * wz;
+    v2f uvz = q.x * wy - q.y * vx;
+    uvx += uvx;
+    uvy += uvy;
+    uvz += uvz;
+    // c = cross(q.xyz, uv)
+    const v2f cx = q.y * uvz - q.z * uvy;
+    const v2f cy = q.z * uvx - q.x * uvz;
+    const v2f cz = q.x * uvy - q.y * uvx;
+    const v2f rx = (vx + q.w * uvx) + cx;
+    const v2f ry = (wy + q.w * uvy) + cy;
+    const v2f rz = (wz + q.w * uvz) + cz;
+    const v2f pcx = rx + P.T.t.x, pcy = ry + P.T.t.y, pcz = rz + P.T.t.z;  // :190
+    const v2f phx = P.K.fx * pcx + P.K.cx * pcz;                        // :193
+    const v2f phy = P.K.fy * pcy + P.K.cy * pcz;
+    fast = recip_safe(pcz[0]) && recip_safe(pcz[1]);
+    v2f qu, qv;
+    if (fast) {  // hnormalized(): see the loop below; make_recip + div_shared on the pair
+      auto fma2 = [](v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); };
+      const v2f r0 = {__builtin_amdgcn_rcpf(pcz[0]), __builtin_amdgcn_rcpf(pcz[1])};
+      const v2f r1 = fma2(fma2(-pcz, r0, v2f{1.f, 1.f}), r0, r0);
+      auto div2 = [&](v2f a) {
+        const v2f q0 = a * r1;
+        const v2f q1 = fma2(fma2(-pcz, q0, a), r1, q0);
+        return fma2(fma2(-pcz, q1, a), r1, q1);
+      };
+      qu = div2(phx);
+      qv = div2(phy);
+    } else {
+      qu = v2f{phx[0] / pcz[0], phx[1] / pcz[1]};
+      qv = v2f{phy[0] / pcz[0], phy[1] / pcz[1]};
+    }
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    const int gx = (int16_t)((int16_t)(item.x << 3) + tx0 + j);         // :183-184
-    const V3 pw{(float)gx * P.vs, wy, wz};                              // :187
-    const V3 pc3 = se3_apply(P.T, pw);                                  // :190
-    ph[j] = intr_mul(P.K, pc3);                                         // :193
-    fast = fast && recip_safe(ph[j].z);
+    for (int j = 0; j < 2; ++j) {
+      const int u = f2i(roundf(qu[j]));                                 // :196-199
+      const int w = f2i(roundf(qv[j]));                                 // :202
+      inb[j] = (uint32_t)u < (uint32_t)P.W && (uint32_t)w < (uint32_t)P.H;  // :205
+      const uint32_t k = (uint32_t)w * (uint32_t)P.W + (uint32_t)u;
+      kk[j] = inb[j] ? k : 0u;
+      phz[j] = pcz[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int gx = (int16_t)((int16_t)(item.x << 3) + tx0 + j);         // :183-184
+      const V3 pw{(float)gx * P.vs, wy, wz};                              // :187
+      const V3 pc3 = se3_apply(P.T, pw);                                  // :190
+      ph[j] = intr_mul(P.K, pc3);                                         // :193
+      fast = fast && recip_safe(ph[j].z);
+    }
   }
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) {
+  for (int j = 0; j < (VPL == 2 && !RATSDF_DBG(P, 14) ? 0 : VPL); ++j) {
     // hnormalized(): two quotients with the same divisor (shared-divisor form, device_math.h: the
     // correctly rounded quotient for |z| in (1e-18, 1e18) and |x / z| below the overflow threshold,
     // i.e. for every pose with coordinates below ~1e18 m); the plain IEEE divisions for a depth
