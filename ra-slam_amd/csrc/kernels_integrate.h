@@ -507,31 +507,42 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
       const v2f e = fma2(-wc, r0, v2f{1.f, 1.f});
       const v2f r1 = fma2(e, r0, r0);
       // one colour channel at a time, packed into the output words at once (short live ranges: the
-      // kernel has 64 VGPRs)
-      uint32_t o0 = 0, o1 = 0;
+      // kernel has 64 VGPRs).  roundf of a non-negative float = v_cvt_rpi_i32_f32 (floor(x + 0.5),
+      // evaluated exactly by the hardware: equal to roundf for every non-negative float, checked
+      // exhaustively by tools/probes/round_probe.hip); quotients and the weight are non-negative and
+      // at most 255 / 44, never NaN (wc >= 1).
+      auto rpi = [](float x) {
+        int r;
+        asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+        return (uint32_t)r;
+      };
+      uint32_t o0, o1;
       {
         const v2f r_old = {(float)(c0 & 0xFFu), (float)(c1 & 0xFFu)};
         const v2f r_new = {(float)(n0 & 0xFFu), (float)(n1 & 0xFFu)};
         const v2f q = div2(r_old * wo + r_new * wn, wc, r1);                       // :234-235
-        o0 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[0]), 0, o0);            // :239-240
-        o1 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[1]), 0, o1);
+        o0 = rpi(q[0]);                                                            // :239-240
+        o1 = rpi(q[1]);
       }
       {
         const v2f g_old = {(float)((c0 >> 8) & 0xFFu), (float)((c1 >> 8) & 0xFFu)};
         const v2f g_new = {(float)((n0 >> 8) & 0xFFu), (float)((n1 >> 8) & 0xFFu)};
         const v2f q = div2(g_old * wo + g_new * wn, wc, r1);
-        o0 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[0]), 1, o0);
-        o1 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[1]), 1, o1);
+        o0 |= rpi(q[0]) << 8;
+        o1 |= rpi(q[1]) << 8;
       }
       {
         const v2f b_old = {(float)((c0 >> 16) & 0xFFu), (float)((c1 >> 16) & 0xFFu)};
         const v2f b_new = {(float)((n0 >> 16) & 0xFFu), (float)((n1 >> 16) & 0xFFu)};
         const v2f q = div2(b_old * wo + b_new * wn, wc, r1);
-        o0 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[0]), 2, o0);
-        o1 = __builtin_amdgcn_cvt_pk_u8_f32(round_nonneg(q[1]), 2, o1);
+        o0 |= rpi(q[0]) << 16;
+        o1 |= rpi(q[1]) << 16;
       }
-      o0 = __builtin_amdgcn_cvt_pk_u8_f32(fminf(round_nonneg(wc[0]), 40), 3, o0);  // :238
-      o1 = __builtin_amdgcn_cvt_pk_u8_f32(fminf(round_nonneg(wc[1]), 40), 3, o1);
+      {
+        const uint32_t w0 = rpi(wc[0]), w1 = rpi(wc[1]);                           // :238
+        o0 |= (w0 < 40u ? w0 : 40u) << 24;
+        o1 |= (w1 < 40u ? w1 : 40u) << 24;
+      }
       const v2f t_old = {__uint_as_float(tv[0]), __uint_as_float(tv[1])};
       const v2f t_new = div2(t_old * wo + ts * wn, wc, r1);                        // :236
       const uint32_t ow[2] = {o0, o1};
