@@ -219,9 +219,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
 
   const bool fast = (!pend || nd + ns <= kSmallCarve) && n <= kSmallRank;
   if (__builtin_expect(!fast, 0)) {  // uniform: the general functions, scratch in device memory
-#ifndef RATSDF_FAST_ONLY  // (a measurement build: what the general paths' presence costs the kernel)
     serial_general(E, par, nwords, nf0, true);
-#endif
     return 2u;
   }
 
