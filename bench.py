@@ -5,18 +5,27 @@
 
 A step = one batch of `--frames-per-step` synthetic 640x480 frames (depth + rgb + ht/lt, 5 mm voxels,
 truncation 30 mm, max depth 4 m, ScanNet intrinsics; the "room" stream of ratsdf.synthetic)
-integrated through the C ABI (ratsdf_integrate_device) with every input already resident in HBM.
-For N > 1 the driver launches one process per GPU with torch.distributed.run; each rank integrates
-its own stream into its own map (frame-batched config of BASELINE.json) and the ranks all-gather
-their block directories over RCCL once per step.  Rank 0 prints ONE JSON line.
+integrated through the C ABI (ratsdf_integrate_device_batch) with every input already resident in
+HBM; `--reps` timed repetitions of K steps each, `value` = the median.  For N > 1 the driver launches
+one process per GPU with torch.distributed.run; each rank integrates its own stream into its own map
+(frame-batched config of BASELINE.json) and the ranks all-gather the deltas of their block directories
+over RCCL once per step (ratsdf.multi.DirectoryDeltaExchange).  Rank 0 prints ONE JSON line.
 
 The line also carries
   roofline      HBM roofline of the dominant kernel (k_integrate): algorithmic bytes per launch
                 (15 W H + 12 V + 24 U) / its average duration measured with HIP events
-                on the engine's stream inside the timed region
+                attached to the dispatch on the engine's stream inside the timed region; `traffic` from
+                the committed PMC passes (`traffic_source`); `launch_also_hosts` = what else rides in
+                that launch; `frame_frac` = the whole frame against the same peak
   cpu_baseline  the CPU oracle (multithreaded port; the reference has no CPU path) timed on this
                 box's host cores on a bounded prefix of the same stream (rank 0, N = 1 only), after
                 asserting that it and the HIP engine produce the same map on that prefix
+  secondary     1280x720 / 2 mm / L515 intrinsics (north_star's second stream size), bounded, with its
+                own roofline block and parity check
+  multi_stream  S streams of this GPU through one launch pair per frame step (ratsdf_group_*);
+                `value` stays the single-stream number
+  host_image_path / pinned_h2d_path   the PCIe-inclusive entry points (never `value`)
+`--config hd2mm | bigmap` run the 1280x720 / 2 mm workload (on a 416 MB map for bigmap) as the main line.
 """
 import argparse
 import json
