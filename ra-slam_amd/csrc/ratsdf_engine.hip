@@ -158,7 +158,8 @@ struct ratsdf_engine {
   uint8_t* d_stage = nullptr;
   hipEvent_t stage_ev[8] = {};  // upload of the slot's last user has been executed
   hipEvent_t use_ev[9] = {};    // the frame that read the slot has been executed (+1: call fence)
-  hipStream_t copy_stream = nullptr;  // uploads of ratsdf_integrate_batch
+  hipStream_t copy_stream = nullptr;   // uploads of ratsdf_integrate_batch: even frames
+  hipStream_t copy_stream2 = nullptr;  // ... odd frames (two copy engines: one sustains ~31 GB/s)
 
   // profiling of the dominant kernel
   bool profiling = false;
@@ -231,11 +232,13 @@ int ratsdf_engine::free_all() {
   if (dl_dev) (void)hipFree(dl_dev);
   if (dl_host) (void)hipHostFree(dl_host);
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+  if (copy_stream2) (void)hipStreamSynchronize(copy_stream2);
   for (auto& ev : stage_ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : use_ev)
     if (ev) (void)hipEventDestroy(ev);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  if (copy_stream2) (void)hipStreamDestroy(copy_stream2);
   for (auto& ev : prof_events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -357,6 +360,7 @@ int ratsdf_engine::ensure_stage(size_t npix) {
   for (int i = 0; i <= kStageSlots; ++i)
     if (!use_ev[i]) HIPCHK(hipEventCreateWithFlags(&use_ev[i], hipEventDisableTiming));
   if (!copy_stream) HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  if (!copy_stream2) HIPCHK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
   stage_pix = npix;
   return RATSDF_OK;
 }
@@ -882,17 +886,19 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
   // the PCIe copy of later frames overlaps the integration of earlier ones (one stream would
   // serialise them).  Per device slot: up_ev = its upload has been executed, use_ev = the frame that
   // read it has been executed.  Layout of a slot: depth | ht | lt | rgb.
+  static const bool two_streams = !(getenv("RATSDF_COPY_STREAMS") && atoi(getenv("RATSDF_COPY_STREAMS")) == 1);
   auto upload = [&](int i) -> int {
     const int slot = i % kStageSlots;
+    hipStream_t cs = ((i & 1) && two_streams) ? e->copy_stream2 : e->copy_stream;
     uint8_t* d = e->d_stage + (size_t)slot * slot_bytes;
-    if (i >= kStageSlots) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->use_ev[slot], 0));
+    if (i >= kStageSlots) HIPCHK(hipStreamWaitEvent(cs, e->use_ev[slot], 0));
     if (pinned) {  // straight from the caller's page-locked buffers
-      HIPCHK(hipMemcpyAsync(d, depth[i], npix * 4, hipMemcpyHostToDevice, e->copy_stream));
+      HIPCHK(hipMemcpyAsync(d, depth[i], npix * 4, hipMemcpyHostToDevice, cs));
       if (sem(i)) {
-        HIPCHK(hipMemcpyAsync(d + npix * 4, ht[i], npix * 4, hipMemcpyHostToDevice, e->copy_stream));
-        HIPCHK(hipMemcpyAsync(d + npix * 8, lt[i], npix * 4, hipMemcpyHostToDevice, e->copy_stream));
+        HIPCHK(hipMemcpyAsync(d + npix * 4, ht[i], npix * 4, hipMemcpyHostToDevice, cs));
+        HIPCHK(hipMemcpyAsync(d + npix * 8, lt[i], npix * 4, hipMemcpyHostToDevice, cs));
       }
-      HIPCHK(hipMemcpyAsync(d + npix * 12, rgb[i], npix * 3, hipMemcpyHostToDevice, e->copy_stream));
+      HIPCHK(hipMemcpyAsync(d + npix * 12, rgb[i], npix * 3, hipMemcpyHostToDevice, cs));
     } else {
       uint8_t* h = e->h_stage + (size_t)slot * slot_bytes;
       if (i >= kStageSlots) HIPCHK(hipEventSynchronize(e->stage_ev[slot]));  // its last upload is done
@@ -902,9 +908,9 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
         memcpy(h + npix * 8, lt[i], npix * 4);
       }
       memcpy(h + npix * 12, rgb[i], npix * 3);
-      HIPCHK(hipMemcpyAsync(d, h, slot_bytes, hipMemcpyHostToDevice, e->copy_stream));
+      HIPCHK(hipMemcpyAsync(d, h, slot_bytes, hipMemcpyHostToDevice, cs));
     }
-    HIPCHK(hipEventRecord(e->stage_ev[slot], e->copy_stream));
+    HIPCHK(hipEventRecord(e->stage_ev[slot], cs));
     return RATSDF_OK;
   };
   auto input = [&](int i) {
@@ -915,6 +921,7 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
   // whatever happens, the caller's buffers (and the staging slots) are no longer in use on return
   auto fail = [&](int status) {
     (void)hipStreamSynchronize(e->copy_stream);
+    (void)hipStreamSynchronize(e->copy_stream2);
     e->abandon_pipeline();
     return status;
   };
@@ -922,6 +929,7 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
   // synchronisation), and nothing earlier on the engine's stream may be overtaken by the uploads
   HIPCHK(hipEventRecord(e->use_ev[kStageSlots], e->stream));
   HIPCHK(hipStreamWaitEvent(e->copy_stream, e->use_ev[kStageSlots], 0));
+  HIPCHK(hipStreamWaitEvent(e->copy_stream2, e->use_ev[kStageSlots], 0));
   const int ahead = kStageSlots - 1;  // uploads enqueued ahead of the frame being launched
   int uploaded = 0;
   for (int i = 0; i < n; ++i) {
