@@ -120,6 +120,30 @@ def test_serial_role_as_a_launch_of_its_own(kw, monkeypatch, make_engine, make_o
     check_totals(gpu, cpu)
 
 
+def test_large_map_in_the_default_directory(make_engine, make_oracle):
+    """1.25 mm voxels at 640x480: ~22 k blocks in the DEFAULT 2^21-bucket
+    directory.  The first frame has far more than 2048 allocation requests (the serial role's general
+    paths inside k_integrate, scratch in device memory); from then on a map of this size has full
+    buckets, so later frames file chained-bucket requests (resolver with LDS keys, then the ordinary
+    frame; voxel update running beside it) -- the regime of bench.py --config bigmap."""
+    vs, md = 0.00125, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+    frames = synthetic.stream("room", 6, noise=True, holes=True)
+    dev = device_frames(frames)
+    slow_seen = 0
+    lo = 0
+    for n in (1, 5):
+        gpu.integrate_device_batch(make_batch(gpu, frames, dev, lo, lo + n, md))
+        for f in frames[lo:lo + n]:
+            cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+            slow_seen += cpu.last_frame_stats()["slow_requests"]
+        lo += n
+        assert_maps_equal(gpu, cpu)
+        assert_stats_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+    assert cpu.num_active_blocks() > 20000 and slow_seen > 100, (cpu.num_active_blocks(), slow_seen)
+
+
 def test_no_semantics_batch(make_engine, make_oracle):
     vs, md = 0.02, 4.0
     gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
