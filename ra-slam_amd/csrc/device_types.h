@@ -52,6 +52,9 @@ struct SlowDelete {
   int32_t freed;   // pool index released
 };
 
+// what carve_resolve_gate (kernels_carve.h) tells a directory reader
+enum GateResult : uint32_t { kGateOpen = 0, kGateWaited = 1, kGateExpired = 2 };
+
 // one successful or pending simple delete of the carve pass: where the block sat, what it held
 struct DelItem {
   uint32_t entry;

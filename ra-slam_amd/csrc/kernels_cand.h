@@ -332,7 +332,7 @@ __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P,
   const uint32_t i0 = part * blockDim.x + threadIdx.x;
   uint4 item = list[i0 < cs.seg_cap ? i0 : 0];
   uint32_t n = cs.count[seg * kCandCountStride];
-  (void)gate();
+  if (gate() == kGateExpired) return;  // uniform: the directory may be half-edited (sticky error set)
   if (n > cs.seg_cap) n = cs.seg_cap;
   for (uint32_t base = part * blockDim.x; base < n; base += stride) {  // uniform
     const uint32_t i = base + threadIdx.x;

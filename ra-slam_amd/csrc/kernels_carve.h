@@ -44,6 +44,11 @@ __device__ inline void occ_clear(const Table& tab, uint32_t e) {
 __device__ inline uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// write-through store (global_store ... sc1): leaves this XCD's L2 at once, so a reader on any CU that
+// has not cached the line sees it after the storing wave's s_waitcnt vmcnt(0)
+__device__ inline void st_agent(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // A block whose min |tsdf| >= 0.9 after the update (voxel_tsdf.cu:253-276).  One thread.
 __device__ inline void carve_candidate(const Table& tab, const CarveBufs& cb, Ctl* ctl, FrameCtl* F,
@@ -84,23 +89,29 @@ __device__ inline void carve_candidate(const Table& tab, const CarveBufs& cb, Ct
 
 // Head / chain deletes.  All threads of one workgroup; every claim of the pass has been placed (the
 // kernel that placed them has finished).
+// Everything this function stores is read by OTHER workgroups of the same launch once the gate below
+// has let them through (directory entries, carve claims, the state of the queued items), so every store
+// is an agent-scope (write-through) store: the hand-off then needs no cache maintenance at all
+// (carve_resolve_gate).  Its own loads are plain: what it reads was written by earlier launches.
 __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb, Ctl* ctl, FrameCtl* F) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   SlowDelete* slow = cb.slow;
   uint32_t ns = F->n_slow_del;
   if (ns > cb.slow_cap) ns = cb.slow_cap;
-  // decide every winner before any claim is released (the state is parked in the item itself and
-  // re-read by the same thread)
+  // decide every winner before any claim is released (the decision is parked in the item itself --
+  // word 1 = z | state << 16 -- written and re-read past the caches by the same thread)
   for (uint32_t j = tid; j < ns; j += nt) {
     const SlowDelete s = slow[j];
     const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
-    slow[j].state = (ld_agent(&tab.dclaim[bucket]) == s.entry) ? 1 : 0;
+    const uint32_t win = ld_agent(&tab.dclaim[bucket]) == s.entry ? 1u : 0u;
+    st_agent(reinterpret_cast<uint32_t*>(&slow[j]) + 1, (uint32_t)(uint16_t)s.z | (win << 16));
   }
   __syncthreads();
   for (uint32_t j = tid; j < ns; j += nt) {
-    const SlowDelete s = slow[j];
+    SlowDelete s = slow[j];
+    s.state = (uint16_t)(ld_agent(reinterpret_cast<const uint32_t*>(&slow[j]) + 1) >> 16);
     const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
-    tab.dclaim[bucket] = kInf;  // ResetLocks
+    st_agent(&tab.dclaim[bucket], kInf);  // ResetLocks
     if (!s.state) continue;
     const uint32_t k0 = key0(s.x, s.y), k1 = key1(s.z);
     uint32_t last = (bucket << 1) + 1;
@@ -114,11 +125,15 @@ __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb,
       freed = h.idx;
       const int noff = entry_offset(nw);
       const int16_t hoff = noff ? (int16_t)(entry_offset(h) + noff) : (int16_t)0;
-      ph[0] = nw.w0;
-      ph[1] = (nw.w1 & 0xFFFFu) | ((uint32_t)(uint16_t)hoff << 16);
-      ph[2] = (uint32_t)nw.idx;
-      pn[1] = pn[1] & 0xFFFFu;
-      pn[2] = (uint32_t)-1;
+      // (a head that is its own successor -- empty chain -- is just cleared: in the reference the copy
+      // onto itself is followed by the clear of the same entry)
+      if (nxt != last) {
+        st_agent(ph + 0, nw.w0);
+        st_agent(ph + 1, (nw.w1 & 0xFFFFu) | ((uint32_t)(uint16_t)hoff << 16));
+        st_agent(ph + 2, (uint32_t)nw.idx);
+      }
+      st_agent(pn + 1, nw.w1 & 0xFFFFu);
+      st_agent(pn + 2, (uint32_t)-1);
       occ_clear(tab, nxt);  // the head keeps its bit unless it was its own successor
     } else {                                                            // voxel_hash.cu:142-158
       for (uint32_t g = 0; g < tab.num_entry; ++g) {
@@ -132,57 +147,91 @@ __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb,
           const int16_t link = coff ? (int16_t)(loff + coff) : (int16_t)0;
           uint32_t* pl = reinterpret_cast<uint32_t*>(tab.entries + last);
           uint32_t* pcur = reinterpret_cast<uint32_t*>(tab.entries + cur);
-          pl[1] = (pl[1] & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16);
+          st_agent(pl + 1, (lw.w1 & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16));
           freed = cw.idx;
-          pcur[1] = pcur[1] & 0xFFFFu;
-          pcur[2] = (uint32_t)-1;
+          st_agent(pcur + 1, cw.w1 & 0xFFFFu);
+          st_agent(pcur + 2, (uint32_t)-1);
           occ_clear(tab, cur);
           break;
         }
         last = cur;
       }
     }
-    if (freed >= 0) {
-      slow[j].state = 2;
-      slow[j].freed = freed;
+    if (freed >= 0) {  // word 1 of the item = z | state << 16
+      st_agent(reinterpret_cast<uint32_t*>(&slow[j]) + 3, (uint32_t)freed);
+      st_agent(reinterpret_cast<uint32_t*>(&slow[j]) + 1, (uint32_t)(uint16_t)s.z | (2u << 16));
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the barrier
   __syncthreads();
-  if (tid == 0) F->slow_resolved = 1;
+  if (tid == 0) st_agent(&F->slow_resolved, 1u);
 }
 
 // Directory readers of the next launch: make sure the queued head / chain deletes of the previous
-// frame have happened.  Workgroup 0 of the launch does them; the others wait for its flag.  The wait
-// relies on nothing HIP promises (waiters all have a higher index than workgroup 0, which the
-// dispatcher has so far always started first), so it is BOUNDED: after kGateTimeoutTicks of the
-// 100 MHz wall clock the waiter gives up, records RATSDF_ERR_TIMEOUT and goes on -- an error the
-// caller sees at the next synchronisation, never a hung GPU.  Uniform per workgroup.
-// Returns true when there was something to wait for (data read before the call may be stale then).
-constexpr unsigned long long kGateTimeoutTicks = 200000;  // 2 ms; the resolver takes microseconds
-__device__ inline bool carve_resolve_gate(const Table& tab, const CarveBufs& cb, Ctl* ctl,
-                                          FrameCtl* Fprev) {
-  if (Fprev->n_slow_del == 0) return false;  // the steady state
+// frame have happened.  Workgroup 0 of the launch does them; the others wait for its flag.
+//
+// The hand-off uses NO cache maintenance (until round 2: __threadfence() + release store in workgroup
+// 0 and an agent-scope acquire fence in every waiting workgroup; in frames with queued deletes -- 60 %
+// of the frames of a 68 k-block map -- that cost the launch a constant +38 us: the release wrote back
+// the L2 of workgroup 0's XCD, which the look-ahead candidate workgroups of the same launch keep
+// filling with dirty texel lines, and ~500 workgroups invalidated the L1 of CUs they share with
+// those).  Instead:
+//   writer   every store of carve_resolve_slow is an agent-scope (sc1, write-through) store; every
+//            storing wave drains (s_waitcnt vmcnt(0)), the workgroup's barrier, then thread 0 stores
+//            the flag the same way;
+//   readers  poll the flag with relaxed agent-scope loads (one lane; an acquire per poll would flush
+//            the CU's L1 each time), then a workgroup barrier, then PLAIN loads.  That is sound because
+//            no workgroup of this launch loads a line of the directory (entries, claims, queued
+//            items) before it has passed the gate -- L1 and L2 start the launch invalidated and the
+//            write-through stores leave no stale copy in the writer's L2 -- with two exceptions: the
+//            occupancy words visible_append_role requests before the gate, which it therefore loads
+//            again at agent scope (atomics on them happen at the memory side), and the lines the
+//            resolver itself loaded on workgroup 0's CU, which that workgroup invalidates (its own
+//            L1 only) before it publishes the flag.
+// The wait relies on nothing HIP promises (waiters all have a higher index than workgroup 0, which the
+// dispatcher has so far always started first), so it is BOUNDED, like the serial role's: after
+// kGateTimeoutTicks of the 100 MHz wall clock the waiter gives up and records RATSDF_ERR_TIMEOUT --
+// an error the caller sees at the next synchronisation, never a hung GPU.  The bound is a safety net,
+// not a deadline (the resolver takes microseconds; 65 536 queued chain deletes with every chain walk
+// missing the caches, on a device shared with other queues or serialised under a profiler, stay far
+// below it).  Uniform per workgroup.
+// Returns kGateOpen (nothing was queued), kGateWaited (data requested before the call may be stale)
+// or kGateExpired: the caller must NOT read the directory -- it may be half-edited -- and skips its
+// work; the frame is then incomplete, which the sticky error reports.
+constexpr unsigned long long kGateTimeoutTicks = 200000000;  // 2 s, as kSerialWaitTicks
+__device__ inline GateResult carve_resolve_gate(const Table& tab, const CarveBufs& cb, Ctl* ctl,
+                                                FrameCtl* Fprev, bool withhold = false) {
+  if (Fprev->n_slow_del == 0) return kGateOpen;  // the steady state
+  __shared__ uint32_t gate_state;
   if (blockIdx.x == 0) {
     if (ld_agent(&Fprev->slow_resolved) == 0) carve_resolve_slow(tab, cb, ctl, Fprev);  // uniform
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0)
-      __hip_atomic_store(&Fprev->slow_resolved, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    if (threadIdx.x == 0) {  // relaxed polling (an acquire per poll would flush this CU's L1 each time)
-      const unsigned long long t0 = (unsigned long long)wall_clock64();
-      while (ld_agent(&Fprev->slow_resolved) != 2u) {
-        if ((unsigned long long)wall_clock64() - t0 > kGateTimeoutTicks) {
-          set_error(ctl, RATSDF_ERR_TIMEOUT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(16);
-      }
+    // (carve_resolve_slow ends with every wave drained and a barrier.)  The resolver's own PLAIN loads
+    // have left lines in THIS CU's L1 that its write-through stores then changed underneath: one
+    // invalidate of this L1 (buffer_inv sc1, no write-back) BEFORE the flag goes out, so that neither
+    // this workgroup nor a waiting workgroup resident on the same CU can hit them afterwards.
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!withhold) st_agent(&Fprev->slow_resolved, 2u);
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return kGateWaited;
   }
-  return true;
+  if (threadIdx.x == 0) {
+    uint32_t st = kGateWaited;
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    while (ld_agent(&Fprev->slow_resolved) != 2u) {
+      if ((unsigned long long)wall_clock64() - t0 > kGateTimeoutTicks) {
+        set_error(ctl, RATSDF_ERR_TIMEOUT);
+        st = kGateExpired;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    gate_state = st;
+  }
+  __syncthreads();
+  return (GateResult)gate_state;
 }
 
 // Pool releases of a finished frame with few deletes (the steady state), spread over kReleaseWGs

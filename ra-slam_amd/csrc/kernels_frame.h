@@ -87,7 +87,7 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
   auto gate = [&]() { return carve_resolve_gate(tab, cb, ctl, Fp); };  // uniform per workgroup
   if (blockIdx.x >= n_vis_wg + n_cons_wg) {
     if (RATSDF_DBG(P, 12)) return;  // diagnostic ablations 3 / 11 / 12: skip one role
-    (void)gate();
+    if (gate() == kGateExpired) return;  // uniform
     carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - n_cons_wg, role_lds);
   } else if (blockIdx.x >= n_vis_wg) {
     if (RATSDF_DBG(P, 11)) return;

@@ -102,9 +102,6 @@ constexpr uint32_t kFusedSlowCap = 512;  // chained-bucket requests resolved wit
 // requests sorted in device memory by 256 threads) takes tens of milliseconds.
 constexpr unsigned long long kSerialWaitTicks = 200000000;  // 2 s of the 100 MHz wall clock
 
-__device__ inline void st_agent(uint32_t* p, uint32_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ inline Request ld_agent_request(const Request* p) {
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
   unsigned long long w[2];

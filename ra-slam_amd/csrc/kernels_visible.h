@@ -93,7 +93,9 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
   const uint32_t w = wg * kVisWG + threadIdx.x;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   unsigned long long occ = w < nwords ? tab.occ[w] : 0ull;
-  if (gate())  // rare: the directory changed after the load above was issued
+  const uint32_t g = gate();
+  if (g == kGateExpired) return;  // uniform: the directory may be half-edited (sticky error set)
+  if (g != kGateOpen)  // rare: the directory changed after the load above was issued
     occ = w < nwords ? __hip_atomic_load(&tab.occ[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
   for (;;) {  // one round unless the workgroup's 16 384 entries hold more than kVisListCap blocks
     if (tid < kNumLists) {

@@ -53,8 +53,9 @@ struct RgbImage {
   int width = 0, height = 0;
   std::vector<uint8_t> data;
 };
-// Baseline / extended-sequential Huffman JPEG (jpeg.cc): output identical to the IJG library's default
-// decoding path (accurate integer IDCT, fancy upsampling).  Throws std::runtime_error naming `name`.
+// Baseline / extended-sequential Huffman JPEG (jpeg.cc): output identical, byte for byte, to what the
+// reference's loader produces (third_party/scannet/stb_image/stb_image.h via RGBDFrame.cc:56-63: its
+// IDCT, its chroma filters, its fixed-point colour conversion).  Throws std::runtime_error naming `name`.
 RgbImage decode_jpeg(const uint8_t* data, size_t size, const std::string& name);
 // cv::resize(src CV_8UC3, dst, cv::Size(out_w, out_h)) with its default INTER_LINEAR, as OpenCV
 // evaluates it for 8-bit images (11-bit fixed-point coefficients; see oracle/segmentation_oracle.py)
@@ -130,6 +131,8 @@ class scannet_sens_reader : public offline_data_provider {
   int color_height() const { return (int)color_h_; }
   int depth_width() const { return (int)depth_w_; }
   int depth_height() const { return (int)depth_h_; }
+  // the colour frame as decompressColorAlloc returns it (sensorData.hpp:170-176), before cv::resize
+  RgbImage decode_color_full(int frame_idx) const;
 
  private:
   struct FrameRec {

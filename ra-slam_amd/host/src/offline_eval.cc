@@ -14,7 +14,9 @@
 //
 // usage: ratsdf_offline_eval <folder> [--lib libratsdf.so] [--voxel 0.01]
 //          [--max-depth 6] [--device 0] [--frames N] [--download-all FILE] [--download-mesh PREFIX]
-//          [--reader-only] [--dump-frames DIR] [--threads N (decoder threads, default 4)]
+//          [--reader-only] [--dump-frames DIR] [--dump-raw-color (.sens: also DIR/<i>.color, the colour
+//          frame before the resize, and DIR/raw_meta.txt = its width and height)]
+//          [--threads N (decoder threads, default 4)]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -49,7 +51,7 @@ int main(int argc, char** argv) {
   float voxel_size = 0.01f, max_depth = 6.f;  // offline_eval.cc:49-53
   int device = 0, max_frames = -1, threads = 4;
   std::string download_all, download_mesh, dump_dir;
-  bool reader_only = false;
+  bool reader_only = false, dump_raw_color = false;
   for (int i = 2; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&]() -> const char* {
@@ -69,6 +71,7 @@ int main(int argc, char** argv) {
     else if (a == "--download-mesh") download_mesh = next();
     else if (a == "--dump-frames") dump_dir = next();
     else if (a == "--reader-only") reader_only = true;
+    else if (a == "--dump-raw-color") dump_raw_color = true;
     else {
       fprintf(stderr, "unknown option %s\n", a.c_str());
       return 2;
@@ -92,6 +95,14 @@ int main(int argc, char** argv) {
            << K.cx << " " << K.cy << " " << reader.get_depth_map_factor() << "\n"
            << e.qx << " " << e.qy << " " << e.qz << " " << e.qw << " " << e.tx << " " << e.ty << " " << e.tz
            << "\n";
+    }
+    if (dump_raw_color && is_sens && !dump_dir.empty()) {
+      const auto& sr = static_cast<const scannet_sens_reader&>(reader);
+      std::ofstream(dump_dir + "/raw_meta.txt") << sr.color_width() << " " << sr.color_height() << "\n";
+      for (int i = 0; i < n; ++i) {
+        const RgbImage full = sr.decode_color_full(i);
+        write_file(dump_dir + "/" + std::to_string(i) + ".color", full.data.data(), full.data.size());
+      }
     }
     std::unique_ptr<TSDFSystem> tsdf;
     if (!reader_only)

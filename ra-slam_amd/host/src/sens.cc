@@ -82,8 +82,8 @@ scannet_sens_reader::scannet_sens_reader(const std::string& sens_filepath) : pat
   in.read(reinterpret_cast<char*>(file_.data()), len);
   if (!in) throw std::runtime_error(sens_filepath + ": read error");
   size_t p = 0;
-  auto need = [&](size_t n) {
-    if (p + n > file_.size()) throw std::runtime_error(path_ + ": truncated .sens stream");
+  auto need = [&](uint64_t n) {  // p <= size always; lengths come from 64-bit fields of the file
+    if (n > (uint64_t)(file_.size() - p)) throw std::runtime_error(path_ + ": truncated .sens stream");
   };
   auto rd = [&](void* dst, size_t n) {
     need(n);
@@ -96,7 +96,7 @@ scannet_sens_reader::scannet_sens_reader(const std::string& sens_filepath) : pat
     throw std::runtime_error(path_ + ": invalid file version -- found " + std::to_string(version) + " but expected 4");
   uint64_t name_len = 0;
   rd(&name_len, 8);
-  need((size_t)name_len);
+  need(name_len);
   p += (size_t)name_len;  // m_sensorName
   rd(color_intr_, 64);
   rd(color_extr_, 64);
@@ -120,11 +120,11 @@ scannet_sens_reader::scannet_sens_reader(const std::string& sens_filepath) : pat
     rd(&ts_depth, 8);
     rd(&csize, 8);
     rd(&dsize, 8);
-    need((size_t)csize);
+    need(csize);
     f.color_off = p;
     f.color_size = (size_t)csize;
     p += (size_t)csize;
-    need((size_t)dsize);
+    need(dsize);
     f.depth_off = p;
     f.depth_size = (size_t)dsize;
     p += (size_t)dsize;
@@ -165,7 +165,7 @@ void scannet_sens_reader::get_depth_frame_by_id(PngImage* out, int frame_idx) co
   }
 }
 
-void scannet_sens_reader::get_color_frame_by_id(PngImage* out, int frame_idx) const {  // :55-66
+RgbImage scannet_sens_reader::decode_color_full(int frame_idx) const {  // :56 decompressColorAlloc
   const FrameRec& f = frames_.at((size_t)frame_idx);
   RgbImage full;
   if (color_type_ == kColorJpeg) {
@@ -180,6 +180,11 @@ void scannet_sens_reader::get_color_frame_by_id(PngImage* out, int frame_idx) co
   } else {
     throw std::runtime_error(path_ + ": unsupported colour compression type " + std::to_string(color_type_));
   }
+  return full;
+}
+
+void scannet_sens_reader::get_color_frame_by_id(PngImage* out, int frame_idx) const {  // :55-66
+  const RgbImage full = decode_color_full(frame_idx);
   const RgbImage small = (full.width == get_width() && full.height == get_height())
                              ? full
                              : resize_rgb_linear(full, get_width(), get_height());  // :62

@@ -49,15 +49,14 @@ def test_offline_eval_on_hip_engine(tmp_path, make_oracle):
 
 def test_offline_eval_on_a_sens_stream(tmp_path, make_oracle):
     """A ScanNet .sens stream (committed fixture tests/golden/tiny.sens) through the harness on the HIP
-    engine == the CPU oracle fed with the frames as Python decodes them (PIL JPEG + numpy resize)."""
-    import io
+    engine == the CPU oracle fed with the frames as the REFERENCE's loader decodes them
+    (tests/golden/tiny_sens_ref.npz: stb_image colour, made by make_sens_ref_golden.py) + numpy resize."""
     import make_sens as M
     import segmentation_oracle as S
-    from PIL import Image
     from ratsdf import pose as P
     from test_dataset_reader import build
     frames = M.synthetic_frames(3, color_hw=(97, 130))          # what tiny.sens was written from
-    kw = dict(quality=85, subsampling="4:2:0")
+    ref = np.load(ROOT / "tests" / "golden" / "tiny_sens_ref.npz")
     out = tmp_path / "map.bin"
     lib = ROOT / "ra-slam_amd" / "csrc" / "build" / "libratsdf.so"
     r = subprocess.run([str(build()), str(ROOT / "tests" / "golden" / "tiny.sens"), "--lib", str(lib), "--voxel",
@@ -67,9 +66,8 @@ def test_offline_eval_on_a_sens_stream(tmp_path, make_oracle):
     got = np.fromfile(out, dtype=REC)
     cpu = make_oracle(0.02, 0.12)
     K = tuple(float(np.float32(v)) for v in (577.87, 577.87, 319.5, 239.5))
-    for f in frames:
-        full = np.asarray(Image.open(io.BytesIO(M.encode_jpeg(f["rgb"], **kw))).convert("RGB"))
-        rgb = S.resize_u8_linear(full, 480, 640)
+    for i, f in enumerate(frames):
+        rgb = S.resize_u8_linear(ref[f"color{i}"], 480, 640)
         depth = f["depth"].astype(np.float32) * np.float32(1.0 / 1000.0)
         cpu.integrate(rgb, depth, None, None, 4.0, K, P.invert(P.pose_from_matrix(f["cam_to_world"])))
     exp = cpu.gather_valid_semantic()
