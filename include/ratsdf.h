@@ -33,7 +33,9 @@ extern "C" {
 
 typedef enum ratsdf_status {
   RATSDF_OK = 0,
-  RATSDF_ERR_BAD_ARGUMENT = 1,   /* reference: assert()s in TSDFGrid::Integrate, voxel_tsdf.cu:419-428 */
+  RATSDF_ERR_BAD_ARGUMENT = 1,   /* reference: assert()s in TSDFGrid::Integrate, voxel_tsdf.cu:419-428;
+                                    also: NaN / inf in a pose, intrinsics or max_depth (the reference would
+                                    integrate garbage: every voxel picks pixel (0, 0))                     */
   RATSDF_ERR_DEVICE = 2,         /* reference: CUDA_SAFE_CALL prints in debug builds, errors.cuh:13-20  */
   RATSDF_ERR_POOL_EXHAUSTED = 3, /* reference: device assert(idx >= 1), voxel_mem.cu:39                 */
   RATSDF_ERR_CAPACITY = 4,       /* an internal work list overflowed (no reference counterpart)        */

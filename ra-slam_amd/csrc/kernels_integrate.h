@@ -23,15 +23,25 @@
 
 namespace ratsdf {
 
-__device__ inline float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return v;
+// Wave-wide sum by DPP (data-parallel primitives: the VALU reads a neighbouring lane's register
+// directly): six steps, no LDS.  __shfl_xor compiles to ds_bpermute_b32 -- an LDS instruction plus four
+// VALU instructions of index arithmetic per step, each step waiting for the LDS round trip of the one
+// before it.  The result is valid in lane 63 and is broadcast from there through a scalar register.
+// (The voxel update itself needs no such reduction any more: finish_block works with ballots.)
+//   quad_perm [1,0,3,2], [2,3,0,1]: within 4 lanes; row_half_mirror, row_mirror: within a row of 16;
+//   row_bcast:15 (rows 1, 3 take lane 15 of the row before), row_bcast:31 (rows 2, 3 take lane 31)
+template <typename Op>
+__device__ inline uint32_t wave_reduce_dpp(uint32_t v, uint32_t identity, Op op) {
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0xB1, 0xF, 0xF, false));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x4E, 0xF, 0xF, false));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x141, 0xF, 0xF, false));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x140, 0xF, 0xF, false));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x142, 0xA, 0xF, false));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x143, 0xC, 0xF, false));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ inline uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  return wave_reduce_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a + b; });
 }
 
 template <int N>
@@ -310,6 +320,13 @@ __device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint
   }
 }
 
+// |(int)roundf(x)| in one instruction (see integrate_block)
+__device__ inline uint32_t rpi_abs(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32_e64 %0, |%1|" : "=v"(r) : "v"(x));
+  return (uint32_t)r;
+}
+
 // round-half-away-from-zero of a NON-NEGATIVE float (roundf for x >= 0, NaN stays NaN); the generic
 // roundf additionally restores the sign (v_bfi)
 __device__ inline float round_nonneg(float x) {
@@ -317,8 +334,9 @@ __device__ inline float round_nonneg(float x) {
   return t + ((x - t) >= .5f ? 1.f : 0.f);
 }
 
-// Update of one voxel block by the waves that own it (WPB waves, `part` = which one).  Returns the
-// number of voxels this lane updated and the lane's min |tsdf| after the update.
+// Update of one voxel block by the waves that own it (WPB waves, `part` = which one).  Called with the
+// whole wave (all 64 lanes) or not at all.  Returns the wave's summary word (the same in every lane):
+// voxels updated | (a voxel with |tsdf| < 0.9 exists) << 16 | (a voxel that is not a NaN exists) << 17.
 #ifdef RATSDF_STAMPS
 #define WSTAMP(i) do { if (wstamps && (threadIdx.x & 63) == 0) wstamps[i] = (unsigned long long)clock64(); } while (0)
 #else
@@ -327,7 +345,7 @@ __device__ inline float round_nonneg(float x) {
 template <int VPL>
 __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, const VisItem& item,
                                        bool fresh_in, uint32_t vi0, const float4* texA,
-                                       const uint32_t* texB, uint32_t* out_nupd, float* out_min,
+                                       const uint32_t* texB, uint32_t* out_word,
                                        unsigned long long* wstamps = nullptr) {
   bool fresh = fresh_in;
   const int tx0 = vi0 & 7, ty = (vi0 >> 3) & 7, tz = vi0 >> 6;
@@ -389,15 +407,27 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
       qu = div2(phx);
       qv = div2(phy);
     } else {
-      qu = v2f{phx[0] / pcz[0], phx[1] / pcz[1]};
-      qv = v2f{phy[0] / pcz[0], phy[1] / pcz[1]};
+      // a depth outside the shared-reciprocal range, e.g. a voxel in the camera plane (z == 0): plain
+      // IEEE quotients; 0 / 0 = NaN picks pixel 0 like the reference's float -> int conversion, which
+      // the short pixel pick below gets from a zero quotient (its conversion of a NaN is not 0)
+      auto q = [](float a, float z) {
+        const float r = a / z;
+        return r == r ? r : 0.f;
+      };
+      qu = v2f{q(phx[0], pcz[0]), q(phx[1], pcz[1])};
+      qv = v2f{q(phy[0], pcz[0]), q(phy[1], pcz[1])};
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int u = f2i(roundf(qu[j]));                                 // :196-199
-      const int w = f2i(roundf(qv[j]));                                 // :202
-      inb[j] = (uint32_t)u < (uint32_t)P.W && (uint32_t)w < (uint32_t)P.H;  // :205
-      const uint32_t k = (uint32_t)w * (uint32_t)P.W + (uint32_t)u;
+      // u = (int)roundf(qu), 0 <= u < W (:196-205), in its short form: |u| = v_cvt_rpi_i32_f32(|qu|)
+      // (floor(|x| + 0.5) evaluated exactly = |roundf(x)| for every float, NaN -> 0 and saturation as
+      // the conversion of roundf(x) gives them), and a negative coordinate lies in the image only if it
+      // rounds to 0, i.e. unless qu <= -0.5.  Equal to the long form for every one of the 2^32 floats
+      // (tools/probes/round_probe.hip, k_pick) at a third of its instructions.
+      const uint32_t u = rpi_abs(qu[j]);
+      const uint32_t w = rpi_abs(qv[j]);
+      inb[j] = u < (uint32_t)P.W && w < (uint32_t)P.H && !(qu[j] <= -.5f) && !(qv[j] <= -.5f);
+      const uint32_t k = w * (uint32_t)P.W + u;
       kk[j] = inb[j] ? k : 0u;
       phz[j] = pcz[j];
     }
@@ -467,6 +497,7 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
     }
   }
   uint32_t nupd = 0;
+  bool upd2[2] = {false, false};  // VPL == 2: which of the lane's two voxels updated
   const Recip rtrunc = make_recip(P.trunc);
   if (VPL == 2 && !RATSDF_DBG(P, 14)) {
     // The lane's two voxels side by side in 2-wide vectors: the same operations in the same order as
@@ -485,7 +516,7 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
     };
     const v2f d = {ta[0].x, ta[1].x};
     const v2f sdf = v2f{ta[0].y, ta[1].y} * (d - v2f{phz[0], phz[1]});            // :216
-    bool upd[2];
+    bool (&upd)[2] = upd2;
 #pragma unroll
     for (int j = 0; j < 2; ++j)  // (colour-word test: see the loop below)
       upd[j] = inb[j] && !(d[j] == 0 || d[j] > P.md) && sdf[j] > -P.trunc && tb[j] != 0xFFFFFFFFu;  // :211,217
@@ -553,9 +584,9 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
         const float x = (wo[j] * L + wn[j] * ta[j].z) * r1[j];
         const float ex = __builtin_amdgcn_exp2f(x * -1.44269504f);
         sv[j] = __float_as_uint(__builtin_amdgcn_rcpf(1.f + ex));
-        ++nupd;
       }
     }
+    nupd = upd[0] || upd[1];  // (non-zero = something to store)
   } else {
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
@@ -616,47 +647,65 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
     VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), sv);
     VecIO<VPL>::store(pool.rgbw + v, cv);
   }
-  // space_carving_kernel, :253-276: min |tsdf| over the block after the update
-  float m = fabsf(__uint_as_float(tv[0]));
+  // space_carving_kernel, :253-276: "min |tsdf| over the block >= 0.9" with fminf's NaN rule (a NaN
+  // never wins) is "no voxel with |tsdf| < 0.9, and at least one that is a number": two per-lane
+  // predicates, combined over the wave by ballots in finish_block (two v_cmp each, the rest on the
+  // scalar unit) instead of a 512-way min reduction.
+  // (the builtin on the predicates themselves, one ballot per comparison: anything that passes through
+  // an integer or a logical OR of lanes' predicates first makes the compiler move a predicate that
+  // already sits in a scalar register pair into a vector register and compare it again)
+  auto ballot = [](bool p) { return (unsigned long long)__builtin_amdgcn_ballot_w64(p); };
+  unsigned long long low = 0, num = 0;
 #pragma unroll
-  for (int j = 1; j < VPL; ++j) m = fminf(m, fabsf(__uint_as_float(tv[j])));
-  *out_nupd = nupd;
-  *out_min = m;
+  for (int j = 0; j < VPL; ++j) {
+    const float t = __uint_as_float(tv[j]);
+    low |= ballot(fabsf(t) < .9f);
+    num |= ballot(t == t);
+  }
+  // the wave's word (uniform): voxels updated | any-low << 16 | any-number << 17
+  uint32_t cnt = 0;
+  if (VPL == 2 && !RATSDF_DBG(P, 14)) {
+    cnt = (uint32_t)__popcll(ballot(upd2[0])) + (uint32_t)__popcll(ballot(upd2[1]));
+  } else {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cnt += (uint32_t)__popcll(ballot((nupd >> b) & 1u)) << b;
+  }
+  *out_word = cnt | (low != 0ull ? 1u << 16 : 0u) | (num != 0ull ? 1u << 17 : 0u);
 }
 
-// End of a block's update: combine the WPB waves of the block (min |tsdf|, voxels updated) through
-// LDS; one thread adds the update count to its workgroup's counter (a single device-wide counter
+// End of a block's update: combine the WPB waves of the block (carve predicates, voxels updated)
+// through LDS; one thread adds the update count to its workgroup's counter (a single device-wide counter
 // would cost more than the whole update: ~90 atomics/us per address) and files the block for carving
 // when min |tsdf| >= 0.9 (space_carving_kernel, voxel_tsdf.cu:253-276).
-// smin / supd: [2][8] words, used alternately by consecutive calls (`phase` = call parity), so one
+// Inside a wave everything is a ballot (integrate_block: v_cmp into a scalar register pair + s_bcnt1 on
+// the scalar unit; the voxel count is the sum of the popcounts of the bits of the per-lane count).  Until round 3
+// this was two 64-lane butterflies of __shfl_xor = ds_bpermute (LDS) -- ~70 VALU instructions and six
+// dependent LDS round trips per block and wave, a fifth of the update.
+// sred: [2][8] words, used alternately by consecutive calls (`phase` = call parity), so one
 // LDS-only barrier per call is enough: a wave can only be one call ahead of the slowest reader.
+// Word = voxels updated | any-low << 16 | any-number << 17.
 template <int WPB>
 __device__ inline void finish_block(EnginePtr E, FrameCtl* F, uint32_t* upd_wg, uint32_t par,
                                     bool carve_after_serial, const VisItem& item,
-                                    bool active, float m, uint32_t nupd, uint32_t wv, uint32_t part,
-                                    uint32_t lane, uint32_t phase, uint32_t counter, float (*smin)[8],
-                                    uint32_t (*supd)[8]) {
-  m = wave_min(m);
-  nupd = wave_sum(nupd);
+                                    bool active, uint32_t word, uint32_t wv, uint32_t part,
+                                    uint32_t lane, uint32_t phase, uint32_t counter, uint32_t (*sred)[8]) {
   bool fin = active && lane == 0;
   if (WPB > 1) {
-    if (lane == 0) {
-      smin[phase][wv] = m;
-      supd[phase][wv] = nupd;
-    }
+    if (lane == 0) sred[phase][wv] = word;
     lds_barrier();  // not __syncthreads(): that would also wait for the voxel stores in flight
     fin = fin && part == 0;
     if (fin) {
 #pragma unroll
       for (int i = 1; i < WPB; ++i) {
-        m = fminf(m, smin[phase][wv + i]);
-        nupd += supd[phase][wv + i];
+        const uint32_t o = sred[phase][wv + i];
+        word = ((word + o) & 0xFFFFu) | ((word | o) & 0x30000u);
       }
     }
   }
   if (fin) {
-    if (nupd) atomicAdd(&upd_wg[counter & (kUpdCounters - 1)], nupd);
-    if (m >= .9f) {  // rare: operands come from the engine record, not from registers held all along
+    const uint32_t n = word & 0xFFFFu;
+    if (n) atomicAdd(&upd_wg[counter & (kUpdCounters - 1)], n);
+    if ((word & 0x30000u) == 0x20000u) {  // rare: operands come from the engine record, not from registers held all along
       // the resolver of this frame's chained-bucket requests (serial role, possibly still running
       // beside this update) reads and edits the directory as it was BEFORE the frame's carving
       if (carve_after_serial) wait_serial_done(F, E->ctl);

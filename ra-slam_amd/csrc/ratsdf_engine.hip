@@ -633,6 +633,18 @@ int ratsdf_engine::sticky() {
   return (int)err;
 }
 
+// Non-finite camera parameters are refused at the boundary (RATSDF_ERR_BAD_ARGUMENT).  The reference
+// would integrate garbage (a NaN pose projects every voxel to pixel (0, 0): float -> int of NaN is 0 in
+// CUDA); the engine's short pixel pick (kernels_integrate.h) reproduces the reference for
+// every finite pose -- including voxels in the camera plane, z == 0 -- and relies on this check for the
+// rest.
+static bool finite_frame(const ratsdf_intrinsics& K, const ratsdf_pose& T, float max_depth) {
+  const float v[] = {K.fx, K.fy, K.cx, K.cy, T.qx, T.qy, T.qz, T.qw, T.tx, T.ty, T.tz, max_depth};
+  for (float x : v)
+    if (!std::isfinite(x)) return false;
+  return true;
+}
+
 // ================================== C ABI =====================================================
 extern "C" {
 
@@ -807,6 +819,7 @@ int ratsdf_integrate_device(ratsdf_engine* e, const void* d_rgb, const void* d_d
   DeviceGuard guard(e ? e->device : -1);
   if (!e || !d_rgb || !d_depth || !K || !T || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
+  if (!finite_frame(*K, *T, max_depth)) return RATSDF_ERR_BAD_ARGUMENT;
   if (!d_ht || !d_lt) d_ht = d_lt = nullptr;
   const ratsdf_engine::FrameIn in{d_rgb, d_depth, d_ht, d_lt, K, T};
   return e->frame(in, nullptr, height, width, max_depth);
@@ -820,7 +833,7 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
   if (!e || n < 0 || (n > 0 && (!d_rgb || !d_depth || !K || !T)) || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   for (int i = 0; i < n; ++i)
-    if (!d_rgb[i] || !d_depth[i]) return RATSDF_ERR_BAD_ARGUMENT;
+    if (!d_rgb[i] || !d_depth[i] || !finite_frame(K[i], T[i], max_depth)) return RATSDF_ERR_BAD_ARGUMENT;
   auto input = [&](int i) {
     const void* ht = (d_ht && d_lt) ? d_ht[i] : nullptr;
     const void* lt = (d_ht && d_lt) ? d_lt[i] : nullptr;
@@ -846,6 +859,7 @@ int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, c
   DeviceGuard guard(e ? e->device : -1);
   if (!e || !rgb || !depth || !K || !T || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
+  if (!finite_frame(*K, *T, max_depth)) return RATSDF_ERR_BAD_ARGUMENT;
   if (!ht || !lt) ht = lt = nullptr;  // modules/tsdf_module.cc:27-31
   const size_t npix = (size_t)height * width;
   int st = e->ensure_stage(npix);
@@ -875,7 +889,7 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
   if (!e || n < 0 || (n > 0 && (!rgb || !depth || !K || !T)) || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   for (int i = 0; i < n; ++i)
-    if (!rgb[i] || !depth[i]) return RATSDF_ERR_BAD_ARGUMENT;
+    if (!rgb[i] || !depth[i] || !finite_frame(K[i], T[i], max_depth)) return RATSDF_ERR_BAD_ARGUMENT;
   if (n == 0) return e->sticky();
   const size_t npix = (size_t)height * width;
   int st = e->ensure_stage(npix);
@@ -1756,7 +1770,7 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
   const int S = g->S;
   const size_t npix = (size_t)height * width;
   for (size_t i = 0; i < (size_t)n * S; ++i)
-    if (!d_rgb[i] || !d_depth[i]) return RATSDF_ERR_BAD_ARGUMENT;
+    if (!d_rgb[i] || !d_depth[i] || !finite_frame(K[i], T[i], max_depth)) return RATSDF_ERR_BAD_ARGUMENT;
   DeviceGuard guard(g->device);
   ratsdf_engine* e0 = g->eng[0];
   if (npix * (size_t)e0->S >= 0xFFFFFFFFull) return RATSDF_ERR_BAD_ARGUMENT;

@@ -318,3 +318,46 @@ def test_tum_640x480_5mm_pair(make_engine, make_oracle):
     assert frames[0]["depth"].shape == (480, 640)
     worst = run_both(gpu, cpu, frames)
     print("tum 5mm", worst)
+
+
+def test_voxels_in_the_camera_plane(make_engine, make_oracle):
+    """pc.z == 0 exactly: x / 0 = +-inf falls outside the image, 0 / 0 = NaN picks pixel (0, 0) because
+    CUDA's float -> int conversion of NaN is 0 (voxel_tsdf.cu:196-205, SURVEY 8a).  The kernel's
+    shared-reciprocal division does not cover z == 0 and its short pixel pick does not convert NaN to 0:
+    this is the frame that takes the plain-division branch."""
+    vs = 0.02
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    f0 = synthetic.frame("wall", 0, scale=0.25)          # fronto-parallel wall at z = 2 m, identity rotation
+    assert tuple(float(v) for v in f0["pose"][:4]) == (0.0, 0.0, 0.0, 1.0)
+    run_both(gpu, cpu, [f0])
+    # second frame: the camera moved INTO the wall's blocks, its plane on the voxel plane gz = 100
+    # (world z = fl(100 * vs)): with the identity rotation pc.z = fl(gz * vs) + t.z is exactly 0 there
+    f1 = dict(f0)
+    tz = -float(np.float32(100) * np.float32(vs))
+    f1["pose"] = (0.0, 0.0, 0.0, 1.0, 0.0, 0.0, tz)
+    f1["depth"] = np.full_like(f0["depth"], 0.05)         # valid everywhere, pixel (0, 0) included
+    before = gpu.last_frame_stats()["active_blocks"]
+    run_both(gpu, cpu, [f1])
+    s = gpu.last_frame_stats()
+    # (8 blocks straddle the camera plane; the voxel on the optical axis -- 0 / 0 -- is among the updated)
+    assert s["visible_blocks"] > 0 and s["updated_voxels"] > 0 and before > 0
+
+
+def test_non_finite_camera_parameters_are_refused(make_engine):
+    """ratsdf_integrate*: NaN / inf in pose, intrinsics or max depth -> RATSDF_ERR_BAD_ARGUMENT, map untouched"""
+    import ratsdf
+    vs = 0.02
+    gpu = make_engine(vs, 6 * vs)
+    f = synthetic.frame("wall", 0, scale=0.25)
+    gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+    n0 = gpu.num_active_blocks()
+    for bad_pose in [(0, 0, 0, 1, float("nan"), 0, 0), (0, 0, float("inf"), 1, 0, 0, 0)]:
+        with pytest.raises(ratsdf.RatsdfError) as ei:
+            gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], bad_pose)
+        assert ei.value.status == 1   # RATSDF_ERR_BAD_ARGUMENT
+    with pytest.raises(ratsdf.RatsdfError):
+        gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, (float("nan"), 500.0, 80.0, 60.0), f["pose"])
+    with pytest.raises(ratsdf.RatsdfError):
+        gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], float("inf"), f["intrinsics"], f["pose"])
+    assert gpu.num_active_blocks() == n0
+    gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])  # still usable
