@@ -547,6 +547,12 @@ __device__ inline void lds_rank_all(uint32_t* keys, uint32_t n, Emit emit) {
 }
 
 constexpr uint32_t kSmallRank = 4096;  // LDS list capacity (16 KiB of the resolver's sort buffer)
+// The serial role inside k_integrate (kernels_integrate.h) lists the winners' ranks in device memory
+// (RankBufs::win_ranks) and every committing wave counts the smaller ones itself, so its ordinary path
+// is not limited by LDS: it takes frames of up to kFusedRank requests -- a whole new view at 1280x720 /
+// 2 mm files ~30 k -- which until round 3 fell into the general path (a rank-indexed bitmap scanned by
+// one 256-thread workgroup with its scratch in device memory while 2 048 workgroups poll: 0.8-1.4 ms).
+constexpr uint32_t kFusedRank = 32768;
 
 // All threads of one workgroup; `skeys` = the workgroup's dynamic LDS (kSerialLdsBytes), `nf` = the
 // pool's free count at the start of this pass.
@@ -595,15 +601,33 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
     lds_rank_all(lds_rank, total, [&](uint32_t w, uint32_t k) { req_k[lds_req[w]] = k; });
     RATSDF_STAMP(ctl->stamps, 10);
   } else {
-    for (uint32_t i = tid; i < n; i += nt) {
-      const Request r = req[i];
-      bool win = (r.flags & kReqWinner) != 0;
-      if (!(r.flags & kReqPlaced)) {
-        const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
-        win = tab.claim[bucket] == r.rank;
-        if (win) req[i].flags = kReqWinner;
+    // Thousands of requests (the first frames of a view) on one workgroup: every request costs two
+    // DEPENDENT loads (the request, then its bucket's claim), so the loops below keep kU requests per
+    // thread in flight -- taken one at a time, 30 k requests on 256 threads were ~230 back-to-back
+    // memory round trips and most of the 0.85 ms such a frame took in round 2.
+    constexpr int kU = 4;
+    for (uint32_t base = tid; base < n; base += nt * kU) {  // uniform
+      Request r[kU];
+      uint32_t c[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t i = base + (uint32_t)u * nt;
+        r[u] = req[i < n ? i : 0];
       }
-      if (win) bitmap_set(bitmap, summary, r.rank);
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        c[u] = tab.claim[block_hash(r[u].x, r[u].y, r[u].z, tab.bucket_mask)];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t i = base + (uint32_t)u * nt;
+        if (i >= n) continue;
+        bool win = (r[u].flags & kReqWinner) != 0;
+        if (!(r[u].flags & kReqPlaced)) {
+          win = c[u] == r[u].rank;
+          if (win) req[i].flags = kReqWinner;
+        }
+        if (win) bitmap_set(bitmap, summary, r[u].rank);
+      }
     }
     __syncthreads();
     RATSDF_STAMP(ctl->stamps, 9);
@@ -612,9 +636,27 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
     const uint32_t excl = block_exclusive_scan(sum, lds, &total);
     bitmap_write_prefix(bitmap, summary, prefix, nwords, chunk, sum, excl);
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += nt) {
-      const Request r = req[i];
-      if (r.flags & kReqWinner) req_k[i] = bitmap_rank(bitmap, prefix, r.rank);
+    for (uint32_t base = tid; base < n; base += nt * kU) {  // uniform
+      Request r[kU];
+      uint32_t pw[kU], bw[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t i = base + (uint32_t)u * nt;
+        r[u] = req[i < n ? i : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {  // bitmap_rank's two loads (rank < 32 * nwords by construction)
+        const uint32_t w = r[u].rank >> 5;
+        const bool need = (r[u].flags & kReqWinner) && w < nwords;
+        pw[u] = prefix[need ? w : 0];
+        bw[u] = bitmap[need ? w : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t i = base + (uint32_t)u * nt;
+        if (i < n && (r[u].flags & kReqWinner))
+          req_k[i] = pw[u] + __popc(bw[u] & ((1u << (r[u].rank & 31)) - 1u));
+      }
     }
     __syncthreads();
     bitmap_clean(bitmap, summary, nwords);

@@ -361,9 +361,27 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
     bitmap_write_prefix(cb.bitmap, cb.summary, cb.prefix, nwords, chunk, sum, excl);
     __syncthreads();
     n_del = total;
-    for (uint32_t i = tid; i < nd; i += nt) {
-      const DelItem d = cb.del[i];
-      pool.heap[(uint32_t)nf + bitmap_rank(cb.bitmap, cb.prefix, d.entry)] = d.idx;
+    // (four deletes per thread in flight: item -> prefix word / bitmap word are dependent loads)
+    constexpr int kU = 4;
+    for (uint32_t base = tid; base < nd; base += nt * kU) {  // uniform
+      DelItem d[kU];
+      uint32_t pw[kU], bw[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t i = base + (uint32_t)u * nt;
+        d[u] = cb.del[i < nd ? i : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t w = d[u].entry >> 5;
+        pw[u] = cb.prefix[w < nwords ? w : 0];
+        bw[u] = cb.bitmap[w < nwords ? w : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t i = base + (uint32_t)u * nt;
+        if (i < nd) pool.heap[(uint32_t)nf + pw[u] + __popc(bw[u] & ((1u << (d[u].entry & 31)) - 1u))] = d[u].idx;
+      }
     }
     for (uint32_t j = tid; j < ns; j += nt) {
       const SlowDelete s = cb.slow[j];

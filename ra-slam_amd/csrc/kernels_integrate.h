@@ -124,20 +124,43 @@ __device__ inline Request ld_agent_request(const Request* p) {
 
 // A wave waits until the frame's serial role has published (one lane polls; bounded, sticky error on
 // expiry); after the general path (serial_done == 2) the caller's plain loads need an acquire.
+// The polling backs off: in the ordinary frame the flag comes within ~2 us and the first polls are
+// 0.25 us apart; in a frame that takes the role's general path (the first frames of a view: hundreds
+// of microseconds) 8 192 waves polling one cache line at that cadence saturate its L2 channel and
+// slow down the very role they are waiting for, so the gap doubles up to ~30 us.
+__device__ inline uint32_t poll_serial_done(FrameCtl* F, Ctl* ctl) {
+  uint32_t v = 0;
+  const unsigned long long t0 = (unsigned long long)wall_clock64();
+  uint32_t naps = 0;
+  while ((v = ld_agent(&F->serial_done)) == 0u) {
+    if ((unsigned long long)wall_clock64() - t0 > kSerialWaitTicks) {
+      set_error(ctl, RATSDF_ERR_TIMEOUT);
+      break;
+    }
+    if (naps < 16) {
+      __builtin_amdgcn_s_sleep(8);
+    } else {  // 4, 8, 16 ... 31 us (s_sleep 127 = 8 128 cycles)
+      const uint32_t reps = naps < 24 ? 1u : (naps < 32 ? 2u : (naps < 40 ? 4u : 8u));
+      for (uint32_t k = 0; k < reps; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+    ++naps;
+  }
+  return v;
+}
 __device__ inline void wait_serial_done(FrameCtl* F, Ctl* ctl) {
   uint32_t v = 0;
-  if ((threadIdx.x & 63u) == 0) {
-    const unsigned long long t0 = (unsigned long long)wall_clock64();
-    while ((v = ld_agent(&F->serial_done)) == 0u) {
-      if ((unsigned long long)wall_clock64() - t0 > kSerialWaitTicks) {
-        set_error(ctl, RATSDF_ERR_TIMEOUT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-  }
+  if ((threadIdx.x & 63u) == 0) v = poll_serial_done(F, ctl);
   v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
   if (v != 1u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // uniform
+}
+// The same for a whole workgroup at once (every wave of the workgroup calls it at the same point):
+// wave 0 polls, the others wait at an LDS barrier -- a quarter of the pollers.  `lds`: one word.
+__device__ inline void wait_serial_done_wg(FrameCtl* F, Ctl* ctl, uint32_t* lds) {
+  if (threadIdx.x == 0) *lds = poll_serial_done(F, ctl);
+  lds_barrier();
+  const uint32_t v = *lds;
+  if (v != 1u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // uniform
+  lds_barrier();  // (the word may be reused)
 }
 
 // returns 1 (ordinary frame: agent-scope stores only) or 2 (general path: plain stores)
@@ -224,40 +247,51 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
   if (ns > cb.slow_cap) ns = cb.slow_cap;
   if (n > rb.req_cap) n = rb.req_cap;
 
-  const bool fast = (!pend || nd + ns <= kSmallCarve) && n <= kSmallRank;
+  const bool fast = (!pend || nd + ns <= kSmallCarve) && n <= kFusedRank;
   if (__builtin_expect(!fast, 0)) {  // uniform: the general functions, scratch in device memory
     serial_general(E, par, nwords, nf0, true);
     return 2u;
   }
 
-  // second dependent round: the claim of every request's bucket (two requests per thread at once;
-  // further batches only for frames with more than 512 requests)
+  // second dependent round: the claim of every request's bucket.  Four requests per thread are in
+  // flight at once (the first two rode in the first round): a frame with n requests costs
+  // ceil(n / 1024) times two dependent round trips, ~35 of them for a whole new view of 30 k requests.
   // (the previous frame's update counters ride in this round: nothing depends on them but a sum)
   uint4 u = make_uint4(0, 0, 0, 0);
   static_assert(UPT == 4, "one uint4 of update counters per thread");
   if (pend) u = reinterpret_cast<const uint4*>(cb.upd_wg)[tid];
   if (tid < 3) lds[tid] = 0;  // [0] slow deletes that happened, [1] winners, [2] voxels updated
   lds_barrier();
-  for (uint32_t base = 0; base < n; base += 2 * NT) {  // uniform
-    const uint32_t i0 = base + tid, i1 = base + NT + tid;
-    if (base != 0) {  // (agent scope: requests the resolver appended are read past this CU's L1)
-      if (i0 < n) r0 = ld_agent_request(rb.req + i0);
-      if (i1 < n) r1 = ld_agent_request(rb.req + i1);
+  constexpr int kU = 4;
+  for (uint32_t base = 0; base < n; base += kU * NT) {  // uniform
+    Request r[kU];
+    uint32_t c[kU];
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {  // (agent scope: requests the resolver appended are read past this CU's L1)
+      const uint32_t i = base + (uint32_t)k * NT + tid;
+      r[k] = Request{0, 0, 0, 0, 0, 0};
+      if (base == 0 && k == 0) r[k] = r0;
+      else if (base == 0 && k == 1) r[k] = r1;
+      else if (i < n) r[k] = ld_agent_request(rb.req + i);  // (nothing is issued for the steady state's few hundred)
     }
-    uint32_t c0 = kInf, c1 = kInf;
-    if (i0 < n) c0 = tab.claim[block_hash(r0.x, r0.y, r0.z, tab.bucket_mask)];
-    if (i1 < n) c1 = tab.claim[block_hash(r1.x, r1.y, r1.z, tab.bucket_mask)];
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      const uint32_t i = base + (uint32_t)k * NT + tid;
+      c[k] = kInf;
+      if (i < n) c[k] = tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)];
+    }
     // the winners' ranks go to a compact list; the committing waves turn a rank into the winner's
     // position in raster order (= order of the AquireBlock calls) by counting the smaller ones.
     // A request the resolver placed is a winner as it stands (its bucket's claim is not its own).
-    const bool p0 = i0 < n && (r0.flags & kReqPlaced), p1 = i1 < n && (r1.flags & kReqPlaced);
-    if (i0 < n && (p0 || c0 == r0.rank)) {
-      if (!p0) mark_winner(rb.req + i0, r0);
-      st_agent(&rb.win_ranks[atomicAdd(&lds[1], 1u)], r0.rank);
-    }
-    if (i1 < n && (p1 || c1 == r1.rank)) {
-      if (!p1) mark_winner(rb.req + i1, r1);
-      st_agent(&rb.win_ranks[atomicAdd(&lds[1], 1u)], r1.rank);
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      const uint32_t i = base + (uint32_t)k * NT + tid;
+      if (i >= n) continue;
+      const bool placed = (r[k].flags & kReqPlaced) != 0;
+      if (placed || c[k] == r[k].rank) {
+        if (!placed) mark_winner(rb.req + i, r[k]);
+        st_agent(&rb.win_ranks[atomicAdd(&lds[1], 1u)], r[k].rank);
+      }
     }
   }
   if (pend) {  // previous frame: count of its head / chain deletes, voxels-updated sum

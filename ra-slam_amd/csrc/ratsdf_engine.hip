@@ -757,7 +757,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     CREATE_CHK(hipMemsetAsync(e->upd_wg[i], 0, kUpdCounters * 4, e->stream));
     CREATE_CHK(hipMalloc(&e->slowdel[i], (size_t)kSlowDelCap * sizeof(SlowDelete)));
   }
-  CREATE_CHK(hipMalloc(&e->win_ranks, (size_t)kSmallRank * 4));
+  CREATE_CHK(hipMalloc(&e->win_ranks, (size_t)kFusedRank * 4));
   CREATE_CHK(hipMalloc(&t.dclaim, (size_t)t.num_bucket * 4));
   CREATE_CHK(hipMemsetAsync(t.dclaim, 0xFF, (size_t)t.num_bucket * 4, e->stream));
   e->dwords = (e->dwords + kGroupWords - 1) / kGroupWords * kGroupWords;
