@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--max-depth", type=float, default=4.0)
     ap.add_argument("--cpu-frames", type=int, default=1080,
                     help="frames of the stream timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--config", default="vga5mm", choices=["vga5mm", "hd2mm", "bigmap"],
+    ap.add_argument("--config", default="vga5mm", choices=["vga5mm", "hd2mm", "bigmap", "flythrough"],
                     help="vga5mm: BASELINE metric config (640x480, 5 mm); hd2mm: 1280x720, 2 mm "
                          "(BASELINE configs[3] workload, single GPU unless --shard); bigmap: hd2mm on a "
                          "120-degree sweep whose map (> 256 MiB of voxel data, revisited only after a "
@@ -75,7 +75,10 @@ def parse():
                     help="N = 1: also time S concurrent streams on this GPU through one launch "
                          "triple per frame step (ratsdf_group_*); 0 / 1 = skip")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="vga5mm, N = 1: skip the bounded 1280x720 / 2 mm leg (`secondary`)")
+                    help="vga5mm, N = 1: skip the bounded 1280x720 / 2 mm legs (`secondary`: hd2mm, bigmap), the "
+                         "non-repeating pass (`flythrough`) and the C++ TSDFSystem leg (`tsdf_system_path`)")
+    ap.add_argument("--flythrough-frames", type=int, default=180,
+                    help="frames of the non-repeating pass (`flythrough`; --config flythrough: 360 at 1280x720)")
     return ap.parse_args()
 
 
@@ -123,11 +126,15 @@ def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", en
                 launches=k_n)
 
 
-def bench_streams(ratsdf, torch, dev, dev_index, S, scene, cam, vs, md, nfr, steps, reps):
-    """S concurrent streams of this GPU through ONE launch triple per frame step (ratsdf_group_*:
+def bench_streams(ratsdf, torch, dev, dev_index, S, scene, cam, vs, md, nfr, steps, reps, cpu_threads=16):
+    """S concurrent streams of this GPU through ONE launch pair per frame step (ratsdf_group_*:
     frame-batched integration, BASELINE configs[4] on one device).  Every member's map is exactly
-    what the member alone would produce (tests/test_gpu_group.py)."""
+    what the member alone would produce: asserted here against the CPU oracle on the first pass over
+    the streams, before anything is timed (and in tests/test_gpu_group.py)."""
     from ratsdf import synthetic
+    from oracle_binding import load_oracle
+    from parity import assert_maps_equal
+    from ratsdf._abi import Engine
     half = nfr // 2
     streams = []
     for s in range(S):
@@ -143,7 +150,18 @@ def bench_streams(ratsdf, torch, dev, dev_index, S, scene, cam, vs, md, nfr, ste
     gb = grp.make_batch(rows("rgb"), rows("depth"), rows("ht"), rows("lt"), H, W, md,
                         [[streams[s][f]["intrinsics"] for s in range(S)] for f in range(n)],
                         [[streams[s][f]["pose"] for s in range(S)] for f in range(n)])
-    for _ in range(3):
+    # first pass: parity of every member against the oracle fed with that member's stream
+    grp.integrate_device_batch(gb)
+    grp.synchronize()
+    worst = dict(tsdf=0.0, prob=0.0)
+    for s_ in range(S):
+        cpu = Engine(load_oracle(), vs, 6 * vs, threads=cpu_threads)
+        for f in streams[s_]:
+            cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+        w = assert_maps_equal(engines[s_], cpu)
+        worst = {k: max(worst[k], w[k]) for k in worst}
+        cpu.close()
+    for _ in range(2):
         grp.integrate_device_batch(gb)
     grp.synchronize()
     for e in engines:
@@ -170,6 +188,8 @@ def bench_streams(ratsdf, torch, dev, dev_index, S, scene, cam, vs, md, nfr, ste
                roofline=roofline_block(b_alg / frames_total * S, k_ms, k_n, "vga5mm", kernel="k_integrate_g",
                                        whole_frame_gbps=b_alg / frames_total * fps / 1e9,
                                        engines=S),
+               parity=dict(members=S, frames_each=n, max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"],
+                           directory="bit-exact"),
                note="one k_front_g / k_integrate_g launch pair per frame step serves all "
                     "streams (one grid slice per stream); a k_integrate_g launch = S frames")
     grp.close()
@@ -178,28 +198,33 @@ def bench_streams(ratsdf, torch, dev, dev_index, S, scene, cam, vs, md, nfr, ste
     return out
 
 
-def bench_secondary(ratsdf, torch, dev, dev_index, md, cpu_threads):
-    """Bounded 1280x720 / 2 mm / L515 leg (BASELINE configs[3] workload on one GPU; north_star asks
-    for both stream sizes): throughput, k_integrate roofline and parity against the CPU oracle."""
+def bench_secondary(ratsdf, torch, dev, dev_index, md, cpu_threads, config="hd2mm"):
+    """Bounded 1280x720 / 2 mm / L515 legs (BASELINE configs[3] workload on one GPU; north_star asks
+    for both stream sizes): throughput, k_integrate roofline and parity against the CPU oracle.
+      hd2mm   20-frame ping-pong: the 100 MB map lives in the 256 MiB Infinity Cache
+      bigmap  240-frame sweep (120 degrees there and back): 416 MB of voxel data, every block revisited
+              only after the rest of the map has gone through the caches -> the HBM-resident number"""
     from ratsdf import synthetic
     from oracle_binding import load_oracle
     from parity import assert_maps_equal
     from ratsdf._abi import Engine
-    vs, cam, half, steps, reps = 0.002, "l515_720p", 10, 8, 3
+    vs, cam = 0.002, "l515_720p"
+    half, steps, reps, n_par = (10, 8, 3, 20) if config == "hd2mm" else (120, 2, 2, 12)
     fr = [synthetic.frame("room", i, cam=cam, noise=True, holes=True) for i in range(half)]
     frames = fr + fr[::-1]
     H, W = frames[0]["depth"].shape
-    d = [{k: torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")} for f in frames]
+    d = [{k: torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")} for f in fr]
+    d = d + d[::-1]
     intr = [ratsdf.Intrinsics(*f["intrinsics"]) for f in frames]
     pose = [ratsdf.Pose(*f["pose"]) for f in frames]
-    # parity on the first pass over the stream
+    # parity on the first frames of the stream
     cpu = Engine(load_oracle(), vs, 6 * vs, threads=cpu_threads)
     chk = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
     t0 = time.perf_counter()
-    for f in frames:
+    for f in frames[:n_par]:
         cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
     t_cpu = time.perf_counter() - t0
-    for i, f in enumerate(frames):
+    for i in range(n_par):
         chk.integrate_device(d[i]["rgb"].data_ptr(), d[i]["depth"].data_ptr(), d[i]["ht"].data_ptr(),
                              d[i]["lt"].data_ptr(), H, W, md, intr[i], pose[i])
     chk.synchronize()
@@ -210,7 +235,7 @@ def bench_secondary(ratsdf, torch, dev, dev_index, md, cpu_threads):
     batch = eng.make_batch([x["rgb"].data_ptr() for x in d], [x["depth"].data_ptr() for x in d],
                            [x["ht"].data_ptr() for x in d], [x["lt"].data_ptr() for x in d], H, W, md,
                            intr, pose)
-    for _ in range(3):
+    for _ in range(3 if config == "hd2mm" else 1):
         eng.integrate_device_batch(batch)
     eng.synchronize()
     eng.totals(reset=True)
@@ -225,20 +250,120 @@ def bench_secondary(ratsdf, torch, dev, dev_index, md, cpu_threads):
     k_ms, k_n = eng.profile_read()
     eng.profile_enable(False)
     tot = eng.totals()
+    stats = eng.last_frame_stats()
     dt = sorted(rep_dt)[len(rep_dt) // 2]
     fps = steps * len(frames) / dt
     b_alg = alg_bytes(W, H, tot) / max(tot["frames"], 1)
-    out = dict(config="hd2mm", workload=f"synthetic 'room' stream, {cam} intrinsics {W}x{H}, voxel 2 mm, "
-                                        f"truncation 12 mm, max depth {md:g} m, {len(frames)}-frame ping-pong",
+    out = dict(config=config, workload=f"synthetic 'room' stream, {cam} intrinsics {W}x{H}, voxel 2 mm, "
+                                       f"truncation 12 mm, max depth {md:g} m, {len(frames)}-frame ping-pong",
                value=round(fps, 1), unit="frames/s", steps=steps, reps=reps, frames_per_step=len(frames),
                frame=dict(avg_visible_blocks=round(tot["visible_blocks"] / tot["frames"], 1),
                           avg_updated_voxels=round(tot["updated_voxels"] / tot["frames"], 1),
-                          alg_bytes=round(b_alg)),
-               roofline=roofline_block(b_alg, k_ms, k_n, "hd2mm", whole_frame_gbps=b_alg * fps / 1e9),
-               cpu_frames_per_s=round(len(frames) / t_cpu, 1), cpu_threads=cpu_threads,
-               parity=dict(frames=len(frames), max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"],
+                          alg_bytes=round(b_alg), active_blocks=stats["active_blocks"],
+                          map_voxel_bytes=stats["active_blocks"] * 6144,
+                          hbm_resident=bool(stats["active_blocks"] * 6144 > 256 * 2 ** 20)),
+               roofline=roofline_block(b_alg, k_ms, k_n, config, whole_frame_gbps=b_alg * fps / 1e9),
+               cpu_frames_per_s=round(n_par / t_cpu, 1), cpu_threads=cpu_threads,
+               parity=dict(frames=n_par, max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"],
                            directory="bit-exact"))
     eng.close()
+    return out
+
+
+def bench_flythrough(ratsdf, torch, dev, dev_index, cam, vs, md, nframes, cpu_threads, n_par=12):
+    """A non-repeating stream: one pass of the room camera (1 degree / frame, no frame seen twice), from
+    an empty map.  Every frame allocates; the first one allocates a whole view (the serial role's long
+    path).  Every frame's k_integrate carries events (ratsdf_profile_enable(2)): per-frame kernel time
+    and start-to-start period -> p50 / p99 / max, which a repeating sweep never shows."""
+    from ratsdf import synthetic
+    from oracle_binding import load_oracle
+    from parity import assert_maps_equal
+    from ratsdf._abi import Engine
+    frames = [synthetic.frame("room", i, cam=cam, noise=True, holes=True) for i in range(nframes)]
+    H, W = frames[0]["depth"].shape
+    d = [{k: torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")} for f in frames]
+    intr = [ratsdf.Intrinsics(*f["intrinsics"]) for f in frames]
+    pose = [ratsdf.Pose(*f["pose"]) for f in frames]
+    cpu = Engine(load_oracle(), vs, 6 * vs, threads=cpu_threads)
+    chk = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
+    for i, f in enumerate(frames[:n_par]):
+        cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+        chk.integrate_device(d[i]["rgb"].data_ptr(), d[i]["depth"].data_ptr(), d[i]["ht"].data_ptr(),
+                             d[i]["lt"].data_ptr(), H, W, md, intr[i], pose[i])
+    chk.synchronize()
+    worst = assert_maps_equal(chk, cpu)
+    chk.close()
+    cpu.close()
+    runs = []
+    for _ in range(3):   # three passes, each from an empty map (a fresh engine); the median pass counts
+        eng = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
+        batch = eng.make_batch([x["rgb"].data_ptr() for x in d], [x["depth"].data_ptr() for x in d],
+                               [x["ht"].data_ptr() for x in d], [x["lt"].data_ptr() for x in d], H, W, md,
+                               intr, pose)
+        eng.synchronize()
+        eng.totals(reset=True)
+        eng.profile_enable(True, every_frame=True)
+        t0 = time.perf_counter()
+        eng.integrate_device_batch(batch)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        k_us, period_us = eng.profile_read_frames()
+        eng.profile_enable(False)
+        tot = eng.totals()
+        stats = eng.last_frame_stats()
+        runs.append((dt, k_us, period_us, tot, stats))
+        eng.close()
+    dt, k_us, period_us, tot, stats = sorted(runs, key=lambda r: r[0])[1]
+    per = np.sort(period_us[:-1]) if len(period_us) > 1 else np.zeros(1)
+    ks = np.sort(k_us)
+    q = lambda a, p: float(a[min(len(a) - 1, int(p * len(a)))])
+    return dict(workload=f"one pass of the 'room' camera, {cam} intrinsics {W}x{H}, voxel {vs * 1e3:g} mm, "
+                         f"{nframes} frames, 1 deg / frame, from an empty map (no frame seen twice)",
+                frames=nframes, frames_per_s=round(nframes / dt, 1),
+                frame_period_us=dict(p50=round(q(per, .5), 1), p90=round(q(per, .9), 1), p99=round(q(per, .99), 1),
+                                     max=round(float(per[-1]), 1)),
+                k_integrate_us=dict(first_frame=round(float(k_us[0]), 1), p50=round(q(ks, .5), 1),
+                                    p99=round(q(ks, .99), 1), max=round(float(ks[-1]), 1)),
+                allocated_blocks_per_frame=round(tot["allocated_blocks"] / max(tot["frames"], 1), 1),
+                deleted_blocks_per_frame=round(tot["deleted_blocks"] / max(tot["frames"], 1), 1),
+                allocated_blocks_first_frame=None, active_blocks=stats["active_blocks"],
+                map_voxel_bytes=stats["active_blocks"] * 6144,
+                parity=dict(frames=n_par, max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"],
+                            directory="bit-exact"),
+                note="period = start of a frame's k_integrate to the start of the next frame's (HIP events "
+                     "attached to the dispatches); the first frame allocates a whole view")
+
+
+def bench_tsdf_system(frames, md, vs, nframes=3000):
+    """The reference's calling convention end to end, in C++: TSDFSystem::Integrate (deep copy of pageable
+    host images into the queue, modules/tsdf_module.cc:22-37) -> worker thread -> IntegrateBatch ->
+    Flush (ra-slam_amd/host/src/system_bench.cc).  PCIe included; never the headline value."""
+    import subprocess
+    import tempfile
+    exe = ROOT / "ra-slam_amd" / "host" / "build" / "ratsdf_system_bench"
+    lib = Path(os.environ.get("RATSDF_LIB", ROOT / "ra-slam_amd" / "csrc" / "build" / "libratsdf.so"))
+    if not exe.exists():
+        return dict(error="ratsdf_system_bench not built (make -C ra-slam_amd/host)")
+    H, W = frames[0]["depth"].shape
+    use = frames[:24]
+    with tempfile.NamedTemporaryFile(suffix=".bin", dir="/tmp") as fh:
+        fh.write(np.array([H, W, len(use)], dtype=np.int32).tobytes())
+        for f in use:
+            fh.write(np.array(f["pose"], dtype=np.float32).tobytes())
+            fh.write(np.array(f["intrinsics"], dtype=np.float32).tobytes())
+            for k in ("depth", "ht", "lt", "rgb"):
+                fh.write(np.ascontiguousarray(f[k]).tobytes())
+        fh.flush()
+        out = {}
+        for tag, extra in (("with_semantics", []), ("tsdf_only", ["--no-sem"])):
+            r = subprocess.run([str(exe), fh.name, "--lib", str(lib), "--frames", str(nframes), "--voxel", str(vs),
+                                "--max-depth", str(md)] + extra, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return dict(error=(r.stdout + r.stderr)[-400:])
+            out[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    out["note"] = ("ratsdf::TSDFSystem (the reference's class shape) fed from pageable std::vector images by one "
+                   "producer thread; the queue's deep copy is split over 4 threads, the worker hands up to 32 queued "
+                   "frames to one ratsdf_integrate_batch(pinned) call")
     return out
 
 
@@ -276,6 +401,17 @@ def main():
             a.frames_per_step = 30
         if a.cpu_frames == 1080:
             a.cpu_frames = 60
+    if a.config == "flythrough":   # the non-repeating pass as the whole run (1280x720 / 2 mm, a full circle)
+        if not torch.cuda.is_available():
+            raise SystemExit("needs a GPU")
+        n = a.flythrough_frames if a.flythrough_frames != 180 else 360
+        out = bench_flythrough(ratsdf, torch, dev, dev_index, "l515_720p", 0.002, a.max_depth, n,
+                               min(len(os.sched_getaffinity(0)), 16), n_par=8)
+        out = {"metric": "depth+semantic frames/sec integrated @1280x720, 2mm voxels (non-repeating pass)",
+               "value": out["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "higher_is_better": True,
+               "dtype": "f32", "data": "synthetic", "config": {"workload": out["workload"]}, "flythrough": out}
+        print(json.dumps(out))
+        return
     if a.config == "bigmap":
         a.cam, a.voxel = "l515_720p", 0.002
         if a.frames_per_step == 90:
@@ -345,11 +481,11 @@ def main():
         from ratsdf import multi
         if backend == "nccl":
             # deltas of the block directories: what a rank added / deleted since the previous
-            # step, at most 2^16 entries per rank and step (a larger directory or delta raises, it is
-            # never truncated silently); every rank keeps replicas of all directories
-            ex = multi.DirectoryDeltaExchange(capacity=1 << 16, device=dev)
+            # step; the exchange buffers hold a whole block pool (2^block_bits entries), so no directory
+            # or delta can overflow them; every rank keeps replicas of all directories
+            ex = multi.DirectoryDeltaExchange(engine=eng, device=dev)   # capacity = the engine's block pool
         else:  # rehearsal backend (gloo): stage through the host
-            ex = multi.DirectoryDeltaExchange(capacity=1 << 16)
+            ex = multi.DirectoryDeltaExchange(engine=eng)
 
     def exchange():
         if backend == "nccl":
@@ -496,14 +632,20 @@ def main():
     multi = None
     if rank == 0 and world == 1 and a.streams > 1 and not a.shard:
         multi = bench_streams(ratsdf, torch, dev, dev_index, a.streams, a.scene, a.cam, vs, a.max_depth,
-                              min(60, len(frames)), max(a.steps // 2, 4), 3)
+                              min(60, len(frames)), max(a.steps // 2, 4), 3,
+                              cpu_threads=min(len(os.sched_getaffinity(0)), 16))
 
     # ---- the other stream size north_star names, bounded ----------------------------------------
     secondary = None
+    flythrough = None
+    system_path = None
     if rank == 0 and world == 1 and a.config == "vga5mm" and not a.no_secondary and a.cpu_frames > 0:
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        secondary = [bench_secondary(ratsdf, torch, dev, dev_index, a.max_depth,
-                                     min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16"))))]
+        nthr = min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16")))
+        secondary = [bench_secondary(ratsdf, torch, dev, dev_index, a.max_depth, nthr, "hd2mm"),
+                     bench_secondary(ratsdf, torch, dev, dev_index, a.max_depth, nthr, "bigmap")]
+        flythrough = bench_flythrough(ratsdf, torch, dev, dev_index, a.cam, vs, a.max_depth, a.flythrough_frames, nthr)
+        system_path = bench_tsdf_system(frames, a.max_depth, vs)
 
     nframes = a.steps * len(frames)
     if rank == 0:
@@ -555,8 +697,10 @@ def main():
             "cpu_baseline": cpu_baseline,
             "host_image_path": host_path,
             "pinned_h2d_path": pinned_path,
+            "tsdf_system_path": system_path,
             "multi_stream": multi,
             "secondary": secondary,
+            "flythrough": flythrough,
             "parity": parity,
         }
         print(json.dumps(out))

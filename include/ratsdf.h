@@ -181,6 +181,12 @@ int ratsdf_stream(ratsdf_engine* e, void** out_stream);
  * log line around Integrate (modules/tsdf_module.cc:108-112).  HIP engine only. */
 int ratsdf_profile_enable(ratsdf_engine* e, int enable);
 int ratsdf_profile_read(ratsdf_engine* e, double* integrate_ms, int64_t* launches);
+/* enable = 2 times EVERY frame and keeps per-frame records (for latency distributions: a frame whose
+ * view is new costs several times the steady-state frame): k_us[i] = k_integrate time of timed frame
+ * i, period_us[i] = start of frame i's k_integrate to the start of frame i+1's (0 for the last frame of
+ * a drained run of frames; at most 60 000 frames between reads).  *n = frames recorded; at most
+ * `capacity` are copied; the records are cleared. */
+int ratsdf_profile_read_frames(ratsdf_engine* e, float* k_us, float* period_us, int capacity, int* n);
 
 /* VoxelHashTable::NumActiveBlock, voxel_hash.cu:225 */
 int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out);

@@ -967,6 +967,9 @@ int ratsdf_oracle_profile_enable(ratsdf_engine*, int) { return RATSDF_ERR_NOT_IM
 int ratsdf_oracle_profile_read(ratsdf_engine*, double*, int64_t*) {
   return RATSDF_ERR_NOT_IMPLEMENTED;
 }
+int ratsdf_oracle_profile_read_frames(ratsdf_engine*, float*, float*, int, int*) {
+  return RATSDF_ERR_NOT_IMPLEMENTED;
+}
 
 // groups are a device-launch construct of the HIP engine (several maps per launch): no CPU counterpart
 int ratsdf_oracle_group_create(ratsdf_engine* const*, int, ratsdf_group** out) {

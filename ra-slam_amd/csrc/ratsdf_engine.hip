@@ -168,6 +168,8 @@ struct ratsdf_engine {
   uint64_t prof_frame = 0;
   double prof_ms = 0;
   int64_t prof_n = 0;
+  int prof_mode = 1;                     // 1: every 4th frame, sums only; 2: every frame, per-frame records
+  std::vector<float> prof_k_us, prof_period_us;  // mode 2: kernel time of a frame / start-to-start period
 
   int free_all();
   int ensure_image(size_t npix, size_t nranks);
@@ -565,7 +567,8 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   }
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  const bool timed = profiling && (prof_frame++ % 4 == 0);  // sample: events perturb the stream
+  // (sampled: events perturb the stream; mode 2 times every frame, for latency distributions)
+  const bool timed = profiling && (prof_mode == 2 || prof_frame++ % 4 == 0);
   if (timed) {
     if (prof_used == prof_events.size()) {
       hipEvent_t a, b;
@@ -609,7 +612,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
 
   HIPCHK(hipGetLastError());
   pending = true;
-  if (profiling && prof_used >= 4096) return drain_profile();
+  if (profiling && prof_used >= (prof_mode == 2 ? 60000u : 4096u)) return drain_profile();
   return RATSDF_OK;
 }
 
@@ -621,6 +624,14 @@ int ratsdf_engine::drain_profile() {
     HIPCHK(hipEventElapsedTime(&ms, prof_events[i].first, prof_events[i].second));
     prof_ms += ms;
     ++prof_n;
+    if (prof_mode == 2) {
+      prof_k_us.push_back(ms * 1e3f);
+      if (i + 1 < prof_used) {  // consecutive frames: start of this frame's k_integrate to the next one's
+        float gap = 0;
+        HIPCHK(hipEventElapsedTime(&gap, prof_events[i].first, prof_events[i + 1].first));
+        prof_period_us.push_back(gap * 1e3f);
+      }
+    }
   }
   prof_used = 0;
   return RATSDF_OK;
@@ -1008,6 +1019,26 @@ int ratsdf_profile_enable(ratsdf_engine* e, int enable) {
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   const int st = e->drain_profile();
   e->profiling = enable != 0;
+  e->prof_mode = enable == 2 ? 2 : 1;
+  e->prof_k_us.clear();
+  e->prof_period_us.clear();
+  return st;
+}
+
+int ratsdf_profile_read_frames(ratsdf_engine* e, float* k_us, float* period_us, int capacity, int* n) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!e || !n || capacity < 0) return RATSDF_ERR_BAD_ARGUMENT;
+  const int st = e->drain_profile();
+  const int have = (int)e->prof_k_us.size();
+  *n = have;
+  for (int i = 0; i < have && i < capacity; ++i) {
+    if (k_us) k_us[i] = e->prof_k_us[(size_t)i];
+    if (period_us) period_us[i] = (size_t)i < e->prof_period_us.size() ? e->prof_period_us[(size_t)i] : 0.f;
+  }
+  e->prof_k_us.clear();
+  e->prof_period_us.clear();
+  e->prof_ms = 0;
+  e->prof_n = 0;
   return st;
 }
 

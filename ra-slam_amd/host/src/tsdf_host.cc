@@ -2,6 +2,7 @@
 // to the reference's modules/tsdf_module.* and utils/tsdf/voxel_tsdf.cuh).
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -221,7 +222,7 @@ HostBlock HostBlockPool::acquire(size_t bytes) {
 void HostBlockPool::release(const HostBlock& b) {
   {
     std::lock_guard<std::mutex> lock(mtx_);
-    if (free_.size() < 32) {
+    if (free_.size() < 128) {  // (640x480: 4.9 MB each)
       free_.push_back(b);
       return;
     }
@@ -233,12 +234,62 @@ HostBlockPool::~HostBlockPool() {
   for (const HostBlock& b : free_) api_->host_free(b.ptr);
 }
 
+// ---- parallel clone ---------------------------------------------------------------------------
+ParallelCopier::ParallelCopier(int helpers) {
+  for (int i = 0; i < helpers; ++i) threads_.emplace_back(&ParallelCopier::worker, this);
+}
+
+ParallelCopier::~ParallelCopier() {
+  {
+    std::lock_guard<std::mutex> lock(mtx_);
+    stop_ = true;
+  }
+  cv_work_.notify_all();
+  for (auto& t : threads_) t.join();
+}
+
+void ParallelCopier::worker() {
+  std::unique_lock<std::mutex> lock(mtx_);
+  while (true) {
+    while (!stop_ && next_ >= pieces_.size()) cv_work_.wait(lock);
+    if (stop_) return;
+    const Piece p = pieces_[next_++];
+    lock.unlock();
+    memcpy(p.dst, p.src, p.bytes);
+    lock.lock();
+    if (++done_ == pieces_.size()) cv_done_.notify_all();
+  }
+}
+
+void ParallelCopier::copy(const void* const* src, void* const* dst, const size_t* bytes, int n) {
+  // pieces of at most 1 MiB: enough of them for every helper, large enough to amortise the hand-off
+  constexpr size_t kPiece = 1u << 20;
+  std::unique_lock<std::mutex> lock(mtx_);
+  pieces_.clear();
+  next_ = done_ = 0;
+  for (int i = 0; i < n; ++i)
+    for (size_t off = 0; off < bytes[i]; off += kPiece)
+      pieces_.push_back(Piece{static_cast<uint8_t*>(dst[i]) + off, static_cast<const uint8_t*>(src[i]) + off,
+                              std::min(kPiece, bytes[i] - off)});
+  if (pieces_.empty()) return;
+  if (!threads_.empty()) cv_work_.notify_all();
+  while (next_ < pieces_.size()) {  // the caller copies too
+    const Piece p = pieces_[next_++];
+    lock.unlock();
+    memcpy(p.dst, p.src, p.bytes);
+    lock.lock();
+    ++done_;
+  }
+  while (done_ < pieces_.size()) cv_done_.wait(lock);
+}
+
 // ---- TSDFSystem -----------------------------------------------------------------------------
 TSDFSystem::TSDFSystem(float voxel_size, float truncation, float max_depth,
                        const CameraIntrinsics<float>& intrinsics, const SE3<float>& extrinsics,
                        int device, const Api* api)
     : tsdf_(voxel_size, truncation, device, api),
       pool_(&tsdf_.api()),
+      copier_(getenv("RATSDF_COPY_THREADS") ? atoi(getenv("RATSDF_COPY_THREADS")) : 3),
       max_depth_(max_depth),
       intrinsics_(intrinsics),
       cam_T_posecam_(extrinsics),
@@ -267,12 +318,13 @@ void TSDFSystem::Integrate(const SE3<float>& posecam_T_world, const Image& rgb, 
   in->block = pool_.acquire(npix * 16);
   in->has_sem = !(ht.empty() || lt.empty());
   uint8_t* b = static_cast<uint8_t*>(in->block.ptr);
-  memcpy(b, depth.data, npix * 4);
-  if (in->has_sem) {
-    memcpy(b + npix * 4, ht.data, npix * 4);
-    memcpy(b + npix * 8, lt.data, npix * 4);
+  {
+    const void* src[4] = {depth.data, rgb.data, ht.data, lt.data};
+    void* dst[4] = {b, b + npix * 12, b + npix * 4, b + npix * 8};
+    const size_t bytes[4] = {npix * 4, npix * 3, npix * 4, npix * 4};
+    std::lock_guard<std::mutex> lock(mtx_copy_);
+    copier_.copy(src, dst, bytes, in->has_sem ? 4 : 2);
   }
-  memcpy(b + npix * 12, rgb.data, npix * 3);
   {
     std::lock_guard<std::mutex> lock(mtx_queue_);
     inputs_.push(std::move(in));

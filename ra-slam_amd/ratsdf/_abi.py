@@ -68,7 +68,7 @@ assert VOXEL_SEGM_DTYPE.itemsize == 20 and RGBW_DTYPE.itemsize == 4
 SYMBOLS = [
     "create", "create_ex", "destroy", "integrate", "integrate_device", "integrate_device_batch",
     "integrate_batch", "host_alloc", "host_free", "synchronize", "stream",
-    "profile_enable", "profile_read", "totals",
+    "profile_enable", "profile_read", "profile_read_frames", "totals",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "raycast", "raycast_device", "gather_valid_mesh", "download_all_mesh",
     "export_directory_device", "group_create", "group_destroy", "group_size",
@@ -114,6 +114,8 @@ class Library:
         self.fn["stream"].argtypes = [vp, C.POINTER(vp)]
         self.fn["profile_enable"].argtypes = [vp, C.c_int]
         self.fn["profile_read"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        self.fn["profile_read_frames"].argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                                    C.POINTER(C.c_int)]
         self.fn["totals"].argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
         self.fn["num_active_blocks"].argtypes = [vp, C.POINTER(C.c_int32)]
         self.fn["last_frame_stats"].argtypes = [vp, C.POINTER(FrameStats)]
@@ -312,8 +314,19 @@ class Engine:
         _check(self.lib.fn["stream"](self._h, C.byref(s)), "stream")
         return s.value or 0
 
-    def profile_enable(self, on=True):
-        _check(self.lib.fn["profile_enable"](self._h, 1 if on else 0), "profile_enable")
+    def profile_enable(self, on=True, every_frame=False):
+        """HIP events on k_integrate: every 4th frame (sums), or every frame with per-frame records"""
+        _check(self.lib.fn["profile_enable"](self._h, (2 if every_frame else 1) if on else 0), "profile_enable")
+
+    def profile_read_frames(self, capacity=60000):
+        """(k_integrate us per frame, start-to-start period us per frame) as float32 arrays"""
+        k = np.zeros(capacity, dtype=np.float32)
+        p = np.zeros(capacity, dtype=np.float32)
+        n = C.c_int()
+        _check(self.lib.fn["profile_read_frames"](self._h, _ptr(k, C.c_float), _ptr(p, C.c_float), capacity,
+                                                  C.byref(n)), "profile_read_frames")
+        m = min(n.value, capacity)
+        return k[:m], p[:m]
 
     def profile_read(self):
         """(summed k_integrate milliseconds, launches) since the last read."""

@@ -100,24 +100,50 @@ class DirectoryDeltaExchange(DirectoryExchange):
     the block directory delta ... every N frames"): a rank sends the entries it has added (or whose
     pool index changed) and the positions it has deleted; every rank keeps a replica of every rank's
     directory and applies the deltas.  The first exchange is a full one by construction (everything
-    is new).  Wire format per rank: counts {added, deleted}, then `capacity` 12-byte entries
-    (the added ones first, then the deleted ones: position only).  result() returns the replicas in
-    DirectoryExchange.result()'s form (entries sorted by position), so multi.query() takes either.
+    is new).  result() returns the replicas in DirectoryExchange.result()'s form (entries sorted by
+    position), so multi.query() takes either.
 
-    The engine still exports its whole directory into a device buffer per exchange (one small
-    kernel); the set differences are torch ops on that device, only the deltas travel."""
+    Wire format per rank, ONE collective: int32 {added, deleted} followed by `delta_capacity`
+    12-byte entries (the added ones first, then the deleted ones: position only).
 
-    def __init__(self, capacity=None, device=None, engine=None):
+    Nothing on the exchange path waits for the device:
+      * the engine exports its whole directory into a pool-sized device buffer (one small kernel; the
+        buffer holds 2^block_bits entries, so the export cannot overflow and never touches the engine's
+        sticky error);
+      * the delta is taken with fixed-shape tensor ops on that device (sort, searchsorted, cumulative
+        sums, scatter into the payload) -- no .item(), no boolean-mask indexing, whose result sizes the
+        host would have to read;
+      * the counts travel inside the payload; a delta that does not fit `delta_capacity` is clamped in
+        the buffer and its TRUE size is what travels, so every rank learns of the overflow from the
+        same collective and raises the same OverflowError -- no rank is left waiting in a collective;
+      * the received deltas are applied to the replicas one exchange LATER (or when result() is
+        called): by then the collective has long finished, so reading its counts does not stall the
+        host while the next batch of frames waits to be enqueued.
+    """
+
+    def __init__(self, capacity=None, device=None, engine=None, delta_capacity=None):
         super().__init__(capacity, device, engine)
         torch = self.torch
         dev = device if device is not None else "cpu"
-        self.count = torch.zeros(2, dtype=torch.int32, device=dev)            # {added, deleted}
-        self.counts = torch.zeros(self.world * 2, dtype=torch.int32, device=dev)
-        self.full = torch.zeros(self.capacity * 3, dtype=torch.int32, device=dev)  # export target
-        self.full_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._prev = torch.zeros((0, 3), dtype=torch.int32, device=dev)       # my directory as last sent
-        self._replica = [torch.zeros((0, 3), dtype=torch.int32, device=dev) for _ in range(self.world)]
+        i32 = dict(dtype=torch.int32, device=dev)
+        # the payload: by default a quarter of the pool (a delta is a frame batch's worth of blocks).  The
+        # FIRST exchange carries whole directories and uses pool-sized buffers of its own, once.
+        self.delta_capacity = int(delta_capacity) if delta_capacity else max(self.capacity // 4, 1024)
+        self.delta_capacity = min(self.delta_capacity, self.capacity)
+        self._i32 = i32
+        self.full = torch.zeros(self.capacity * 3, **i32)          # export target (whole directory)
+        self.full_count = torch.zeros(1, **i32)
+        self._first = True
+        self._C = self.capacity                                    # payload entries of the exchange in hand
+        self.send = torch.zeros(2 + 3 * (self._C + 1), **i32)      # header, C entries, one dump slot
+        self.recv2 = [torch.zeros(self.world * (2 + 3 * (self._C + 1)), **i32)]
+        self._slot = 0
+        self._todo = None                                          # received, not yet applied
+        self._prev = torch.zeros((self.capacity, 3), **i32)        # my directory as last sent, sorted
+        self._prev_key = torch.full((self.capacity,), 2 ** 62, dtype=torch.int64, device=dev)
+        self._replica = [torch.zeros((0, 3), **i32) for _ in range(self.world)]
         self.last_sent = (0, 0)
+        self._last_counts = None
 
     def _pos_key(self, rows):
         """int64 key of the block position (x, y, z int16 in the first 6 bytes of an entry)."""
@@ -127,48 +153,80 @@ class DirectoryDeltaExchange(DirectoryExchange):
     def fill_from_engine_device(self, engine):
         engine.export_directory_device(self.full.data_ptr(), self.capacity, self.full_count.data_ptr())
         self._engine_stream = self.torch.cuda.ExternalStream(engine.stream(), device=self.device)
-        self._pending_full = True
 
     def fill_from_numpy(self, blocks):
         n = len(blocks)
-        if n > self.capacity:
-            raise OverflowError(f"block directory has {n} entries, exchange capacity is {self.capacity}")
+        if n > self.capacity:   # (cannot happen with the default capacity = the engine's pool)
+            raise ValueError(f"block directory has {n} entries, the export buffer holds {self.capacity}")
         raw = np.zeros(self.capacity * 3, dtype=np.int32)
         raw[:n * 3] = np.ascontiguousarray(blocks).view(np.int32).reshape(-1)
         self.full.copy_(self.torch.from_numpy(raw))
         self.full_count.fill_(n)
         self._engine_stream = None
-        self._pending_full = True
 
     def _make_delta(self):
-        """send / count from (current export) minus (previous export)."""
+        """payload from (current export) minus (previous export); fixed shapes, no host read."""
         torch = self.torch
-        n = int(self.full_count.item())
-        if n > self.capacity:
-            raise OverflowError(f"block directory has {n} entries, exchange capacity is {self.capacity}")
-        now = self.full[:n * 3].reshape(n, 3)
-        kn, kp = self._pos_key(now), self._pos_key(self._prev)
-        order = torch.argsort(kn)
-        now, kn = now[order], kn[order]
-        if len(kp):
-            at = torch.searchsorted(kp, kn).clamp_(max=len(kp) - 1)
-            same_pos = kp[at] == kn
-            unchanged = same_pos & (self._prev[at, 2] == now[:, 2]) & (self._prev[at, 1] == now[:, 1])
-            added = now[~unchanged]
-            at2 = torch.searchsorted(kn, kp).clamp_(max=max(len(kn) - 1, 0))
-            gone = self._prev[~(kn[at2] == kp)] if len(kn) else self._prev
-        else:
-            added, gone = now, self._prev
-        na, nd = len(added), len(gone)
-        if na + nd > self.capacity:
-            raise OverflowError(f"directory delta of {na} + {nd} entries, exchange capacity is {self.capacity}")
-        self.send.zero_()
-        self.send[:na * 3] = added.reshape(-1)
-        self.send[na * 3:(na + nd) * 3] = gone.reshape(-1)
-        self.count[0] = na
-        self.count[1] = nd
+        cap, C = self.capacity, self._C
+        BIG = 2 ** 62
+        rows = self.full.reshape(cap, 3)
+        valid = torch.arange(cap, device=rows.device) < self.full_count.to(torch.int64)
+        key = torch.where(valid, self._pos_key(rows), torch.full_like(self._prev_key, BIG))
+        key, order = torch.sort(key)
+        now = rows[order]
+        valid = key < BIG
+        # added / changed: my position is new, or its pool index / offset word differs
+        at = torch.searchsorted(self._prev_key, key).clamp_(max=cap - 1)
+        same = (self._prev_key[at] == key) & (self._prev[at, 2] == now[:, 2]) & (self._prev[at, 1] == now[:, 1])
+        add = valid & ~same
+        # gone: a previous position that no longer exists
+        pvalid = self._prev_key < BIG
+        at2 = torch.searchsorted(key, self._prev_key).clamp_(max=cap - 1)
+        gone = pvalid & ~(key[at2] == self._prev_key)
+        na, nd = add.sum(), gone.sum()
+        # scatter into the payload: added entries at [0, na), deleted at [na, na + nd); whatever does not
+        # fit goes to the dump slot C (the header carries the true counts, so everybody sees the overflow)
+        pa = torch.cumsum(add, 0) - 1
+        pd = na + torch.cumsum(gone, 0) - 1
+        body = self.send[2:].reshape(C + 1, 3)
+        body.zero_()
+        ia = torch.where(add & (pa < C), pa, torch.full_like(pa, C))
+        body.index_copy_(0, ia, now)
+        idl = torch.where(gone & (pd < C), pd, torch.full_like(pd, C))
+        body.index_copy_(0, idl, self._prev)
+        self.send[0] = na.to(torch.int32)
+        self.send[1] = nd.to(torch.int32)
         self._prev = now.clone()
-        self.last_sent = (na, nd)
+        self._prev_key = key
+
+    def _apply(self, recv, C):
+        """host side of an exchange that has completed: counts, overflow, replicas"""
+        torch = self.torch
+        rows = recv.reshape(self.world, 2 + 3 * (C + 1))
+        counts = rows[:, :2].cpu()
+        self._last_counts = counts
+        over = [(r, int(counts[r, 0]), int(counts[r, 1])) for r in range(self.world)
+                if int(counts[r, 0]) + int(counts[r, 1]) > C]
+        if over:   # every rank sees the same counts: every rank raises, nobody is left in a collective
+            r, na, nd = over[0]
+            raise OverflowError(f"directory delta of rank {r}: {na} added + {nd} deleted entries, "
+                                f"delta_capacity is {C}")
+        self.last_sent = (int(counts[self.rank, 0]), int(counts[self.rank, 1]))
+        for r in range(self.world):
+            na, nd = int(counts[r, 0]), int(counts[r, 1])
+            body = rows[r, 2:].reshape(C + 1, 3)
+            rep = self._replica[r]
+            drop = body[:na + nd]                      # replaced and deleted positions
+            if len(rep) and len(drop):
+                rep = rep[~torch.isin(self._pos_key(rep), self._pos_key(drop))]
+            rep = torch.cat([rep, body[:na].clone()])
+            self._replica[r] = rep[torch.argsort(self._pos_key(rep))]
+
+    def flush(self):
+        """apply what has been received (reads the last collective's counts: waits for it)"""
+        if self._todo is not None:
+            (todo, C), self._todo = self._todo, None
+            self._apply(todo, C)
 
     def all_gather(self):
         torch = self.torch
@@ -178,29 +236,28 @@ class DirectoryDeltaExchange(DirectoryExchange):
             ev.record(es)
             torch.cuda.current_stream(self.device).wait_event(ev)
         self._make_delta()
+        recv = self.recv2[self._slot % len(self.recv2)]
+        self._slot += 1
         if self.world == 1:
-            self.recv.copy_(self.send)
-            self.counts.copy_(self.count)
+            recv.copy_(self.send)
         else:
-            self.dist.all_gather_into_tensor(self.recv, self.send)
-            self.dist.all_gather_into_tensor(self.counts, self.count)
+            self.dist.all_gather_into_tensor(recv, self.send)
         if es is not None:  # the engine may not overwrite the export buffer before the delta was taken
             ev2 = torch.cuda.Event()
             ev2.record(torch.cuda.current_stream(self.device))
             es.wait_event(ev2)
-        counts = self.counts.reshape(self.world, 2).cpu()
-        rows = self.recv.reshape(self.world, self.capacity, 3)
-        for r in range(self.world):
-            na, nd = int(counts[r, 0]), int(counts[r, 1])
-            rep = self._replica[r]
-            drop = torch.cat([rows[r, :na], rows[r, na:na + nd]])  # replaced and deleted positions
-            if len(rep) and len(drop):
-                rep = rep[~torch.isin(self._pos_key(rep), self._pos_key(drop))]
-            rep = torch.cat([rep, rows[r, :na]])
-            self._replica[r] = rep[torch.argsort(self._pos_key(rep))]
+        self.flush()          # the PREVIOUS exchange (finished long ago): no stall
+        self._todo = (recv, self._C)
+        if self._first:       # from now on: deltas, in the smaller payload buffers
+            self._first = False
+            self.flush()      # (the pool-sized buffers are released)
+            self._C = self.delta_capacity
+            self.send = torch.zeros(2 + 3 * (self._C + 1), **self._i32)
+            self.recv2 = [torch.zeros(self.world * (2 + 3 * (self._C + 1)), **self._i32) for _ in range(2)]
 
     def result(self):
         """List (one per rank) of structured BLOCK_DTYPE arrays, sorted by block position."""
+        self.flush()
         return [np.ascontiguousarray(rep.cpu().numpy()).reshape(-1).view(BLOCK_DTYPE) for rep in self._replica]
 
 
@@ -256,6 +313,35 @@ def query(engine, bounds, per_rank, device=None):
     dist.all_gather_into_tensor(recv, send)
     rows = recv.cpu().numpy().reshape(world, width)
     return np.concatenate([rows[r, :nrec[r] * 4] for r in range(world)]).view(VOXEL_TSDF_DTYPE)
+
+
+def download_all(engine, device=None):
+    """TSDFSystem::DownloadAll (modules/tsdf_module.cc:57-64) across the ranks of a sharded map: every
+    rank gets the 20-byte records (VOXEL_SEGM_DTYPE, GatherValidSemantic) of ALL ranks' blocks,
+    concatenated by rank, the reference's order (ascending hash-entry index) within a rank.  Exact by
+    construction: blocks are disjoint between ranks and a record depends on its own block only.
+    (Ray casting and marching cubes read NEIGHBOUR blocks -- voxel_tsdf.cu:278-374,561-715 -- and need
+    the halo plan of DESIGN.md section 6 instead.)"""
+    import torch
+    import torch.distributed as dist
+    from ._abi import VOXEL_SEGM_DTYPE
+    mine = engine.gather_valid_semantic()
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return mine
+    dev = device if device is not None else "cpu"
+    n = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
+    ns = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(ns, n)
+    ns = [int(v) for v in ns.cpu()]
+    width = max(ns) * 5
+    send = torch.zeros(max(width, 1), dtype=torch.float32, device=dev)
+    if len(mine):
+        send[:len(mine) * 5].copy_(torch.from_numpy(mine.view(np.float32).copy()))
+    recv = torch.empty(world * max(width, 1), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    rows = recv.cpu().numpy().reshape(world, max(width, 1))
+    return np.concatenate([rows[r, :ns[r] * 5] for r in range(world)]).view(VOXEL_SEGM_DTYPE)
 
 
 def check_sharded_directories(per_rank, slab_bits=2):

@@ -91,6 +91,12 @@ def _worker(rank, world, port, mode, ret):
                 seen += len(kg)
             assert seen > 0
             # a directory that does not fit the exchange buffers is reported, not truncated
+            # DownloadAll across the shards == the concatenation of every rank's GatherValidSemantic
+            mine_rec = eng.gather_valid_semantic()
+            all_rec = multi.download_all(eng)
+            sizes = [len(b) * 512 for b in per_rank]
+            assert len(all_rec) == sum(sizes) and len(mine_rec) == sizes[rank]
+            assert np.array_equal(all_rec[sum(sizes[:rank]):sum(sizes[:rank + 1])], mine_rec)
             small = multi.DirectoryExchange(capacity=8)
             small.fill_from_numpy(blocks)
             small.all_gather()
@@ -107,7 +113,7 @@ def _worker(rank, world, port, mode, ret):
             # a fraction of the directory travels.
             def by_pos(b):
                 return b[np.lexsort((b["z"], b["y"], b["x"]))]
-            dx = multi.DirectoryDeltaExchange(capacity=4096)
+            dx = multi.DirectoryDeltaExchange(capacity=4096, delta_capacity=1024)
             more = [synthetic.frame("room", 20 * rank + 4 + i, scale=0.25) for i in range(6)]
             sent = []
             for step in range(4):
@@ -123,6 +129,24 @@ def _worker(rank, world, port, mode, ret):
                     eng.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
             assert sent[0][0] == sent[0][1]                      # first exchange: everything is new
             assert all(0 < d < 0.7 * n for d, n in sent[1:]), sent   # then only what changed
+            # A delta that does not fit the payload: ONE rank's delta is too large, yet EVERY rank raises
+            # (the true counts travel in the collective) -- nobody hangs in an all-gather.
+            tiny = multi.DirectoryDeltaExchange(capacity=4096, delta_capacity=4)
+            _, mine = eng.dump_directory()
+            tiny.fill_from_numpy(mine)
+            tiny.all_gather()              # first exchange: whole directories, pool-sized buffers
+            tiny.result()
+            f = synthetic.frame("room", 20 * rank + 60, scale=0.25)   # a view far from the ones before
+            if rank == 0:                  # only rank 0's map changes by more than 4 entries
+                eng.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+            _, mine = eng.dump_directory()
+            tiny.fill_from_numpy(mine)
+            tiny.all_gather()
+            try:
+                tiny.result()
+                raise AssertionError(f"rank {rank}: oversized delta accepted")
+            except OverflowError as e:
+                assert "rank 0" in str(e)
         dist.barrier()
         ret[rank] = "ok"
     finally:
@@ -164,3 +188,63 @@ def test_owner_function_matches_engine(make_oracle):
             expect = int((multi.owner_of(pos[:, 0], world, slab) == r).sum())
             # one insertion per bucket per pass: allow a few deferred blocks
             assert expect - 8 <= len(b) <= expect
+
+
+def _big_worker(rank, world, port, ret):
+    """bench.py's N > 1 control flow with directories larger than 2^16 entries (the 416 MB bench map has
+    67 682 blocks): engine-sized exchange buffers, first exchange = whole directories, then deltas."""
+    sys.path.insert(0, str(ROOT / "ra-slam_amd"))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from oracle_binding import load_oracle
+    from ratsdf import multi
+    from ratsdf._abi import Engine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = Engine(load_oracle(), 0.01, 0.06, shard_rank=rank, shard_count=world, shard_slab_bits=2)
+        n_side = 48                               # 48^3 = 110 592 blocks asked for, half per rank
+        g = np.arange(n_side, dtype=np.int16)
+        pos = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+        for _ in range(4):                        # (one insertion per bucket per pass)
+            eng.test_allocate(pos)
+        _, blocks = eng.dump_directory()
+        assert len(blocks) > 40000, len(blocks)
+        ex = multi.DirectoryDeltaExchange(engine=eng)      # what bench.py builds
+        assert ex.capacity == 1 << eng.block_bits
+        ex.fill_from_numpy(blocks)
+        ex.all_gather()
+        per_rank = ex.result()
+        assert sum(len(b) for b in per_rank) > (1 << 16)
+        assert multi.check_sharded_directories(per_rank, slab_bits=2) == sum(len(b) for b in per_rank)
+        eng.test_delete(pos[rank::97])            # a small change ...
+        _, blocks2 = eng.dump_directory()
+        ex.fill_from_numpy(blocks2)
+        ex.all_gather()
+        per_rank2 = ex.result()
+        assert len(per_rank2[rank]) == len(blocks2) < len(blocks)
+        assert 0 < sum(ex.last_sent) < 2000       # ... travels as a small delta
+        dist.barrier()
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_directories_beyond_64k_entries(oracle_lib):
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_big_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("rank hung")
+        assert p.exitcode == 0
+    assert dict(ret) == {0: "ok", 1: "ok"}
