@@ -84,7 +84,9 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
   }
   FrameCtl* F = &ctl->fr[par];
   FrameCtl* Fp = &ctl->fr[par ^ 1u];
-  auto gate = [&]() { return carve_resolve_gate(tab, cb, ctl, Fp); };  // uniform per workgroup
+  // (diagnostic build, RATSDF_DEBUG=20: workgroup 0 never publishes -- the waiters' bounded wait is what
+  // tests/test_gpu_errors.py::test_in_launch_waits_are_bounded exercises)
+  auto gate = [&]() { return carve_resolve_gate(tab, cb, ctl, Fp, RATSDF_DBG(P, 20)); };  // uniform per workgroup
   if (blockIdx.x >= n_vis_wg + n_cons_wg) {
     if (RATSDF_DBG(P, 12)) return;  // diagnostic ablations 3 / 11 / 12: skip one role
     if (gate() == kGateExpired) return;  // uniform
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((am
   }
   if (blockIdx.x == 0) {  // the frame's serial role
     const uint32_t nwords = ((uint32_t)(J->P.W * J->P.H) * (uint32_t)J->P.S + 31u) / 32u;
-    serial_workgroup(E, par, nwords, role_lds);
+    serial_workgroup(E, par, nwords, role_lds, RATSDF_DBG(J->P, 21));
   }
 }
 

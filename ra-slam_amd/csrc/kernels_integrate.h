@@ -341,7 +341,10 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
 
 // workgroup 0 of a fused launch: the role, then the hand-off (every storing wave drained, barrier,
 // one agent-scope release, the flag)
-__device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint32_t nwords, uint32_t* lds) {
+// (`withhold`: diagnostic build only, RATSDF_DEBUG=21 -- the flag never goes out, the consumers' bounded
+// waits expire: tests/test_gpu_errors.py::test_in_launch_waits_are_bounded)
+__device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint32_t nwords, uint32_t* lds,
+                                                 bool withhold = false) {
   const uint32_t how = serial_role256(E, par, nwords, lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -350,7 +353,7 @@ __device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    st_agent(&E->ctl->fr[par].serial_done, how);
+    if (!withhold) st_agent(&E->ctl->fr[par].serial_done, how);
   }
 }
 
@@ -799,7 +802,7 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((am
     return;
   }
   if (blockIdx.x == 0)
-    serial_workgroup(E, A.par, ((uint32_t)(P.W * P.H) * (uint32_t)P.S + 31u) / 32u, role_lds);
+    serial_workgroup(E, A.par, ((uint32_t)(P.W * P.H) * (uint32_t)P.S + 31u) / 32u, role_lds, RATSDF_DBG(P, 21));
 }
 
 }  // namespace ratsdf

@@ -35,10 +35,21 @@ using namespace ratsdf;
 struct DeviceGuard {
   int prev = -1;
   bool changed = false;
+  bool selected = true;  // false: the engine's device could not be made current -- every entry point
+                         // then returns RATSDF_ERR_DEVICE instead of working on the caller's device
+                         // with another device's pointers
   explicit DeviceGuard(int device) {
-    if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device)
+    if (device < 0) return;  // (no engine: the entry point reports the bad argument itself)
+    if (hipGetDevice(&prev) != hipSuccess) {
+      selected = false;
+      return;
+    }
+    if (prev != device) {
       changed = hipSetDevice(device) == hipSuccess;
+      selected = changed;
+    }
   }
+  bool ok() const { return selected; }
   ~DeviceGuard() {
     if (changed) (void)hipSetDevice(prev);
   }
@@ -671,6 +682,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RATSDF_ERR_NO_DEVICE;
   if (cfg->device < 0 || cfg->device >= ndev) return RATSDF_ERR_BAD_ARGUMENT;
   DeviceGuard guard(cfg->device);  // the caller's current device is restored on return
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   ratsdf_engine* e = new (std::nothrow) ratsdf_engine();
   if (!e) return RATSDF_ERR_DEVICE;
   e->device = cfg->device;
@@ -818,6 +830,7 @@ int ratsdf_create(float voxel_size, float truncation, int device, ratsdf_engine*
 
 int ratsdf_destroy(ratsdf_engine* e) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   e->free_all();
   delete e;
@@ -828,6 +841,7 @@ int ratsdf_integrate_device(ratsdf_engine* e, const void* d_rgb, const void* d_d
                             const void* d_ht, const void* d_lt, int height, int width,
                             float max_depth, const ratsdf_intrinsics* K, const ratsdf_pose* T) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !d_rgb || !d_depth || !K || !T || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   if (!finite_frame(*K, *T, max_depth)) return RATSDF_ERR_BAD_ARGUMENT;
@@ -841,6 +855,7 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
                                   const void* const* d_lt, int height, int width, float max_depth,
                                   const ratsdf_intrinsics* K, const ratsdf_pose* T) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || n < 0 || (n > 0 && (!d_rgb || !d_depth || !K || !T)) || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   for (int i = 0; i < n; ++i)
@@ -868,6 +883,7 @@ int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, c
                      const float* lt, int height, int width, float max_depth,
                      const ratsdf_intrinsics* K, const ratsdf_pose* T) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !rgb || !depth || !K || !T || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   if (!finite_frame(*K, *T, max_depth)) return RATSDF_ERR_BAD_ARGUMENT;
@@ -897,6 +913,7 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
                            const float* const* lt, int height, int width, float max_depth,
                            const ratsdf_intrinsics* K, const ratsdf_pose* T, int pinned) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || n < 0 || (n > 0 && (!rgb || !depth || !K || !T)) || height <= 0 || width <= 0)
     return RATSDF_ERR_BAD_ARGUMENT;
   for (int i = 0; i < n; ++i)
@@ -1002,6 +1019,7 @@ int ratsdf_host_free(void* p) {
 
 int ratsdf_synchronize(ratsdf_engine* e) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   return e->sticky();
@@ -1009,6 +1027,7 @@ int ratsdf_synchronize(ratsdf_engine* e) {
 
 int ratsdf_stream(ratsdf_engine* e, void** out) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   *out = (void*)e->stream;
   return RATSDF_OK;
@@ -1016,6 +1035,7 @@ int ratsdf_stream(ratsdf_engine* e, void** out) {
 
 int ratsdf_profile_enable(ratsdf_engine* e, int enable) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   const int st = e->drain_profile();
   e->profiling = enable != 0;
@@ -1027,6 +1047,7 @@ int ratsdf_profile_enable(ratsdf_engine* e, int enable) {
 
 int ratsdf_profile_read_frames(ratsdf_engine* e, float* k_us, float* period_us, int capacity, int* n) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !n || capacity < 0) return RATSDF_ERR_BAD_ARGUMENT;
   const int st = e->drain_profile();
   const int have = (int)e->prof_k_us.size();
@@ -1044,6 +1065,7 @@ int ratsdf_profile_read_frames(ratsdf_engine* e, float* k_us, float* period_us, 
 
 int ratsdf_profile_read(ratsdf_engine* e, double* ms, int64_t* launches) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   const int st = e->drain_profile();
   if (ms) *ms = e->prof_ms;
@@ -1055,6 +1077,7 @@ int ratsdf_profile_read(ratsdf_engine* e, double* ms, int64_t* launches) {
 
 int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int32_t nf = 0;
@@ -1066,6 +1089,7 @@ int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out) {
 
 int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   HIPCHK(hipMemcpyAsync(out, e->d_stats, sizeof(*out), hipMemcpyDeviceToHost, e->stream));
@@ -1076,6 +1100,7 @@ int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
 // diagnostic: per-wave stamps of the LAST k_integrate launch (stamps build only)
 extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   static unsigned long long* buf = nullptr;
   const size_t n = 16384 * 8;
   if (enable) {
@@ -1138,6 +1163,7 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
 // diagnostic: prints the accumulated phase stamps of the single-workgroup kernels (stamps build only)
 extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   unsigned long long t[32];
   unsigned long long tot[5];
   HIPCHK(hipMemcpyAsync(t, e->ctl->stamps, sizeof(t), hipMemcpyDeviceToHost, e->stream));
@@ -1159,6 +1185,7 @@ extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
 
 int ratsdf_totals(ratsdf_engine* e, int64_t* out5, int reset) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   unsigned long long t[5] = {0, 0, 0, 0, 0};
@@ -1231,6 +1258,7 @@ static inline int16_t host_f2s(float f) {  // static_cast<short>, BoundingCube::
 
 int ratsdf_query(ratsdf_engine* e, const ratsdf_bounds* b, ratsdf_voxel_tsdf** out, size_t* n) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !b || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   const float scale = (float)(1. / e->vs);  // volumn.Scale<short>(1. / voxel_size_), voxel_tsdf.cu:534
@@ -1243,6 +1271,7 @@ int ratsdf_query(ratsdf_engine* e, const ratsdf_bounds* b, ratsdf_voxel_tsdf** o
 
 int ratsdf_gather_valid(ratsdf_engine* e, ratsdf_voxel_tsdf** out, size_t* n) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
@@ -1252,6 +1281,7 @@ int ratsdf_gather_valid(ratsdf_engine* e, ratsdf_voxel_tsdf** out, size_t* n) {
 
 int ratsdf_gather_valid_semantic(ratsdf_engine* e, ratsdf_voxel_segm** out, size_t* n) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !out || !n) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
@@ -1261,6 +1291,7 @@ int ratsdf_gather_valid_semantic(ratsdf_engine* e, ratsdf_voxel_segm** out, size
 
 int ratsdf_download_all(ratsdf_engine* e, const char* path) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !path) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   ratsdf_voxel_segm* buf = nullptr;
@@ -1286,6 +1317,7 @@ int ratsdf_free_buffer(void* p) {
 int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
                           const ratsdf_pose* T, float max_depth, void* d_rgba, void* d_normal) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !K || !T || height <= 0 || width <= 0 || !(max_depth > 0))
     return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
@@ -1308,6 +1340,7 @@ int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int heig
 int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
                    const ratsdf_pose* T, float max_depth, uint8_t* rgba, uint8_t* normal) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || height <= 0 || width <= 0) return RATSDF_ERR_BAD_ARGUMENT;
   const size_t bytes = (size_t)height * width * 4;
   uint8_t* d = nullptr;
@@ -1342,6 +1375,7 @@ static int mask_positions(ratsdf_engine* e, const uint32_t* mask, size_t n, uint
 int ratsdf_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_vertices,
                              int32_t** indices, size_t* n_triangles, float** vertex_prob) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !vertices || !n_vertices || !indices || !n_triangles || !vertex_prob)
     return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
@@ -1419,6 +1453,7 @@ int ratsdf_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_verti
 
 int ratsdf_download_all_mesh(ratsdf_engine* e, const char* vp, const char* ip, const char* pp) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !vp || !ip || !pp) return RATSDF_ERR_BAD_ARGUMENT;
   float *v = nullptr, *pr = nullptr;
   int32_t* idx = nullptr;
@@ -1448,6 +1483,7 @@ int ratsdf_download_all_mesh(ratsdf_engine* e, const char* vp, const char* ip, c
 int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t capacity,
                                    void* d_count) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !d_blocks || capacity < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
@@ -1469,6 +1505,7 @@ static int upload_s3(ratsdf_engine* e, const int16_t* src, int32_t n, int16_t** 
 
 int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || (!bp && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return e->sticky();
@@ -1494,6 +1531,7 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
 
 int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || (!bp && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   // keep the first occurrence of every position (a repeated Delete is a no-op in list order)
@@ -1524,6 +1562,7 @@ int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
 int ratsdf_test_retrieve(ratsdf_engine* e, const int16_t* pts, int32_t n, ratsdf_rgbw* rgbw,
                          float* tsdf, float* prob, ratsdf_block* blocks) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || (!pts && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return RATSDF_OK;
@@ -1553,6 +1592,7 @@ int ratsdf_test_retrieve(ratsdf_engine* e, const int16_t* pts, int32_t n, ratsdf
 int ratsdf_test_assign_rgbw(ratsdf_engine* e, const int16_t* pts, const ratsdf_rgbw* vals,
                             int32_t n) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || ((!pts || !vals) && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return RATSDF_OK;
@@ -1573,6 +1613,7 @@ int ratsdf_test_assign_rgbw(ratsdf_engine* e, const int16_t* pts, const ratsdf_r
 int ratsdf_dump_directory(ratsdf_engine* e, int32_t** entry_index, ratsdf_block** blocks,
                           size_t* n) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !entry_index || !blocks || !n) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);
@@ -1604,6 +1645,7 @@ int ratsdf_dump_directory(ratsdf_engine* e, int32_t** entry_index, ratsdf_block*
 int ratsdf_dump_voxels(ratsdf_engine* e, const int32_t* pool_idx, int32_t n, float* tsdf,
                        ratsdf_rgbw* rgbw, float* prob) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || (!pool_idx && n > 0) || n < 0) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return RATSDF_OK;
@@ -1628,6 +1670,7 @@ int ratsdf_dump_voxels(ratsdf_engine* e, const int32_t* pool_idx, int32_t n, flo
 
 int ratsdf_dump_heap(ratsdf_engine* e, int32_t* num_free, int32_t* heap) {
   DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (num_free)
@@ -1735,6 +1778,7 @@ int ratsdf_group_create(ratsdf_engine* const* engines, int n, ratsdf_group** out
       if (engines[j] == a) return RATSDF_ERR_BAD_ARGUMENT;
   }
   DeviceGuard guard(engines[0]->device);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   ratsdf_group* g = new (std::nothrow) ratsdf_group();
   if (!g) return RATSDF_ERR_DEVICE;
   g->device = engines[0]->device;
@@ -1778,6 +1822,7 @@ int ratsdf_group_create(ratsdf_engine* const* engines, int n, ratsdf_group** out
 int ratsdf_group_destroy(ratsdf_group* g) {
   if (!g) return RATSDF_ERR_BAD_ARGUMENT;
   DeviceGuard guard(g->device);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   g->free_all();
   delete g;
   return RATSDF_OK;
@@ -1803,6 +1848,7 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
   for (size_t i = 0; i < (size_t)n * S; ++i)
     if (!d_rgb[i] || !d_depth[i] || !finite_frame(K[i], T[i], max_depth)) return RATSDF_ERR_BAD_ARGUMENT;
   DeviceGuard guard(g->device);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   ratsdf_engine* e0 = g->eng[0];
   if (npix * (size_t)e0->S >= 0xFFFFFFFFull) return RATSDF_ERR_BAD_ARGUMENT;
   for (ratsdf_engine* e : g->eng) {
@@ -1876,6 +1922,40 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
     hipLaunchKernelGGL(k_cand_g, dim3(g0.n_cand_wg, S), dim3(256), 0, g->stream, engs,
                        (JobPtr)g->d_jobs, all);
   }
+  // A failure from here on leaves launches queued on the group's stream on behalf of members that do
+  // not know about them: the members are brought to a consistent state before the error is returned
+  // (the counterpart of ratsdf_engine::abandon_pipeline for a group).
+  auto abandon = [&](int frames_launched) {
+    (void)hipStreamSynchronize(g->stream);
+    for (ratsdf_engine* e : g->eng) {
+      if (frames_launched > 0) {
+        e->parity = (e->parity + (unsigned)frames_launched) & 1u;
+        e->pending = true;   // the last launched frame owes its carve tail
+      }
+      // the look-ahead pass of a frame that will not come may have filled the next candidate lists
+      if (e->cand[e->parity].count)
+        (void)hipMemsetAsync(e->cand[e->parity].count, 0, (size_t)kCandSegs * kCandCountStride * 4, e->stream);
+      e->cand_ready = false;
+      (void)e->settle();
+      (void)hipStreamSynchronize(e->stream);
+    }
+  };
+  if (g->profiling) {  // events for every frame that will be timed, created before anything is launched
+    const size_t need = g->prof_used + (size_t)n / 4 + 2;
+    while (g->prof_events.size() < need) {
+      hipEvent_t a, b;
+      HIPCHK(hipEventCreate(&a));
+      if (hipEventCreate(&b) != hipSuccess) {
+        (void)hipEventDestroy(a);
+        return RATSDF_ERR_DEVICE;
+      }
+      g->prof_events.emplace_back(a, b);
+    }
+  }
+  if (hipGetLastError() != hipSuccess) {  // k_cand_g
+    abandon(0);
+    return RATSDF_ERR_DEVICE;
+  }
   for (int f = 0; f < n; ++f) {
     const bool has_next = f + 1 < n;
     const ratsdf_engine::Geom& gg = has_next ? g1 : g0;
@@ -1889,13 +1969,7 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
                          engs, cur, nxt, gg.b);
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (g->profiling && (g->prof_frame++ % 4 == 0)) {
-      if (g->prof_used == g->prof_events.size()) {
-        hipEvent_t a, b;
-        HIPCHK(hipEventCreate(&a));
-        HIPCHK(hipEventCreate(&b));
-        g->prof_events.emplace_back(a, b);
-      }
+    if (g->profiling && (g->prof_frame++ % 4 == 0) && g->prof_used < g->prof_events.size()) {
       ev0 = g->prof_events[g->prof_used].first;
       ev1 = g->prof_events[g->prof_used].second;
       ++g->prof_used;
@@ -1912,25 +1986,37 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
       default: RATSDF_LAUNCH_INTEGRATE_G(2, RATSDF_INTEG_NT);
     }
 #undef RATSDF_LAUNCH_INTEGRATE_G
+    if (hipGetLastError() != hipSuccess) {  // a launch of this frame was refused
+      abandon(f);
+      return RATSDF_ERR_DEVICE;
+    }
     if (g->profiling && g->prof_used >= 4096) {
       const int st = g->drain_profile();
-      if (st != RATSDF_OK) return st;
+      if (st != RATSDF_OK) {
+        abandon(f + 1);
+        return st;
+      }
     }
   }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(g->ev_done, g->stream));
+  if (hipEventRecord(g->ev_done, g->stream) != hipSuccess) {
+    abandon(n);
+    return RATSDF_ERR_DEVICE;
+  }
+  int st_all = RATSDF_OK;
   for (ratsdf_engine* e : g->eng) {
-    HIPCHK(hipStreamWaitEvent(e->stream, g->ev_done, 0));
+    if (hipStreamWaitEvent(e->stream, g->ev_done, 0) != hipSuccess) st_all = RATSDF_ERR_DEVICE;
     e->parity = (e->parity + (unsigned)n) & 1u;
     e->cand_ready = false;
     e->pending = true;
   }
-  return RATSDF_OK;
+  if (st_all != RATSDF_OK) (void)hipStreamSynchronize(g->stream);  // ordering by waiting instead
+  return st_all;
 }
 
 int ratsdf_group_synchronize(ratsdf_group* g) {
   if (!g) return RATSDF_ERR_BAD_ARGUMENT;
   DeviceGuard guard(g->device);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   HIPCHK(hipStreamSynchronize(g->stream));
   int worst = RATSDF_OK;
   for (ratsdf_engine* e : g->eng) {
@@ -1943,6 +2029,7 @@ int ratsdf_group_synchronize(ratsdf_group* g) {
 int ratsdf_group_profile_enable(ratsdf_group* g, int enable) {
   if (!g) return RATSDF_ERR_BAD_ARGUMENT;
   DeviceGuard guard(g->device);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   const int st = g->drain_profile();
   g->profiling = enable != 0;
   return st;
@@ -1951,6 +2038,7 @@ int ratsdf_group_profile_enable(ratsdf_group* g, int enable) {
 int ratsdf_group_profile_read(ratsdf_group* g, double* ms, int64_t* launches) {
   if (!g) return RATSDF_ERR_BAD_ARGUMENT;
   DeviceGuard guard(g->device);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
   const int st = g->drain_profile();
   if (ms) *ms = g->prof_ms;
   if (launches) *launches = g->prof_n;

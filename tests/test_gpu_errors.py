@@ -111,3 +111,53 @@ def test_entry_points_work_from_another_thread(make_engine, make_oracle):
     for f in frames:
         _integrate(cpu, f)
     assert_maps_equal(gpu, cpu)
+
+
+@pytest.mark.parametrize("switch,what", [(20, "slow_resolved (carve_resolve_gate, k_front)"),
+                                         (21, "serial_done (the serial role's flag, k_integrate)")])
+def test_in_launch_waits_are_bounded(switch, what):
+    """The two in-launch waits between workgroups rely on dispatch order, which HIP
+    does not promise, so they are bounded.  The diagnostic build can withhold either flag
+    (RATSDF_DEBUG=20 / 21): the waiters must give up after the 2 s bound, the frame must END (no hung
+    GPU), the error must surface as RATSDF_ERR_TIMEOUT (status 7, sticky), and the engine must still be
+    queryable and destroyable.  Runs in a child process: the diagnostic library is selected at import."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    lib = root / "ra-slam_amd" / "csrc" / "build" / "libratsdf_stamps.so"
+    assert lib.exists(), "diagnostic build missing: make -C ra-slam_amd/csrc stamps (build() does it)"
+    code = f"""
+import sys, time
+sys.path.insert(0, r'{root / "ra-slam_amd"}')
+import ratsdf
+from ratsdf import synthetic
+e = ratsdf.TSDFGrid(0.02, 0.12, bucket_bits=9, block_bits=14)   # 512 buckets: chained deletes in most frames
+frames = [synthetic.frame('room', i, scale=0.25, noise=True, holes=True) for i in range(40)]
+t0 = time.time()
+status = 0
+for i in range(0, 40, 4):      # back-to-back frames: the hand-offs only exist inside a batch
+    try:
+        e.integrate_batch(frames[i:i + 4], 4.0)
+        e.synchronize()
+    except ratsdf.RatsdfError as err:
+        status = err.status
+        break
+dt = time.time() - t0
+try:
+    e.synchronize()
+    sticky = 0
+except ratsdf.RatsdfError as err:
+    sticky = err.status
+n = e.num_active_blocks() if False else -1
+e.close()
+print('RESULT', status, sticky, i, round(dt, 1))
+"""
+    env = dict(os.environ, RATSDF_LIB=str(lib), RATSDF_DEBUG=str(switch))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    status, sticky, frame, dt = int(line[1]), int(line[2]), int(line[3]), float(line[4])
+    assert status == 7 and sticky == 7, (what, r.stdout)
+    assert dt < 60, (what, dt)

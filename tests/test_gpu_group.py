@@ -97,3 +97,46 @@ def test_group_full_resolution_two_streams(make_engine, make_oracle):
         assert_maps_equal(engines[s], cpu)
         cpu.close()
     group.close()
+
+
+def test_group_of_four_full_resolution_streams(make_engine, make_oracle):
+    """What bench.py's `multi_stream` leg times (S = 4 members, 640x480 / 5 mm, BASELINE configs[4] on one
+    device): every member against the oracle after one batch of four frames."""
+    import ratsdf
+    vs, S, n = 0.005, 4, 4
+    streams = [[synthetic.frame("room", 45 * s + i, noise=True, holes=True) for i in range(n)]
+               for s in range(S)]
+    dev_streams = [_upload(fr) for fr in streams]
+    engines = [make_engine(vs, 6 * vs) for _ in range(S)]
+    group = ratsdf.Group(engines)
+    group.integrate_device_batch(_group_batch(group, streams, dev_streams, 0, n))
+    group.synchronize()
+    for s in range(S):
+        cpu = make_oracle(vs, 6 * vs, threads=16)
+        for f in streams[s]:
+            cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+        assert_stats_equal(engines[s], cpu)
+        assert_maps_equal(engines[s], cpu)
+        cpu.close()
+    group.close()
+
+
+def test_group_of_eight_streams(make_engine, make_oracle):
+    """BASELINE configs[4]'s stream count (8) in one group: small frames, mixed scenes, two batches."""
+    import ratsdf
+    vs, S, n = 0.02, 8, 6
+    scenes = ["room", "sphere", "wall", "room", "sphere", "room", "wall", "room"]
+    streams = [[synthetic.frame(scenes[s], 11 * s + i, scale=0.25, noise=(s % 2 == 0), holes=(s % 3 == 0))
+                for i in range(n)] for s in range(S)]
+    dev_streams = [_upload(fr) for fr in streams]
+    engines = [make_engine(vs, 6 * vs) for _ in range(S)]
+    oracles = [make_oracle(vs, 6 * vs) for _ in range(S)]
+    group = ratsdf.Group(engines)
+    for lo, hi in ((0, 2), (2, 6)):
+        group.integrate_device_batch(_group_batch(group, streams, dev_streams, lo, hi))
+        for s in range(S):
+            for f in streams[s][lo:hi]:
+                oracles[s].integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+            assert_stats_equal(engines[s], oracles[s])
+            assert_maps_equal(engines[s], oracles[s])
+    group.close()

@@ -361,3 +361,15 @@ def test_non_finite_camera_parameters_are_refused(make_engine):
         gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], float("inf"), f["intrinsics"], f["pose"])
     assert gpu.num_active_blocks() == n0
     gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])  # still usable
+
+
+def test_full_resolution_tsdf_only_pair(make_engine, make_oracle):
+    """BASELINE configs[1]: 640x480, 5 mm, ScanNet intrinsics, TSDF-only (ht / lt NULL -> all ones,
+    modules/tsdf_module.cc:27-31): two frames; the probability of every voxel stays exactly 0.5."""
+    vs = 0.005
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+    frames = synthetic.stream("room", 2, scale=1.0, semantic=False, noise=True, holes=True)
+    assert frames[0]["ht"] is None and frames[0]["depth"].shape == (480, 640)
+    run_both(gpu, cpu, frames)
+    p = gpu.gather_valid_semantic()["prob"]
+    assert len(p) > 1000 * 512 and np.all(p == np.float32(0.5))

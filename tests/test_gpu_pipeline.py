@@ -327,3 +327,41 @@ def test_many_deletes_take_the_bitmap_path(make_engine, make_oracle):
         assert deleted[0] > 2048, deleted
         assert_maps_equal(gpu, cpu)
         check_totals(gpu, cpu)
+
+
+def test_bounded_soak_on_a_small_directory(make_engine, make_oracle):
+    """tools/soak.py in the suite, bounded: ~200 frames in random batch sizes through the pipelined engine
+    (look-ahead candidate pass, serial role and carve tail inside the launches) on a 512-bucket directory
+    -- chained buckets, head / chain deletes, the resolver and pool reuse in almost every frame -- against
+    the frame-at-a-time oracle, compared every ~50 frames.  This is also the standing stress of the
+    fence-free hand-offs."""
+    import torch
+    kw = dict(bucket_bits=9, block_bits=14)
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs, **kw), make_oracle(vs, 6 * vs, threads=8, **kw)
+    dev = torch.device("cuda", 0)
+    base = synthetic.stream("room", 40, scale=0.25, noise=True, holes=True) + \
+        synthetic.stream("sphere", 25, scale=0.25, noise=True)
+    seq = base + base[::-1]
+    d = [{k: torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")} for f in seq]
+    h, w = seq[0]["depth"].shape
+    rng = np.random.default_rng(5)
+    at, slow, checked = 0, 0, 0
+    while at < 200:
+        c = int(rng.integers(1, 17))
+        idx = [(at + j) % len(seq) for j in range(c)]
+        b = gpu.make_batch([d[i]["rgb"].data_ptr() for i in idx], [d[i]["depth"].data_ptr() for i in idx],
+                           [d[i]["ht"].data_ptr() for i in idx], [d[i]["lt"].data_ptr() for i in idx], h, w, md,
+                           [seq[i]["intrinsics"] for i in idx], [seq[i]["pose"] for i in idx])
+        gpu.integrate_device_batch(b)
+        for i in idx:
+            f = seq[i]
+            cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+            slow += cpu.last_frame_stats()["slow_requests"]
+        at += c
+        if at // 50 != (at - c) // 50:
+            assert_maps_equal(gpu, cpu)
+            checked += 1
+    assert_maps_equal(gpu, cpu)
+    assert gpu.totals() == cpu.totals()
+    assert slow > 5000 and checked >= 3, (slow, checked)   # the chained-bucket paths really ran
