@@ -167,7 +167,11 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
     const uint32_t k0 = act ? key0(bx, by) : kInf;
     const uint32_t k1 = act ? key1(bz) : kInf;
     // repeats of the previous sample / the previous pixel carry a larger rank for the same block
-    const uint32_t n0 = __shfl_up(k0, 1), n1 = __shfl_up(k1, 1);
+    // (the left neighbour's key by DPP wave_shr:1 -- a register read of the neighbouring lane; __shfl_up
+    // is ds_bpermute_b32: an LDS round trip and index arithmetic, twice per sample, on the critical path
+    // of a pass whose workgroups live ~6 us)
+    const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k0, 0x138, 0xF, 0xF, false);
+    const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, 0x138, 0xF, 0xF, false);
     const bool dup = (k0 == prev0 && k1 == prev1) || (lane > 0 && k0 == n0 && k1 == n1);
     if (act && !dup && shard_owned(bx, P) && !RATSDF_DBG(P, 2)) {
       const uint32_t rank = (uint32_t)pix * (uint32_t)P.S + (uint32_t)i;

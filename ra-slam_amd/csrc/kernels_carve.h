@@ -38,6 +38,18 @@ constexpr uint32_t kUpdCounters = 1024;  // voxels-updated counters (workgroup i
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 
+// Sum over each aligned group of 16 lanes, in every lane of the group, by DPP (registers of neighbouring
+// lanes read directly; the __shfl_xor butterfly it replaces is four ds_bpermute_b32 = four dependent LDS
+// round trips): pairs, quads, then the two mirror patterns -- a sum does not care which lane a partial
+// sum came from.
+__device__ inline uint32_t dpp_sum16(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+  return v;
+}
+
 __device__ inline void occ_clear(const Table& tab, uint32_t e) {
   atomicAnd(&tab.occ[e >> 6], ~(1ull << (e & 63)));
 }
@@ -294,10 +306,7 @@ __device__ inline void carve_release_role(const Pool& pool, const CarveBufs& cb,
       const uint4 x = v[c];
       k += (x.x < mine) + (x.y < mine) + (x.z < mine) + (x.w < mine);
     }
-    k += __shfl_xor(k, 1);
-    k += __shfl_xor(k, 2);
-    k += __shfl_xor(k, 4);
-    k += __shfl_xor(k, 8);
+    k = dpp_sum16(k);  // over the 16 lanes that share the delete
     if (sub == 0 && item < n) pool.heap[(uint32_t)nf + k] = del_pool[item];
   }
 }
