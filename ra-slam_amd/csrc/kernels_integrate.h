@@ -464,7 +464,8 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
       const uint32_t u = rpi_abs(qu[j]);
       const uint32_t w = rpi_abs(qv[j]);
       inb[j] = u < (uint32_t)P.W && w < (uint32_t)P.H && !(qu[j] <= -.5f) && !(qv[j] <= -.5f);
-      const uint32_t k = w * (uint32_t)P.W + u;
+      uint32_t k = w * (uint32_t)P.W + u;
+      if (RATSDF_DBG(P, 15)) k = (k >> 6) << 6;  // diagnostic: 64-texel granularity (few cache lines per gather)
       kk[j] = inb[j] ? k : 0u;
       phz[j] = pcz[j];
     }

@@ -365,3 +365,29 @@ def test_bounded_soak_on_a_small_directory(make_engine, make_oracle):
     assert_maps_equal(gpu, cpu)
     assert gpu.totals() == cpu.totals()
     assert slow > 5000 and checked >= 3, (slow, checked)   # the chained-bucket paths really ran
+
+
+def test_directory_delta_exchange_on_the_device(make_engine):
+    """multi.DirectoryDeltaExchange as bench.py --gpus N builds it (engine-sized buffers on the GPU, export
+    on the engine's stream, fixed-shape delta on torch's stream, no host read on the exchange path), with a
+    single rank: the replica built from deltas equals the engine's directory at every step."""
+    from ratsdf import multi
+    dev = torch.device("cuda", 0)
+    vs = 0.02
+    eng = make_engine(vs, 6 * vs)
+    frames = synthetic.stream("room", 12, scale=0.25, noise=True, holes=True)
+    ex = multi.DirectoryDeltaExchange(engine=eng, device=dev, delta_capacity=4096)
+    sent = []
+    for i, f in enumerate(frames):
+        eng.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+        if i % 3 == 2:
+            ex.fill_from_engine_device(eng)
+            ex.all_gather()
+            _, want = eng.dump_directory()
+            got = ex.result()[0]
+            key = lambda b: np.lexsort((b["z"], b["y"], b["x"]))
+            assert len(got) == len(want)
+            assert np.array_equal(got[key(got)], want[key(want)])
+            sent.append((sum(ex.last_sent), len(want)))
+    assert sent[0][0] == sent[0][1] and all(0 < d < n for d, n in sent[1:]), sent
+    eng.synchronize()   # the export never touches the engine's sticky error

@@ -2,7 +2,7 @@
 # Collects the artefacts kept under profiles/ (GPU box): kernel stats, PMC traffic, bench lines.
 #   bash tools/collect_profiles.sh [tag]     -> gpurun_out/profiles_out/<tag>_*
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/profiles_out
 mkdir -p $O

@@ -26,7 +26,7 @@ res={"kernel":ki,"fetch_size_kb":round(f_kb,1),"write_size_kb":round(w_kb,1),
      "k_integrate_bytes_per_launch": round((2*f_kb+w_kb)*1024),
      "raw_bytes_per_launch_uncorrected": round((f_kb+w_kb)*1024),
      "note":"FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B read request); WRITE_SIZE as is; bench workload, steady-state frames",
-     "code_state": os.environ.get("RATSDF_CODE_STATE", "round 2: k_integrate with lean arguments, log-odds probability, 16+4 byte texels; 3 launches per frame"),
+     "code_state": os.environ.get("RATSDF_CODE_STATE", "round 3: 2 launches per frame, ballots + one-instruction pixel pick in k_integrate, fence-free carve gate"),
      "bench_args": "--steps 2 --warmup 1 --reps 1 --cpu-frames 0 --host-frames 0 --no-profile " + (sys.argv[2] if len(sys.argv) > 2 else ""),
      "all_kernels_kb":{k:{kk:round(vv,1) for kk,vv in v.items()} for k,v in out.items()}}
 os.makedirs('gpurun_out/profiles_out',exist_ok=True)
