@@ -34,6 +34,8 @@ struct PngImage {
 };
 // throws std::runtime_error with a message naming the file
 PngImage read_png(const std::string& path);
+PngImage decode_png(const uint8_t* data, size_t size, const std::string& name);  // the same from memory
+PngImage to_rgb8(const PngImage& in);  // 8-bit RGB: grey replicated, alpha dropped, 16-bit samples >> 8
 
 // "key: value" files as written for ORB-SLAM / OpenCV FileStorage (configs/*.yaml): scalars and
 // one-level flow sequences, comments, a leading %YAML line

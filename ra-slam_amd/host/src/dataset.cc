@@ -49,8 +49,20 @@ int paeth(int a, int b, int c) {
 }  // namespace
 
 PngImage read_png(const std::string& path) {
-  static thread_local std::vector<uint8_t> file, idat, raw, pix;
-  read_file(path, &file);
+  static thread_local std::vector<uint8_t> bytes;
+  read_file(path, &bytes);
+  return decode_png(bytes.data(), bytes.size(), path);
+}
+
+PngImage decode_png(const uint8_t* file_data, size_t file_size, const std::string& path) {
+  static thread_local std::vector<uint8_t> idat, raw, pix;
+  struct View {  // (the parser below indexes `file` like the vector it used to be)
+    const uint8_t* p;
+    size_t n;
+    size_t size() const { return n; }
+    const uint8_t* data() const { return p; }
+    const uint8_t& operator[](size_t i) const { return p[i]; }
+  } file{file_data, file_size};
   idat.clear();
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
   if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) throw std::runtime_error(path + ": not a PNG");
@@ -165,8 +177,8 @@ PngImage read_png(const std::string& path) {
   return img;
 }
 
-namespace {
-// what cv::imread(path) (IMREAD_COLOR) followed by cv::COLOR_BGR2RGB leaves: 8-bit RGB
+// what cv::imread(path) (IMREAD_COLOR) followed by cv::COLOR_BGR2RGB leaves: 8-bit RGB -- and what
+// stbi_load_from_memory(..., 3) leaves for a PNG (grey replicated, alpha dropped, 16-bit samples >> 8)
 PngImage to_rgb8(const PngImage& in) {
   PngImage out;
   out.width = in.width;
@@ -190,7 +202,6 @@ PngImage to_rgb8(const PngImage& in) {
   }
   return out;
 }
-}  // namespace
 
 // ---- YAML -------------------------------------------------------------------------------------
 YamlLite::YamlLite(const std::string& path) {

@@ -172,6 +172,13 @@ RgbImage scannet_sens_reader::decode_color_full(int frame_idx) const {  // :56 d
     full = decode_jpeg(&file_[f.color_off], f.color_size, path_ + " frame " + std::to_string(frame_idx));
     if (full.width != (int)color_w_ || full.height != (int)color_h_)
       throw std::runtime_error(path_ + ": colour frame size differs from the header");
+  } else if (color_type_ == kColorPng) {  // RGBDFrame.cc:56-63: stbi_load_from_memory(..., 3) takes PNG too
+    const PngImage rgb = to_rgb8(decode_png(&file_[f.color_off], f.color_size, path_ + " frame " + std::to_string(frame_idx)));
+    if (rgb.width != (int)color_w_ || rgb.height != (int)color_h_)
+      throw std::runtime_error(path_ + ": colour frame size differs from the header");
+    full.width = rgb.width;
+    full.height = rgb.height;
+    full.data = rgb.data;
   } else if (color_type_ == kColorRaw) {
     if (f.color_size != (size_t)color_w_ * color_h_ * 3) throw std::runtime_error(path_ + ": bad raw colour size");
     full.width = (int)color_w_;

@@ -27,8 +27,13 @@ import make_sens as M  # noqa: E402
 
 REF = ROOT / "oracle" / "_ref"
 
-# name -> (frames, colour (h, w), jpeg keywords, gray?)
+# name -> (frames, colour (h, w), jpeg keywords, gray?); a "png" keyword selects TYPE_PNG colour and names
+# what the PNG holds: rgb, rgba, gray or gray16
 VARIANTS = {
+    "png_rgb": (1, (45, 64), dict(png="rgb"), False),
+    "png_rgba": (1, (33, 50), dict(png="rgba"), False),                                # alpha is dropped
+    "png_gray": (1, (40, 40), dict(png="gray"), False),                                # replicated to 3 channels
+    # (16-bit PNG: stb_image v2.08 refuses it -- "1/2/4/8-bit only" -- so there is nothing to pin)
     "420_odd": (2, (97, 130), dict(quality=85, subsampling="4:2:0"), False),          # = tiny.sens's shape
     "422_odd": (2, (121, 163), dict(quality=88, subsampling="4:2:2"), False),
     "444_restart": (2, (61, 75), dict(quality=90, subsampling="4:4:4", restart_rows=1), False),
@@ -64,7 +69,16 @@ def main():
                 for f in frames:
                     f["rgb"] = f["rgb"][..., 1].copy()  # 2-D array -> PIL mode "L" -> 1-component JPEG
             sens = td / "s.sens"
-            M.write_sens(sens, frames, jpeg_kw=kw)
+            if "png" in kw:
+                for f in frames:
+                    rgb = f["rgb"]
+                    if kw["png"] == "rgba":
+                        f["rgb"] = np.dstack([rgb, (rgb[..., 0] // 2 + 64).astype(np.uint8)])
+                    elif kw["png"] == "gray":
+                        f["rgb"] = rgb[..., 1].copy()
+                M.write_sens(sens, frames, color_type=1)
+            else:
+                M.write_sens(sens, frames, jpeg_kw=kw)
             color, depth, poses, meta = run_ref(REF / "ref_sens_dump", sens, td / "simd")
             color_s, depth_s, poses_s, _ = run_ref(REF / "ref_sens_dump_scalar", sens, td / "scalar")
             for a, b in zip(color + depth, color_s + depth_s):

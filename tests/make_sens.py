@@ -43,9 +43,18 @@ def encode_jpeg(rgb, quality=90, subsampling="4:2:0", restart_rows=0):
     return buf.getvalue()
 
 
+def encode_png(img, mode=None):
+    """img: H x W x 3 (RGB), H x W x 4 (RGBA), H x W uint8 (grey) or H x W uint16 (16-bit grey)"""
+    from PIL import Image
+    buf = io.BytesIO()
+    im = Image.fromarray(img, mode) if mode else Image.fromarray(img)
+    im.save(buf, format="PNG")
+    return buf.getvalue()
+
+
 def write_sens(path, frames, intrinsics=(577.87, 577.87, 319.5, 239.5), depth_shift=1000.0,
                color_type=2, depth_type=1, jpeg_kw=None):
-    """color_type: 0 raw, 2 JPEG; depth_type: 0 raw, 1 zlib (COMPRESSION_TYPE_*, include.hpp:259-270)"""
+    """color_type: 0 raw, 1 PNG, 2 JPEG; depth_type: 0 raw, 1 zlib (COMPRESSION_TYPE_*, include.hpp:259-270)"""
     fx, fy, cx, cy = intrinsics
     K = np.array([[fx, 0, cx, 0], [0, fy, cy, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
     eye = np.eye(4, dtype=np.float32)
@@ -57,7 +66,8 @@ def write_sens(path, frames, intrinsics=(577.87, 577.87, 319.5, 239.5), depth_sh
            struct.pack("<iiIIII", color_type, depth_type, cw, ch, 640, 480), struct.pack("<f", depth_shift),
            struct.pack("<Q", len(frames))]
     for i, f in enumerate(frames):
-        color = encode_jpeg(f["rgb"], **(jpeg_kw or {})) if color_type == 2 else f["rgb"].tobytes()
+        color = (encode_jpeg(f["rgb"], **(jpeg_kw or {})) if color_type == 2 else
+                 encode_png(f["rgb"]) if color_type == 1 else f["rgb"].tobytes())
         depth = zlib.compress(f["depth"].tobytes(), 6) if depth_type == 1 else f["depth"].tobytes()
         out += [f["cam_to_world"].astype(np.float32).tobytes(), struct.pack("<QQQQ", 1000 * i, 1000 * i + 3,
                                                                           len(color), len(depth)), color, depth]
