@@ -105,7 +105,19 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   const int py = (int)(sup / J.tiles_x) * 16 + (int)sub * 4 + (lane >> 4);
   const bool inb = wave < J.tiles_per_wg && rel < J.n_tiles && px < P.W && py < P.H;
   const int pix = inb ? py * P.W + px : 0;
-  const float d = inb ? J.depth[pix] : 0.f;
+  // every input of the pixel is requested here, in ONE round of loads (depth, ht, lt, the three colour
+  // bytes): read where they are used they made three dependent memory round trips (depth -> ht / lt ->
+  // colour) in a workgroup whose whole life is ~6 us
+  float d = 0.f, hv = 1.f, lv = 1.f;
+  uint32_t c = 0;
+  if (inb) {
+    d = J.depth[pix];
+    if (P.has_sem) {
+      hv = J.ht[pix];
+      lv = J.lt[pix];
+    }
+    c = (uint32_t)J.rgb[3 * pix] | ((uint32_t)J.rgb[3 * pix + 1] << 8) | ((uint32_t)J.rgb[3 * pix + 2] << 16);
+  }
 
   const V3 pimg{(float)px, (float)py, 1.f};
   const V3 pc = intr_mul(P.Ki, pimg);                                   // :137
@@ -114,10 +126,8 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
     // log ht - log lt: the observation's log-odds, the only form in which ht and lt enter the
     // probability update (kernels_integrate.h); -inf / +inf / NaN for ht = 0 / lt = 0 / both
     float ln = 0.f;
-    if (P.has_sem) ln = __logf(J.ht[pix]) - __logf(J.lt[pix]);
+    if (P.has_sem) ln = __logf(hv) - __logf(lv);
     const float wn = (1 - d / P.md) * 4;                                // :226
-    const uint32_t c = (uint32_t)J.rgb[3 * pix] | ((uint32_t)J.rgb[3 * pix + 1] << 8) |
-                       ((uint32_t)J.rgb[3 * pix + 2] << 16);
     J.texA[pix] = make_float4(d, r, ln, wn);
     J.texB[pix] = c;
   }
