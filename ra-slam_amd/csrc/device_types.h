@@ -200,7 +200,6 @@ struct RankBufs {
   const SlowRequest* slow;
   uint32_t slow_cap;
   XLock* xlocks;
-  SlowRequest* distinct;
   uint32_t* win_ranks;  // raster ranks of the winners (few-winners path, kSmallRank entries)
   uint32_t* bitmap;   // rank bitmap (many-requests path)
   uint32_t* summary;

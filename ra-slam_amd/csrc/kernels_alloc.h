@@ -263,12 +263,39 @@ constexpr int kSlowDistinctCap = 1024;
 constexpr int kXLockCap = 2048;
 
 
+// A set of bucket numbers (open addressing, 0 = empty slot, bucket + 1 stored): the buckets the pass's
+// chained requests have locked so far.  `slot` may point into LDS or into device memory.
+struct LockSet {
+  uint32_t* slot;
+  uint32_t mask;  // slots - 1 (a power of two); at most half of them are ever filled
+};
+__device__ inline bool lockset_has(const LockSet& L, uint32_t bucket) {
+  for (uint32_t h = (bucket * 2654435761u) & L.mask;; h = (h + 1) & L.mask) {
+    const uint32_t v = L.slot[h];
+    if (v == 0) return false;
+    if (v == bucket + 1) return true;
+  }
+}
+__device__ inline void lockset_add(const LockSet& L, uint32_t bucket) {
+  for (uint32_t h = (bucket * 2654435761u) & L.mask;; h = (h + 1) & L.mask) {
+    const uint32_t v = L.slot[h];
+    if (v == bucket + 1) return;
+    if (v == 0) {
+      L.slot[h] = bucket + 1;
+      return;
+    }
+  }
+}
+
+// `xlocks`: kXLockCap * 8 bytes of device memory, the lock set unless the caller has LDS for it
+// (`lds_locks`, `lds_lock_slots` words, a power of two) and the pass at most a quarter as many requests.
 __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uint32_t req_cap,
                                              const SlowRequest* slow, uint32_t slow_cap,
-                                             XLock* xlocks, SlowRequest* distinct, Ctl* ctl,
+                                             XLock* xlocks, Ctl* ctl,
                                              FrameCtl* F, unsigned long long* lds_keys,
                                              unsigned long long* global_keys,
-                                             uint32_t lds_cap = (uint32_t)kSlowLdsCap) {
+                                             uint32_t lds_cap = (uint32_t)kSlowLdsCap,
+                                             uint32_t* lds_locks = nullptr, uint32_t lds_lock_slots = 0) {
   uint32_t n = F->n_slow;
   if (n > slow_cap) n = slow_cap;
   if (n > (uint32_t)kSlowSortCap) {
@@ -278,6 +305,11 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
   // few keys (always, with the default directory size): LDS; many: a global scratch buffer, which is
   // coherent inside one workgroup (same CU, write-through L1, __syncthreads() drains the stores)
   unsigned long long* skeys = n <= lds_cap ? lds_keys : global_keys;
+  // the lock set: every distinct request takes at most two locks
+  static_assert(sizeof(XLock) == 8 && (kXLockCap & (kXLockCap - 1)) == 0 && kXLockCap >= 2 * kSlowDistinctCap,
+                "xlocks holds 2 * kXLockCap set slots, at most half filled");
+  LockSet locks{reinterpret_cast<uint32_t*>(xlocks), 2u * (uint32_t)kXLockCap - 1u};
+  if (lds_locks && 4u * n <= lds_lock_slots) locks = LockSet{lds_locks, lds_lock_slots - 1u};
   uint32_t m = 1;
   while (m < n) m <<= 1;
   for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
@@ -299,19 +331,87 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
       __syncthreads();
     }
   }
+  // Everything that does not depend on the order of the replay is done by the whole workgroup first
+  // (round 3: at 1280x720 / 2 mm a map past 100 k blocks files 100-250 chained requests per frame, and
+  // the one replaying thread -- linear scans of the locks and of the blocks already seen, every
+  // directory line fetched cold -- took 8-10 us per request, 1-4 ms per frame):
+  //  * a request whose block an earlier-ranked request of the pass names too is irrelevant to the
+  //    replay (same block, later rank): flagged here, in bit 31 of its key's index half;
+  //  * one dry run of the replay's reads per request (home entries, chain, the probe for a free slot and
+  //    the claims beside them, as the directory stands before the pass), which leaves those lines in
+  //    this CU's L1 / this XCD's L2 for the replaying thread.
+  constexpr uint32_t kDup = 0x80000000u;
+  auto block_key = [](const SlowRequest& s) -> unsigned long long {
+    return (unsigned long long)(uint16_t)s.x | ((unsigned long long)(uint16_t)s.y << 16) |
+           ((unsigned long long)(uint16_t)s.z << 32);
+  };
+  // the blocks' names in rank order, side by side in the lock set's memory (not in use yet) when they fit
+  const bool staged = 2u * n <= locks.mask + 1u;  // uniform
+  unsigned long long* bk = reinterpret_cast<unsigned long long*>(locks.slot);
+  if (staged) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) bk[i] = block_key(slow[(uint32_t)skeys[i]]);
+    __syncthreads();
+  }
+  uint32_t dup_bits = 0;  // of this thread's requests i = tid, tid + nt, ... (staged: at most 2048 / 256 = 8 of them)
+  for (uint32_t i = threadIdx.x, t = 0; i < n; i += blockDim.x, ++t) {
+    const unsigned long long mine = staged ? bk[i] : block_key(slow[(uint32_t)skeys[i] & ~kDup]);
+    bool dup = false;
+    if (staged) {
+#pragma unroll 8
+      for (uint32_t j = 0; j < i; ++j) dup |= bk[j] == mine;
+    } else {
+      for (uint32_t j = 0; j < i && !dup; ++j) dup = block_key(slow[(uint32_t)skeys[j] & ~kDup]) == mine;
+      if (dup) reinterpret_cast<uint32_t*>(skeys + i)[0] |= kDup;  // (little endian: the index half)
+    }
+    if (staged && dup) dup_bits |= 1u << (t & 31);
+  }
+  if (staged) {  // the names are no longer needed: flags into the keys, the memory becomes the lock set
+    __syncthreads();
+    for (uint32_t i = threadIdx.x, t = 0; i < n; i += blockDim.x, ++t)
+      if ((dup_bits >> (t & 31)) & 1u) reinterpret_cast<uint32_t*>(skeys + i)[0] |= kDup;
+  }
+  for (uint32_t i = threadIdx.x; i <= locks.mask; i += blockDim.x) locks.slot[i] = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t key_lo = (uint32_t)skeys[i];
+    const bool dup = (key_lo & kDup) != 0;
+    const SlowRequest s = slow[key_lo & ~kDup];
+    uint32_t touched = 0;
+    if (!dup) {
+      const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
+      const EntryWords b = load_entry(tab.entries, (bucket << 1) + 1);
+      touched = (uint32_t)load_entry(tab.entries, bucket << 1).idx + tab.claim[bucket];
+      uint32_t last = (bucket << 1) + 1;
+      int off = entry_offset(b);
+      for (uint32_t g = 0; off && g < 64; ++g) {
+        last = (last + (uint32_t)off) & tab.entry_mask;
+        off = entry_offset(load_entry(tab.entries, last));
+      }
+      touched += tab.claim[last >> 1];
+      uint32_t next = last;
+      for (uint32_t g = 0; g < 16; ++g) {
+        next = (next + 1) & tab.entry_mask;
+        if (next & 1u) continue;
+        const uint32_t c = tab.claim[next >> 1];
+        touched += c;
+        if (load_entry(tab.entries, next).idx >= 0 || (c != kInf && c < s.rank)) continue;
+        break;
+      }
+    }
+    asm volatile("" ::"v"(touched));
+  }
+  __syncthreads();
   if (threadIdx.x != 0) return;
 
   uint32_t n_x = 0, n_d = 0;
   auto locked_at = [&](uint32_t bucket, uint32_t time) -> bool {
     const uint32_t c = tab.claim[bucket];
     if (c != kInf && c < time) return true;
-    for (uint32_t i = 0; i < n_x; ++i)
-      if (xlocks[i].bucket == bucket) return true;  // every recorded lock is earlier than `time`
-    return false;
+    return lockset_has(locks, bucket);  // every recorded lock is earlier than `time`
   };
   auto take_lock = [&](uint32_t bucket, uint32_t time) {
-    if (n_x < (uint32_t)kXLockCap) {
-      xlocks[n_x++] = XLock{bucket, time};
+    if (2u * n_x <= locks.mask) {
+      lockset_add(locks, bucket);
+      ++n_x;
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
     }
@@ -339,40 +439,46 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
   };
 
   for (uint32_t si = 0; si < n; ++si) {
-    const SlowRequest s = slow[(uint32_t)(skeys[si] & 0xFFFFFFFFu)];
-    bool seen = false;
-    for (uint32_t i = 0; i < n_d && !seen; ++i)
-      seen = distinct[i].x == s.x && distinct[i].y == s.y && distinct[i].z == s.z;
-    if (seen) continue;  // same block, later rank: irrelevant
+    const uint32_t key_lo = (uint32_t)skeys[si];
+    if (key_lo & kDup) continue;  // same block, later rank: irrelevant
     if (n_d < (uint32_t)kSlowDistinctCap) {
-      distinct[n_d++] = s;
+      ++n_d;
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
       break;
     }
+    const SlowRequest s = slow[key_lo];
     const uint32_t time = s.rank;
     const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
     const uint32_t e0 = bucket << 1;
-    EntryWords w;
-    if (find_block(tab, s.x, s.y, s.z, &w) != kInf) continue;          // :48-65
-    bool handled = false;
-    for (uint32_t i = 0; i < 2 && !handled; ++i) {                      // :67-78
-      if (load_entry(tab.entries, e0 + i).idx < 0) {
-        if (!locked_at(bucket, time)) {
-          take_lock(bucket, time);
-          place(e0 + i, s);
+    // :48-65 -- present already?  (the walk ends on the chain's tail, which :80-84 needs below)
+    const uint32_t k0 = key0(s.x, s.y), k1 = key1(s.z);
+    const EntryWords a = load_entry(tab.entries, e0);
+    const EntryWords b = load_entry(tab.entries, e0 + 1);
+    if (entry_matches(a, k0, k1) || entry_matches(b, k0, k1)) continue;
+    uint32_t last = e0 + 1;
+    {
+      bool present = false;
+      int off = entry_offset(b);
+      for (uint32_t g = 0; off && g < tab.num_entry; ++g) {
+        last = (last + (uint32_t)off) & tab.entry_mask;
+        const EntryWords w = load_entry(tab.entries, last);
+        if (entry_matches(w, k0, k1)) {
+          present = true;
+          break;
         }
-        handled = true;
+        off = entry_offset(w);
       }
+      if (present) continue;
     }
-    if (handled) continue;
-    uint32_t last = e0 + 1;                                             // :80-84
-    for (uint32_t g = 0; g < tab.num_entry; ++g) {
-      const int off = entry_offset(load_entry(tab.entries, last));
-      if (!off) break;
-      last = (last + (uint32_t)off) & tab.entry_mask;
+    if (a.idx < 0 || b.idx < 0) {                                        // :67-78
+      if (!locked_at(bucket, time)) {
+        take_lock(bucket, time);
+        place(e0 + (a.idx < 0 ? 0u : 1u), s);
+      }
+      continue;
     }
-    const uint32_t bucket_last = last >> 1;
+    const uint32_t bucket_last = last >> 1;                              // :80-84
     uint32_t next = last;
     bool found = false;
     for (uint32_t g = 0; g < tab.num_entry && !found; ++g) {            // :86-91
@@ -558,7 +664,7 @@ constexpr uint32_t kFusedRank = 32768;
 // pool's free count at the start of this pass.
 __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t req_cap,
                                        uint32_t* req_k, const SlowRequest* slow, uint32_t slow_cap,
-                                       XLock* xlocks, SlowRequest* distinct, uint32_t* bitmap,
+                                       XLock* xlocks, uint32_t* bitmap,
                                        uint32_t* summary, uint32_t* prefix, uint32_t nwords,
                                        unsigned long long* sort_scratch, Ctl* ctl, FrameCtl* F,
                                        int32_t nf, unsigned long long* skeys, bool resolved = false) {
@@ -568,8 +674,7 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
   RATSDF_STAMP(ctl->stamps, 8);
   const uint32_t n_slow = F->n_slow;
   if (n_slow != 0 && !resolved) {  // uniform
-    resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, distinct, ctl, F, skeys,
-                          sort_scratch);
+    resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, ctl, F, skeys, sort_scratch);
     __syncthreads();
   }
   uint32_t n = n_slow ? ld_agent_u32(&F->n_req) : F->n_req;  // the resolver appends requests

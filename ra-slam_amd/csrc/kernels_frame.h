@@ -179,7 +179,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
   if (!fast) {  // uniform
     int32_t nf = nf0;
     nf += (int32_t)carve_finalize(tab, pool, cb, ctl, Fp, stats, nf, scratch);
-    alloc_rank_role(tab, rb.req, rb.req_cap, rb.req_k, rb.slow, rb.slow_cap, rb.xlocks, rb.distinct,
+    alloc_rank_role(tab, rb.req, rb.req_cap, rb.req_k, rb.slow, rb.slow_cap, rb.xlocks,
                     rb.bitmap, rb.summary, rb.prefix, rb.nwords, rb.sort_scratch, ctl, F, nf, skeys);
     return;
   }
@@ -318,7 +318,7 @@ template <int VPL>
 __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate_g(
     EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_int_wg, uint32_t n_serial_wg, uint32_t n_ahead_wg,
     uint32_t commit_rot, AheadGeom ag) {
-  __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t role_lds[kIntegLdsWords];
   EnginePtr E = engs + blockIdx.y;
   JobPtr J = cur + blockIdx.y;
   const uint32_t par = J->par;

@@ -107,6 +107,12 @@ struct VecIO<1> {
 // scratch in device memory instead of LDS (rare: first frames of a view, chained buckets).
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kFusedSlowCap = 512;  // chained-bucket requests resolved with their keys in the role's LDS
+constexpr uint32_t kFusedLockSlots = 4 * kFusedSlowCap;  // ... and their lock set (resolve_slow_requests)
+// LDS words of a k_integrate workgroup: the candidate pass's lists, or the resolver's keys and lock set
+// behind the role's 8 counters (12 KiB: eight workgroups per CU use 96 of its 160 KiB)
+constexpr uint32_t kIntegLdsWords =
+    (sizeof(CandLds) + 3) / 4 > 8 + 2 * kFusedSlowCap + kFusedLockSlots ? (sizeof(CandLds) + 3) / 4
+                                                                        : 8 + 2 * kFusedSlowCap + kFusedLockSlots;
 
 // A safety net, not a deadline: the role's general path with every capacity exhausted (16 384 chained
 // requests sorted in device memory by 256 threads) takes tens of milliseconds.
@@ -177,7 +183,7 @@ __device__ __forceinline__ void serial_general(EnginePtr E, uint32_t par, uint32
   const Pool& pool = *(const Pool*)(&E->pool);
   uint32_t* scratch = E->serial_scratch;
   nf += (int32_t)carve_finalize(tab, pool, cb, ctl, &ctl->fr[par ^ 1u], E->stats, nf, scratch);
-  alloc_rank_role(tab, rb.req, rb.req_cap, rb.req_k, rb.slow, rb.slow_cap, rb.xlocks, rb.distinct,
+  alloc_rank_role(tab, rb.req, rb.req_cap, rb.req_k, rb.slow, rb.slow_cap, rb.xlocks,
                   rb.bitmap, rb.summary, rb.prefix, nwords, rb.sort_scratch, ctl, &ctl->fr[par], nf,
                   reinterpret_cast<unsigned long long*>(scratch), resolved);
 }
@@ -237,8 +243,9 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
   // memory and the LDS ranking of alloc_rank_role behind it, this took ~300 us per frame at 1280x720 /
   // 2 mm on a 400 MB map: the general path is for frames that are unusual in size, not in kind.)
   if (__builtin_expect(n_slow != 0, 0)) {  // uniform; the resolver's one call site in this role
-    resolve_slow_requests(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, rb.distinct, ctl, F,
-                          reinterpret_cast<unsigned long long*>(lds + 8), rb.sort_scratch, kFusedSlowCap);
+    resolve_slow_requests(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F,
+                          reinterpret_cast<unsigned long long*>(lds + 8), rb.sort_scratch, kFusedSlowCap,
+                          lds + 8 + 2 * kFusedSlowCap, kFusedLockSlots);
     __syncthreads();
     first_round(std::true_type{});  // again rather than held in registers across the resolver (what it
                                     // placed sits behind the frame's own requests)
@@ -787,7 +794,7 @@ template <int VPL>
 __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
     IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, uint32_t n_serial_wg, uint32_t n_ahead_wg,
     uint32_t commit_rot, CandJob ahead) {
-  __shared__ __attribute__((aligned(16))) uint32_t role_lds[(sizeof(CandLds) + 3) / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t role_lds[kIntegLdsWords];
   // Grid: [n_serial_wg: 0, or 8 of which the first is the frame's serial role][n_ahead_wg look-ahead
   // workgroups of the next frame's candidate pass][n_int_wg update workgroups].  The first two groups
   // are multiples of 8, so that the update workgroups keep their list <-> XCD mapping, and they come

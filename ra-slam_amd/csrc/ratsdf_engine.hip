@@ -137,7 +137,6 @@ struct ratsdf_engine {
 
   SlowRequest* slow = nullptr;
   XLock* xlocks = nullptr;
-  SlowRequest* distinct = nullptr;
   unsigned long long* sort_scratch = nullptr;  // resolver's sort keys beyond the LDS capacity
 
   // directory-sized scratch
@@ -237,7 +236,7 @@ int ratsdf_engine::free_all() {
                   d_stats, d_eng, texA[0], texA[1], texB[0], texB[1], cand[0].list, cand[1].list, cand_count,
                   req, req_k, win_ranks, abitmap, asummary, aprefix,
                   slow, xlocks,
-                  distinct, sort_scratch, masks, wg_count, vis, del_list[0], del_list[1], upd_wg[0],
+                  sort_scratch, masks, wg_count, vis, del_list[0], del_list[1], upd_wg[0],
                   upd_wg[1], tab.dclaim, dbitmap, dsummary, dprefix, slowdel[0], slowdel[1], d_stage, d_mc, serial_scratch};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -269,7 +268,6 @@ RankBufs ratsdf_engine::rank_bufs(uint32_t nranks) const {
   rb.slow = slow;
   rb.slow_cap = kSlowCap;
   rb.xlocks = xlocks;
-  rb.distinct = distinct;
   rb.bitmap = abitmap;
   rb.summary = asummary;
   rb.prefix = aprefix;
@@ -766,7 +764,6 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->d_eng, sizeof(EngineDev)));
   CREATE_CHK(hipMalloc(&e->slow, (size_t)kSlowCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->xlocks, (size_t)kXLockCap * sizeof(XLock)));
-  CREATE_CHK(hipMalloc(&e->distinct, (size_t)kSlowDistinctCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->sort_scratch, (size_t)kSlowSortCap * sizeof(unsigned long long)));
   CREATE_CHK(hipMalloc(&e->serial_scratch, (size_t)kSerialLdsBytes));
   CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * kVisWG * 8));
