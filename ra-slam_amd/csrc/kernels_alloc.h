@@ -256,27 +256,67 @@ __global__ void k_alloc_list(Table tab, FrameParams P, const int16_t* pos, int n
 // fills the first empty home entry at that time unless an earlier slow request locked x first.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSlowSortCap = 16384;   // slow requests per pass (bitonic sort by rank)
-constexpr int kSlowLdsCap = 4096;     // ... sorted in LDS up to this many, in global scratch beyond
+constexpr int kSlowLdsCap = 3584;     // ... sorted in LDS up to this many, in global scratch beyond
 // dynamic LDS of the serial role: sort keys | rank lists (alloc_rank_role) | carve_finalize scratch
 constexpr int kSerialLdsBytes = 34 * 1024;
 constexpr int kSlowDistinctCap = 1024;
 constexpr int kXLockCap = 2048;
 
 
+// What Allocate would do for one chained request against the directory as it stands before the pass
+// (resolve_slow_requests): 64 bytes, written by the workgroup, replayed by one thread.
+struct SlowPlan {
+  uint32_t flags;       // kPlan* | chain entries walked << 8
+  uint32_t last, last_w1;  // the chain's tail (entry index, its second word)
+  uint32_t next;        // free slot-0 entry found after the tail
+  uint32_t c_home, c_last, c_next;  // claims of the three buckets
+  uint32_t k0, k1, rank, bucket;    // the request
+  uint32_t chain_b[3];  // buckets of the chain entries walked
+  uint32_t idx;         // the request's place in the slow list
+  uint32_t pad;
+};
+static_assert(sizeof(SlowPlan) == 64, "four 16-byte words");
+enum : uint32_t {
+  kPlanDup = 1,        // same block as an earlier request of the pass
+  kPlanPresent = 2,    // the block exists
+  kPlanHome = 4,       // an empty home entry: slot 0, or slot 1 with kPlanHomeSlot1
+  kPlanHomeSlot1 = 8,
+  kPlanFound = 16,     // append behind `last`, into `next`
+  kPlanComplex = 32,   // long chain or long probe: replayed from memory
+};
+constexpr uint32_t kPlanSpan = 8;  // buckets probed for a plan
+constexpr uint32_t kSlowPlanCap = (uint32_t)kSlowSortCap * 8u / 64u;  // plans that fit the sort scratch
+
+// Pointer to T in LDS (address space 3: ds_read / ds_write) or anywhere (flat).  The resolver's tables sit
+// in LDS on its ordinary path; through generic pointers every access was a FLAT instruction, which waits
+// for the vector-memory counter as well and cost the replaying thread ~300 cycles apiece.
+template <bool Lds, typename T>
+struct PtrOf {
+  using type = T*;
+};
+template <typename T>
+struct PtrOf<true, T> {
+  using type = __attribute__((address_space(3))) T*;
+};
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // A set of bucket numbers (open addressing, 0 = empty slot, bucket + 1 stored): the buckets the pass's
-// chained requests have locked so far.  `slot` may point into LDS or into device memory.
+// chained requests have locked so far.
+template <bool Lds>
 struct LockSet {
-  uint32_t* slot;
+  typename PtrOf<Lds, uint32_t>::type slot;
   uint32_t mask;  // slots - 1 (a power of two); at most half of them are ever filled
 };
-__device__ inline bool lockset_has(const LockSet& L, uint32_t bucket) {
+template <bool Lds>
+__device__ inline bool lockset_has(const LockSet<Lds>& L, uint32_t bucket) {
   for (uint32_t h = (bucket * 2654435761u) & L.mask;; h = (h + 1) & L.mask) {
     const uint32_t v = L.slot[h];
     if (v == 0) return false;
     if (v == bucket + 1) return true;
   }
 }
-__device__ inline void lockset_add(const LockSet& L, uint32_t bucket) {
+template <bool Lds>
+__device__ inline void lockset_add(const LockSet<Lds>& L, uint32_t bucket) {
   for (uint32_t h = (bucket * 2654435761u) & L.mask;; h = (h + 1) & L.mask) {
     const uint32_t v = L.slot[h];
     if (v == bucket + 1) return;
@@ -287,147 +327,245 @@ __device__ inline void lockset_add(const LockSet& L, uint32_t bucket) {
   }
 }
 
+// Exact rank-ordered replay of VoxelHashTable::Allocate for the pass's chained requests (see above).
+// All threads of one workgroup.  Round 3 (at 1280x720 / 2 mm a map past 100 k blocks files 100-250 of them
+// per frame; one thread replaying them against memory, with linear scans of the locks and of the blocks
+// already seen, took 8-10 us per request, 1-4 ms per frame) splits the work in four:
+//  1. order and duplicates, whole workgroup: every request counts the keys (rank, index) below its own
+//     -- its place in rank order -- and looks for an earlier-ranked request naming the same block, which
+//     makes it irrelevant to the replay (same block, later rank);
+//  2. one PLAN per request, whole workgroup: the replay's reads (home entries, chain, the probe for a
+//     free slot and the claims beside them) done against the directory as it stands BEFORE the pass, with
+//     their answer and the buckets that answer came from;
+//  3. the replay proper, one thread, registers and LDS only: a plan holds unless one of its buckets has
+//     been locked by an earlier request of the pass -- every edit of the pass (an entry placed, a tail
+//     linked, a claim cleared) is made under that bucket's lock -- and its outcome is noted as an action
+//     word in LDS.  No store is issued here: on this hardware a wave's loads and stores share one counter,
+//     so waiting for the next plan also waited for the write-through stores of the last request (2.5 us
+//     per request).  A stale plan (one pass in ten has one) first has the noted actions applied, then
+//     reads the directory again from memory as the reference would;
+//  4. the noted actions are applied by the whole workgroup.
 // `xlocks`: kXLockCap * 8 bytes of device memory, the lock set unless the caller has LDS for it
 // (`lds_locks`, `lds_lock_slots` words, a power of two) and the pass at most a quarter as many requests.
+// `global_keys`: kSlowSortCap * 8 bytes: sort keys of passes beyond `lds_cap` requests, plans otherwise.
+// kLds: keys and lock set in LDS (the caller has `lds_locks` and the pass at most min(lds_cap,
+// lds_lock_slots / 4) requests); else wherever they fit.  `lds_chunk`: 4 KiB of LDS in either case.
+template <bool kLds>
 __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uint32_t req_cap,
                                              const SlowRequest* slow, uint32_t slow_cap,
                                              XLock* xlocks, Ctl* ctl,
                                              FrameCtl* F, unsigned long long* lds_keys,
                                              unsigned long long* global_keys,
-                                             uint32_t lds_cap = (uint32_t)kSlowLdsCap,
+                                             uint32_t lds_cap, SlowPlan* lds_chunk,
                                              uint32_t* lds_locks = nullptr, uint32_t lds_lock_slots = 0) {
+  using KeyPtr = typename PtrOf<kLds, unsigned long long>::type;
+  using WordPtr = typename PtrOf<kLds, uint32_t>::type;
+  using ChunkPtr = typename PtrOf<true, u32x4>::type;
+  const ChunkPtr chunk = (ChunkPtr)lds_chunk;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
   uint32_t n = F->n_slow;
   if (n > slow_cap) n = slow_cap;
   if (n > (uint32_t)kSlowSortCap) {
-    if (threadIdx.x == 0) set_error(ctl, RATSDF_ERR_CAPACITY);
+    if (tid == 0) set_error(ctl, RATSDF_ERR_CAPACITY);
     n = kSlowSortCap;
   }
   // few keys (always, with the default directory size): LDS; many: a global scratch buffer, which is
   // coherent inside one workgroup (same CU, write-through L1, __syncthreads() drains the stores)
-  unsigned long long* skeys = n <= lds_cap ? lds_keys : global_keys;
+  const KeyPtr skeys = (KeyPtr)(kLds || n <= lds_cap ? lds_keys : global_keys);
+  RATSDF_STAMP(ctl->stamps, 20);
   // the lock set: every distinct request takes at most two locks
   static_assert(sizeof(XLock) == 8 && (kXLockCap & (kXLockCap - 1)) == 0 && kXLockCap >= 2 * kSlowDistinctCap,
                 "xlocks holds 2 * kXLockCap set slots, at most half filled");
-  LockSet locks{reinterpret_cast<uint32_t*>(xlocks), 2u * (uint32_t)kXLockCap - 1u};
-  if (lds_locks && 4u * n <= lds_lock_slots) locks = LockSet{lds_locks, lds_lock_slots - 1u};
-  uint32_t m = 1;
-  while (m < n) m <<= 1;
-  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
-    skeys[i] = i < n ? (((unsigned long long)slow[i].rank << 32) | i) : ~0ull;
-  __syncthreads();
-  for (uint32_t k = 2; k <= m; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
-        const uint32_t l = i ^ j;
-        if (l > i) {
-          const unsigned long long a = skeys[i], b = skeys[l];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            skeys[i] = b;
-            skeys[l] = a;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // Everything that does not depend on the order of the replay is done by the whole workgroup first
-  // (round 3: at 1280x720 / 2 mm a map past 100 k blocks files 100-250 chained requests per frame, and
-  // the one replaying thread -- linear scans of the locks and of the blocks already seen, every
-  // directory line fetched cold -- took 8-10 us per request, 1-4 ms per frame):
-  //  * a request whose block an earlier-ranked request of the pass names too is irrelevant to the
-  //    replay (same block, later rank): flagged here, in bit 31 of its key's index half;
-  //  * one dry run of the replay's reads per request (home entries, chain, the probe for a free slot and
-  //    the claims beside them, as the directory stands before the pass), which leaves those lines in
-  //    this CU's L1 / this XCD's L2 for the replaying thread.
-  constexpr uint32_t kDup = 0x80000000u;
+  LockSet<kLds> locks{(WordPtr) reinterpret_cast<uint32_t*>(xlocks), 2u * (uint32_t)kXLockCap - 1u};
+  if (kLds) locks = LockSet<kLds>{(WordPtr)lds_locks, lds_lock_slots - 1u};
+  constexpr uint32_t kDup = 0x80000000u;  // in the index half of a sorted key
   auto block_key = [](const SlowRequest& s) -> unsigned long long {
     return (unsigned long long)(uint16_t)s.x | ((unsigned long long)(uint16_t)s.y << 16) |
            ((unsigned long long)(uint16_t)s.z << 32);
   };
-  // the blocks' names in rank order, side by side in the lock set's memory (not in use yet) when they fit
+  // the blocks' names side by side in the lock set's memory (not in use yet) when they fit
   const bool staged = 2u * n <= locks.mask + 1u;  // uniform
-  unsigned long long* bk = reinterpret_cast<unsigned long long*>(locks.slot);
-  if (staged) {
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) bk[i] = block_key(slow[(uint32_t)skeys[i]]);
-    __syncthreads();
-  }
-  uint32_t dup_bits = 0;  // of this thread's requests i = tid, tid + nt, ... (staged: at most 2048 / 256 = 8 of them)
-  for (uint32_t i = threadIdx.x, t = 0; i < n; i += blockDim.x, ++t) {
-    const unsigned long long mine = staged ? bk[i] : block_key(slow[(uint32_t)skeys[i] & ~kDup]);
-    bool dup = false;
-    if (staged) {
-#pragma unroll 8
-      for (uint32_t j = 0; j < i; ++j) dup |= bk[j] == mine;
-    } else {
-      for (uint32_t j = 0; j < i && !dup; ++j) dup = block_key(slow[(uint32_t)skeys[j] & ~kDup]) == mine;
-      if (dup) reinterpret_cast<uint32_t*>(skeys + i)[0] |= kDup;  // (little endian: the index half)
+  const KeyPtr bk = (KeyPtr)locks.slot;
+
+  // ---- 1. order and duplicates -------------------------------------------------------------------
+  if (n <= lds_cap && n <= 2u * nt && staged) {  // uniform: two requests per thread, by counting
+    unsigned long long k[2] = {~0ull, ~0ull}, b[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t i = tid + (uint32_t)u * nt;
+      if (i < n) {
+        const SlowRequest s = slow[i];
+        k[u] = ((unsigned long long)s.rank << 32) | i;
+        b[u] = block_key(s);
+        skeys[i] = k[u];
+        bk[i] = b[u];
+      }
     }
-    if (staged && dup) dup_bits |= 1u << (t & 31);
-  }
-  if (staged) {  // the names are no longer needed: flags into the keys, the memory becomes the lock set
     __syncthreads();
-    for (uint32_t i = threadIdx.x, t = 0; i < n; i += blockDim.x, ++t)
-      if ((dup_bits >> (t & 31)) & 1u) reinterpret_cast<uint32_t*>(skeys + i)[0] |= kDup;
+    uint32_t pos[2] = {0, 0};
+    bool dup[2] = {false, false};
+#pragma unroll 4
+    for (uint32_t j = 0; j < n; ++j) {  // (every lane reads the same words: LDS broadcasts)
+      const unsigned long long kj = skeys[j], bj = bk[j];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bool before = kj < k[u];
+        pos[u] += before;
+        dup[u] |= before && bj == b[u];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + (uint32_t)u * nt < n) skeys[pos[u]] = k[u] | (dup[u] ? kDup : 0u);
+  } else {  // many requests: bitonic sort, then every request looks at the ones before it
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    for (uint32_t i = tid; i < m; i += nt)
+      skeys[i] = i < n ? (((unsigned long long)slow[i].rank << 32) | i) : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = tid; i < m; i += nt) {
+          const uint32_t l = i ^ j;
+          if (l > i) {
+            const unsigned long long a = skeys[i], b = skeys[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) {
+              skeys[i] = b;
+              skeys[l] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (staged) {
+      for (uint32_t i = tid; i < n; i += nt) bk[i] = block_key(slow[(uint32_t)skeys[i]]);
+      __syncthreads();
+    }
+    uint32_t dup_bits = 0;  // of this thread's requests i = tid, tid + nt, ... (staged: at most 2048 / 256 = 8 of them)
+    for (uint32_t i = tid, t = 0; i < n; i += nt, ++t) {
+      const unsigned long long mine = staged ? bk[i] : block_key(slow[(uint32_t)skeys[i] & ~kDup]);
+      bool dup = false;
+      if (staged) {
+#pragma unroll 8
+        for (uint32_t j = 0; j < i; ++j) dup |= bk[j] == mine;
+      } else {
+        for (uint32_t j = 0; j < i && !dup; ++j) dup = block_key(slow[(uint32_t)skeys[j] & ~kDup]) == mine;
+        if (dup) ((WordPtr)(skeys + i))[0] |= kDup;  // (little endian: the index half)
+      }
+      if (staged && dup) dup_bits |= 1u << (t & 31);
+    }
+    if (staged) {  // flags into the keys
+      __syncthreads();
+      for (uint32_t i = tid, t = 0; i < n; i += nt, ++t)
+        if ((dup_bits >> (t & 31)) & 1u) ((WordPtr)(skeys + i))[0] |= kDup;
+    }
   }
-  for (uint32_t i = threadIdx.x; i <= locks.mask; i += blockDim.x) locks.slot[i] = 0;
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+  // (nobody reads a block name past the last barrier above: the memory becomes the lock set)
+  for (uint32_t i = tid; i <= locks.mask; i += nt) locks.slot[i] = 0;
+  __syncthreads();
+  RATSDF_STAMP(ctl->stamps, 22);
+
+  // ---- 2. plans ----------------------------------------------------------------------------------
+  // (in the sort scratch, which a pass of at most lds_cap requests leaves unused; a pass without plans
+  // still does the loads: they warm the caches for the replay from memory)
+  const bool planned = n <= lds_cap && n <= kSlowPlanCap;  // uniform
+  SlowPlan* plans = reinterpret_cast<SlowPlan*>(global_keys);
+  for (uint32_t i = tid; i < n; i += nt) {
     const uint32_t key_lo = (uint32_t)skeys[i];
-    const bool dup = (key_lo & kDup) != 0;
-    const SlowRequest s = slow[key_lo & ~kDup];
+    SlowPlan pl;
+    pl.flags = kPlanDup;
+    pl.last = pl.last_w1 = pl.next = 0;
+    pl.c_home = pl.c_last = pl.c_next = kInf;
+    pl.k0 = pl.k1 = pl.rank = pl.bucket = 0;
+    pl.chain_b[0] = pl.chain_b[1] = pl.chain_b[2] = 0;
+    pl.idx = key_lo & ~kDup;
+    pl.pad = 0;
     uint32_t touched = 0;
-    if (!dup) {
-      const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
-      const EntryWords b = load_entry(tab.entries, (bucket << 1) + 1);
-      touched = (uint32_t)load_entry(tab.entries, bucket << 1).idx + tab.claim[bucket];
-      uint32_t last = (bucket << 1) + 1;
+    if (!(key_lo & kDup)) {
+      const SlowRequest s = slow[key_lo];
+      const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask), e0 = bucket << 1;
+      const uint32_t k0 = key0(s.x, s.y), k1 = key1(s.z);
+      const EntryWords a = load_entry(tab.entries, e0);
+      const EntryWords b = load_entry(tab.entries, e0 + 1);
+      pl.c_home = tab.claim[bucket];
+      pl.k0 = k0;
+      pl.k1 = k1;
+      pl.rank = s.rank;
+      pl.bucket = bucket;
+      uint32_t flags = 0, nchain = 0;
+      bool present = entry_matches(a, k0, k1) || entry_matches(b, k0, k1);
+      uint32_t last = e0 + 1, last_w1 = b.w1;
       int off = entry_offset(b);
-      for (uint32_t g = 0; off && g < 64; ++g) {
+      while (off && !present) {
+        if (nchain == 3) {
+          flags |= kPlanComplex;
+          break;
+        }
         last = (last + (uint32_t)off) & tab.entry_mask;
-        off = entry_offset(load_entry(tab.entries, last));
+        const EntryWords w = load_entry(tab.entries, last);
+        if (nchain == 0) pl.chain_b[0] = last >> 1;  // (constant indices: the record stays in registers)
+        else if (nchain == 1) pl.chain_b[1] = last >> 1;
+        else pl.chain_b[2] = last >> 1;
+        ++nchain;
+        present = entry_matches(w, k0, k1);
+        last_w1 = w.w1;
+        off = entry_offset(w);
       }
-      touched += tab.claim[last >> 1];
-      uint32_t next = last;
-      for (uint32_t g = 0; g < 16; ++g) {
-        next = (next + 1) & tab.entry_mask;
-        if (next & 1u) continue;
-        const uint32_t c = tab.claim[next >> 1];
-        touched += c;
-        if (load_entry(tab.entries, next).idx >= 0 || (c != kInf && c < s.rank)) continue;
-        break;
+      if (present) {
+        flags = kPlanPresent;
+      } else if (!(flags & kPlanComplex)) {
+        if (a.idx < 0 || b.idx < 0) {
+          flags |= kPlanHome | (a.idx < 0 ? 0u : kPlanHomeSlot1);
+        } else {
+          pl.c_last = tab.claim[last >> 1];
+          // the probe looks at slot 0 of the buckets after the tail's, one by one
+          bool found = false;
+          uint32_t bn = last >> 1;
+          for (uint32_t g = 0; g < kPlanSpan && !found; ++g) {
+            bn = (bn + 1) & tab.bucket_mask;
+            const int32_t idx = load_entry(tab.entries, bn << 1).idx;
+            const uint32_t c = tab.claim[bn];
+            if (idx >= 0 || (c != kInf && c < s.rank)) continue;
+            found = true;
+            pl.c_next = c;
+          }
+          pl.next = bn << 1;
+          flags |= found ? kPlanFound : kPlanComplex;
+        }
       }
+      pl.last = last;
+      pl.last_w1 = last_w1;
+      pl.flags = flags | (nchain << 8);
+      touched = pl.c_home;
+    }
+    if (planned) {
+      uint4* q = reinterpret_cast<uint4*>(plans + i);
+      const uint4* v = reinterpret_cast<const uint4*>(&pl);
+      q[0] = v[0];
+      q[1] = v[1];
+      q[2] = v[2];
+      q[3] = v[3];
+      skeys[i] = 0;  // from here on: the request's action word (none)
     }
     asm volatile("" ::"v"(touched));
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  RATSDF_STAMP(ctl->stamps, 23);
 
-  uint32_t n_x = 0, n_d = 0;
-  auto locked_at = [&](uint32_t bucket, uint32_t time) -> bool {
-    const uint32_t c = tab.claim[bucket];
-    if (c != kInf && c < time) return true;
-    return lockset_has(locks, bucket);  // every recorded lock is earlier than `time`
-  };
-  auto take_lock = [&](uint32_t bucket, uint32_t time) {
-    if (2u * n_x <= locks.mask) {
-      lockset_add(locks, bucket);
-      ++n_x;
-    } else {
-      set_error(ctl, RATSDF_ERR_CAPACITY);
-    }
-    const uint32_t c = tab.claim[bucket];
-    if (c != kInf && c > time) tab.claim[bucket] = kInf;  // a later leader finds the lock taken
-  };
-  auto place = [&](uint32_t e, const SlowRequest& s) {
-    // (agent-scope stores: when this role runs inside k_integrate, the committing and carving
-    // workgroups of the same launch read these words past their own L2)
+  // ---- the stores of the pass ----
+  // (agent scope: when this role runs inside k_integrate, the committing and carving workgroups of the
+  // same launch read these words past their own L2)
+  auto write_placed = [&](uint32_t e, uint32_t k0, uint32_t k1, uint32_t rank, uint32_t slot) {
     uint32_t* p = reinterpret_cast<uint32_t*>(tab.entries + e);
-    __hip_atomic_store(&p[0], key0(s.x, s.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&p[1], key1(s.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // offset 0
+    __hip_atomic_store(&p[0], k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p[1], k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // offset 0
     __hip_atomic_store(&p[2], (uint32_t)kPlaceholderIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t slot = atomicAdd(&F->n_req, 1u);
     if (slot < req_cap) {
-      const Request r{s.x, s.y, s.z, (uint16_t)(kReqWinner | kReqPlaced), s.rank, e};
+      const Request r{(int16_t)(k0 & 0xFFFFu), (int16_t)(k0 >> 16), (int16_t)(k1 & 0xFFFFu),
+                      (uint16_t)(kReqWinner | kReqPlaced), rank, e};
       unsigned long long w[2];
       __builtin_memcpy(w, &r, sizeof(r));
       unsigned long long* q = reinterpret_cast<unsigned long long*>(req + slot);
@@ -437,17 +575,67 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
       set_error(ctl, RATSDF_ERR_CAPACITY);
     }
   };
+  auto write_link = [&](uint32_t last, uint32_t last_w1, uint32_t next) {         // :98-99
+    const uint32_t wrap = next > last ? 0u : tab.num_entry;
+    uint32_t* pl = reinterpret_cast<uint32_t*>(tab.entries + last);
+    const int16_t link = (int16_t)(next + wrap - last);
+    __hip_atomic_store(&pl[1], (last_w1 & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // action word of a planned request: [1:0] 1 = fill the home slot, 2 = link the tail and fill `next`;
+  // [2] clear the claim of the first bucket locked (home / tail), [3] of `next`'s; [63:32] request slot
+  auto apply = [&](const SlowPlan& pl, unsigned long long act) {
+    const uint32_t kind = (uint32_t)act & 3u, slot = (uint32_t)(act >> 32);
+    if (act & 4u) tab.claim[(pl.flags & kPlanHome) ? pl.bucket : pl.last >> 1] = kInf;
+    if (act & 8u) tab.claim[pl.next >> 1] = kInf;
+    if (kind == 1u) {
+      write_placed((pl.bucket << 1) + ((pl.flags & kPlanHomeSlot1) ? 1u : 0u), pl.k0, pl.k1, pl.rank, slot);
+    } else if (kind == 2u) {
+      write_link(pl.last, pl.last_w1, pl.next);
+      write_placed(pl.next, pl.k0, pl.k1, pl.rank, slot);
+    }
+  };
+  auto load_plan = [&](uint32_t i) -> SlowPlan {
+    SlowPlan pl;
+    const uint4* q = reinterpret_cast<const uint4*>(plans + i);
+    uint4* v = reinterpret_cast<uint4*>(&pl);
+    v[0] = q[0];
+    v[1] = q[1];
+    v[2] = q[2];
+    v[3] = q[3];
+    return pl;
+  };
 
-  for (uint32_t si = 0; si < n; ++si) {
-    const uint32_t key_lo = (uint32_t)skeys[si];
-    if (key_lo & kDup) continue;  // same block, later rank: irrelevant
-    if (n_d < (uint32_t)kSlowDistinctCap) {
-      ++n_d;
+  // ---- 3. replay ---------------------------------------------------------------------------------
+  // Thread 0 replays; the plans reach it through LDS, 32 at a time, fetched by the second wave one batch
+  // ahead (a plan fetched from memory by the replaying thread itself cost it a full memory latency per
+  // request -- ~1 600 cycles beside a running voxel update -- however early the load was issued).
+  // The pass's only writer of the request list (the frame's ordinary requests were filed by the launch
+  // before): the list's counter lives in a register and is published once at the end.
+  uint32_t n_x = 0, n_d = 0, n_req = 0, n_req_before = 0;
+  uint32_t unapplied = 0;  // actions noted for requests [unapplied, si) are not in memory yet
+  bool stop = false;
+#ifdef RATSDF_STAMPS
+  uint32_t n_stale = 0;
+#endif
+  if (tid == 0) n_req = n_req_before = F->n_req;
+  // Allocate's try-lock of `bucket` at time `time` (voxel_hash.cu:67-70,93-94) given the bucket's claim
+  // `c`: fails when the bucket's leader (claim earlier than `time`) or an earlier chained request of
+  // the pass holds it; a later leader must find the lock taken (*clear: its claim is to be reset).
+  auto try_lock = [&](uint32_t bucket, uint32_t c, uint32_t time, bool* clear) -> bool {
+    if (c != kInf && c < time) return false;
+    if (lockset_has(locks, bucket)) return false;  // every recorded lock is earlier than `time`
+    if (2u * n_x <= locks.mask) {
+      lockset_add(locks, bucket);
+      ++n_x;
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
-      break;
     }
-    const SlowRequest s = slow[key_lo];
+    *clear = c != kInf && c > time;
+    return true;
+  };
+  // Allocate for one request, everything read from the directory as it stands now, stores at once
+  auto replay_from_memory = [&](const SlowRequest& s, uint32_t* took_a, uint32_t* took_b) {
     const uint32_t time = s.rank;
     const uint32_t bucket = block_hash(s.x, s.y, s.z, tab.bucket_mask);
     const uint32_t e0 = bucket << 1;
@@ -455,55 +643,277 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
     const uint32_t k0 = key0(s.x, s.y), k1 = key1(s.z);
     const EntryWords a = load_entry(tab.entries, e0);
     const EntryWords b = load_entry(tab.entries, e0 + 1);
-    if (entry_matches(a, k0, k1) || entry_matches(b, k0, k1)) continue;
-    uint32_t last = e0 + 1;
+    const uint32_t c_home = tab.claim[bucket];  // (rides with the entries)
+    if (entry_matches(a, k0, k1) || entry_matches(b, k0, k1)) return;
+    uint32_t last = e0 + 1, last_w1 = b.w1;
     {
-      bool present = false;
       int off = entry_offset(b);
       for (uint32_t g = 0; off && g < tab.num_entry; ++g) {
         last = (last + (uint32_t)off) & tab.entry_mask;
         const EntryWords w = load_entry(tab.entries, last);
-        if (entry_matches(w, k0, k1)) {
-          present = true;
-          break;
-        }
+        if (entry_matches(w, k0, k1)) return;
+        last_w1 = w.w1;
         off = entry_offset(w);
       }
-      if (present) continue;
     }
+    bool clear = false;
     if (a.idx < 0 || b.idx < 0) {                                        // :67-78
-      if (!locked_at(bucket, time)) {
-        take_lock(bucket, time);
-        place(e0 + (a.idx < 0 ? 0u : 1u), s);
+      if (try_lock(bucket, c_home, time, &clear)) {
+        *took_a = bucket;
+        if (clear) tab.claim[bucket] = kInf;
+        write_placed(e0 + (a.idx < 0 ? 0u : 1u), k0, k1, time, n_req++);
       }
-      continue;
+      return;
     }
     const uint32_t bucket_last = last >> 1;                              // :80-84
-    uint32_t next = last;
+    const uint32_t c_last = bucket_last == bucket ? c_home : tab.claim[bucket_last];
+    uint32_t next = last, c_next = kInf;
     bool found = false;
     for (uint32_t g = 0; g < tab.num_entry && !found; ++g) {            // :86-91
       next = (next + 1) & tab.entry_mask;
       if ((next & 1u) == 1u) continue;  // never the last slot of a bucket
-      if (load_entry(tab.entries, next).idx >= 0) continue;
-      const uint32_t c = tab.claim[next >> 1];
-      if (c != kInf && c < time) continue;  // that bucket's leader has filled its slot 0 by now
+      const int32_t idx = load_entry(tab.entries, next).idx;
+      c_next = tab.claim[next >> 1];    // (both requested before either is looked at)
+      if (idx >= 0) continue;
+      if (c_next != kInf && c_next < time) continue;  // that bucket's leader has filled its slot 0 by now
       found = true;
     }
-    if (!found) continue;
-    const uint32_t bucket_next = next >> 1;
-    if (!locked_at(bucket_last, time)) {                                // :93-94 (short-circuit &&)
-      take_lock(bucket_last, time);
-      if (!locked_at(bucket_next, time)) {
-        take_lock(bucket_next, time);
-        const uint32_t wrap = next > last ? 0u : tab.num_entry;
-        uint32_t* pl = reinterpret_cast<uint32_t*>(tab.entries + last);
-        const int16_t link = (int16_t)(next + wrap - last);             // :98-99
-        __hip_atomic_store(&pl[1], (pl[1] & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        place(next, s);
+    if (!found) return;
+    // :93-94 (short-circuit &&: the tail's lock is taken, and kept, even when the second one fails).
+    // c_last / c_next are what the claims hold now unless the first lock of THIS request changed the
+    // second's: only when both buckets are the same one, and then the second try fails on the lock set.
+    if (!try_lock(bucket_last, c_last, time, &clear)) return;
+    *took_a = bucket_last;
+    if (clear) tab.claim[bucket_last] = kInf;
+    if (!try_lock(next >> 1, c_next, time, &clear)) return;
+    *took_b = next >> 1;
+    if (clear) tab.claim[next >> 1] = kInf;
+    write_link(last, last_w1, next);
+    write_placed(next, k0, k1, time, n_req++);
+  };
+  // one request of the pass, its plan in hand
+  auto replay_planned = [&](uint32_t si, const SlowPlan& pl) {
+    if (pl.flags & kPlanDup) return;  // same block, later rank: irrelevant
+    if (n_d++ >= (uint32_t)kSlowDistinctCap) {
+      set_error(ctl, RATSDF_ERR_CAPACITY);
+      stop = true;
+      return;
+    }
+    if (pl.flags & kPlanPresent) return;  // nothing the pass does removes a block
+    bool stale = (pl.flags & kPlanComplex) != 0 || lockset_has(locks, pl.bucket);
+    const uint32_t nchain = (pl.flags >> 8) & 3u;
+    if (!stale && nchain > 0) stale = lockset_has(locks, pl.chain_b[0]);
+    if (!stale && nchain > 1) stale = lockset_has(locks, pl.chain_b[1]);
+    if (!stale && nchain > 2) stale = lockset_has(locks, pl.chain_b[2]);
+    if (!stale && (pl.flags & kPlanFound)) {
+      const uint32_t bn = pl.next >> 1;
+      for (uint32_t bq = ((pl.last >> 1) + 1) & tab.bucket_mask;; bq = (bq + 1) & tab.bucket_mask) {
+        stale = lockset_has(locks, bq);
+        if (stale || bq == bn) break;
       }
     }
+    if (stale) {
+#ifdef RATSDF_STAMPS
+      ++n_stale;
+#endif
+      for (uint32_t j = unapplied; j < si; ++j) {
+        const unsigned long long act = skeys[j];
+        if (act) {
+          apply(load_plan(j), act);
+          skeys[j] = 0;
+        }
+      }
+      unapplied = si + 1;
+      uint32_t ta, tb;
+      replay_from_memory(slow[pl.idx], &ta, &tb);
+      return;
+    }
+    bool clear_a = false, clear_b = false;
+    unsigned long long act = 0;
+    if (pl.flags & kPlanHome) {
+      if (try_lock(pl.bucket, pl.c_home, pl.rank, &clear_a)) act = 1u | ((unsigned long long)n_req++ << 32);
+    } else if (try_lock(pl.last >> 1, pl.c_last, pl.rank, &clear_a)) {
+      if (try_lock(pl.next >> 1, pl.c_next, pl.rank, &clear_b)) act = 2u | ((unsigned long long)n_req++ << 32);
+      else act = 1ull << 63;  // (so that the word is not zero when only the claim is to be cleared)
+    }
+    if (act) skeys[si] = act | (clear_a ? 4u : 0u) | (clear_b ? 8u : 0u);
+  };
+
+  if constexpr (kLds) {
+    // Keys and locks in LDS: the first wave replays, 64 requests at a time, one per lane, in rank order.
+    // What a request decides from its plan is known beforehand (its claims against its rank); what
+    // the serial order adds is only this: a request whose plan was read from a bucket that an EARLIER
+    // request has locked is stale.  So the lanes step through the batch in order, the request whose turn
+    // it is adds its locks to the set (one lane) and announces them (readlane), and every later lane
+    // tests them against the buckets its plan was read from: ~50 instructions per request instead of ~300
+    // in a single lane, each of which waited for its own LDS round trips.  The outcome stays in the lane
+    // (an action word) and goes to memory when the batch is through -- or before a stale request reads
+    // the directory again.
+    static_assert(!kLds || kSlowDistinctCap >= 512, "the LDS path takes at most 512 requests");
+    if (planned && tid < 64) {
+      constexpr uint32_t kNone = 0xFFFFFFFFu;
+      const uint32_t lane = tid;
+      n_req = n_req_before = F->n_req;  // (uniform)
+      for (uint32_t base = 0; base < n; base += 64) {  // uniform
+        const uint32_t i = base + lane;
+        // (what the loop below needs of the plan, in a dozen registers: the record itself is read again
+        // when its outcome is applied -- the update kernel this role rides in has none to spare)
+        uint32_t bucket, cb0, cb1, cb2, lo, span, A, B, bits, pidx;
+        bool work, stale, ok_a, ok_b;
+        uint32_t nchain;
+        bool ranged;
+        {
+          SlowPlan pl = load_plan(i < n ? i : base);
+          if (i >= n) pl.flags = kPlanDup;
+          const uint32_t flags = pl.flags;
+          nchain = (flags >> 8) & 3u;
+          work = !(flags & (kPlanDup | kPlanPresent));
+          const bool home = (flags & kPlanHome) != 0;
+          ranged = (flags & kPlanFound) != 0;
+          bucket = pl.bucket;
+          cb0 = pl.chain_b[0];
+          cb1 = pl.chain_b[1];
+          cb2 = pl.chain_b[2];
+          pidx = pl.idx;
+          lo = ((pl.last >> 1) + 1) & tab.bucket_mask;       // buckets the probe looked at:
+          span = ((pl.next >> 1) - lo) & tab.bucket_mask;     // lo .. lo + span (circular)
+          stale = (flags & kPlanComplex) != 0;
+          // what the plan does when it holds: try-lock A (home / tail), then B (`next`), voxel_hash.cu:67-70,93-94
+          A = home ? pl.bucket : pl.last >> 1;
+          B = pl.next >> 1;
+          const uint32_t c_a = home ? pl.c_home : pl.c_last;
+          ok_a = work && !(c_a != kInf && c_a < pl.rank);
+          ok_b = ok_a && !home && B != A && !(pl.c_next != kInf && pl.c_next < pl.rank);
+          const uint32_t kind = home ? (ok_a ? 1u : 0u) : (ok_b ? 2u : 0u);
+          bits = kind | (ok_a && c_a != kInf && c_a > pl.rank ? 4u : 0u) |
+                 (ok_b && pl.c_next != kInf && pl.c_next > pl.rank ? 8u : 0u);
+        }
+        auto reads = [&](uint32_t x) -> bool {  // was the plan read from bucket x?
+          return x == bucket || (nchain > 0 && x == cb0) || (nchain > 1 && x == cb1) || (nchain > 2 && x == cb2) ||
+                 (ranged && ((x - lo) & tab.bucket_mask) <= span);
+        };
+        // stale already?  (locks of the batches before)
+        if (work && !stale) {
+          stale = lockset_has(locks, bucket);
+          if (!stale && nchain > 0) stale = lockset_has(locks, cb0);
+          if (!stale && nchain > 1) stale = lockset_has(locks, cb1);
+          if (!stale && nchain > 2) stale = lockset_has(locks, cb2);
+          if (!stale && ranged)
+            for (uint32_t g = 0; g <= span && !stale; ++g) stale = lockset_has(locks, (lo + g) & tab.bucket_mask);
+        }
+        unsigned long long act = 0;  // noted, not yet in memory
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(work);
+        while (todo) {  // uniform
+          const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
+          todo &= todo - 1;
+          uint32_t la = kNone, lb = kNone;  // the buckets request j locks (uniform)
+          if (!((__builtin_amdgcn_ballot_w64(stale) >> j) & 1ull)) {
+            const unsigned long long m_a = __builtin_amdgcn_ballot_w64(ok_a), m_b = __builtin_amdgcn_ballot_w64(ok_b);
+            const unsigned long long m_k = __builtin_amdgcn_ballot_w64((bits & 3u) != 0);
+            if ((m_a >> j) & 1ull) la = __builtin_amdgcn_readlane(A, j);
+            if ((m_b >> j) & 1ull) lb = __builtin_amdgcn_readlane(B, j);
+            if (lane == j) {
+              if (ok_a) lockset_add(locks, A);
+              if (ok_b) lockset_add(locks, B);
+              if (ok_a) act = (1ull << 63) | bits | ((unsigned long long)n_req << 32);
+            }
+            n_req += (uint32_t)((m_k >> j) & 1ull);
+          } else {
+#ifdef RATSDF_STAMPS
+            if (lane == 0) ++n_stale;
+#endif
+            if (act) apply(load_plan(i), act & ~(1ull << 63));
+            act = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint32_t ta = kNone, tb = kNone;
+            if (lane == j) replay_from_memory(slow[pidx], &ta, &tb);
+            la = __builtin_amdgcn_readlane(ta, j);
+            lb = __builtin_amdgcn_readlane(tb, j);
+            n_req = __builtin_amdgcn_readlane(n_req, j);
+          }
+          if ((la != kNone && reads(la)) || (lb != kNone && reads(lb))) stale = true;
+        }
+        if (act) apply(load_plan(i), act & ~(1ull << 63));
+      }
+      if (lane == 0) {
+        if (n_req != n_req_before)
+          __hip_atomic_store(&F->n_req, n_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        RATSDF_STAMP(ctl->stamps, 24);
+#ifdef RATSDF_STAMPS
+        ctl->stamps[25] += n;
+        ctl->stamps[27] += n_stale;
+        ctl->stamps[28] += n_req - n_req_before;
+        ctl->stamps[29] += 1;
+        ctl->stamps[21] += (unsigned long long)clock64();
+#endif
+      }
+    }
+    return;  // (n <= lds_cap on this path: always planned)
   }
+  if (planned) {
+    constexpr uint32_t kBatch = 32;  // plans per LDS batch; lds_chunk holds two
+    const uint32_t nbatch = (n + kBatch - 1) / kBatch;
+    const bool fetcher = tid >= 64 && tid < 64 + kBatch;  // (blockDim.x >= 128)
+    auto fetch = [&](uint32_t bi) {
+      const uint32_t i = bi * kBatch + (tid - 64);
+      if (i >= n) return;
+      const u32x4* q = reinterpret_cast<const u32x4*>(plans + i);
+      const ChunkPtr d = chunk + ((bi & 1u) * kBatch + (tid - 64)) * 4u;
+      const u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+      d[0] = v0;
+      d[1] = v1;
+      d[2] = v2;
+      d[3] = v3;
+    };
+    if (fetcher) fetch(0);
+    __syncthreads();
+    for (uint32_t bi = 0; bi < nbatch; ++bi) {  // uniform
+      if (fetcher && bi + 1 < nbatch) fetch(bi + 1);
+      if (tid == 0 && !stop) {
+        const uint32_t lo = bi * kBatch, hi = lo + kBatch < n ? lo + kBatch : n;
+        for (uint32_t si = lo; si < hi && !stop; ++si) {
+          SlowPlan pl;
+          const ChunkPtr q = chunk + ((bi & 1u) * kBatch + (si - lo)) * 4u;
+          const u32x4 v[4] = {q[0], q[1], q[2], q[3]};
+          __builtin_memcpy(&pl, v, sizeof(pl));
+          replay_planned(si, pl);
+        }
+      }
+      __syncthreads();
+    }
+  } else if (tid == 0) {
+    for (uint32_t si = 0; si < n; ++si) {
+      const uint32_t key_lo = (uint32_t)skeys[si];
+      if (key_lo & kDup) continue;  // same block, later rank: irrelevant
+      if (n_d++ >= (uint32_t)kSlowDistinctCap) {
+        set_error(ctl, RATSDF_ERR_CAPACITY);
+        break;
+      }
+      uint32_t ta, tb;
+      replay_from_memory(slow[key_lo], &ta, &tb);
+    }
+  }
+  if (tid == 0) {
+    if (n_req != n_req_before)
+      __hip_atomic_store(&F->n_req, n_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    RATSDF_STAMP(ctl->stamps, 24);
+#ifdef RATSDF_STAMPS
+    ctl->stamps[25] += n;
+    ctl->stamps[26] += n_d;
+    ctl->stamps[27] += n_stale;
+    ctl->stamps[28] += n_req - n_req_before;
+    ctl->stamps[29] += 1;
+#endif
+  }
+  if (!planned) return;  // uniform
+
+  // ---- 4. the actions noted, whole workgroup ---------------------------------------------------------
+  // (the replay's last batch ended with a barrier: the action words are visible)
+  for (uint32_t i = tid; i < n; i += nt) {
+    const unsigned long long act = skeys[i];
+    if (act) apply(load_plan(i), act);
+  }
+  RATSDF_STAMP(ctl->stamps, 21);  // (index 21: end of the pass)
 }
 
 // Exclusive scan of one value per thread across the workgroup: wave-level scan with cross-lane
@@ -674,7 +1084,9 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
   RATSDF_STAMP(ctl->stamps, 8);
   const uint32_t n_slow = F->n_slow;
   if (n_slow != 0 && !resolved) {  // uniform
-    resolve_slow_requests(tab, req, req_cap, slow, slow_cap, xlocks, ctl, F, skeys, sort_scratch);
+    // (LDS: sort keys of up to kSlowLdsCap requests, then 4 KiB for two batches of plans)
+    resolve_slow_requests<false>(tab, req, req_cap, slow, slow_cap, xlocks, ctl, F, skeys, sort_scratch,
+                          (uint32_t)kSlowLdsCap, reinterpret_cast<SlowPlan*>(skeys + kSlowLdsCap));
     __syncthreads();
   }
   uint32_t n = n_slow ? ld_agent_u32(&F->n_req) : F->n_req;  // the resolver appends requests

@@ -110,9 +110,9 @@ constexpr uint32_t kFusedSlowCap = 512;  // chained-bucket requests resolved wit
 constexpr uint32_t kFusedLockSlots = 4 * kFusedSlowCap;  // ... and their lock set (resolve_slow_requests)
 // LDS words of a k_integrate workgroup: the candidate pass's lists, or the resolver's keys and lock set
 // behind the role's 8 counters (12 KiB: eight workgroups per CU use 96 of its 160 KiB)
+constexpr uint32_t kFusedResolverWords = 8 + 2 * kFusedSlowCap + kFusedLockSlots;
 constexpr uint32_t kIntegLdsWords =
-    (sizeof(CandLds) + 3) / 4 > 8 + 2 * kFusedSlowCap + kFusedLockSlots ? (sizeof(CandLds) + 3) / 4
-                                                                        : 8 + 2 * kFusedSlowCap + kFusedLockSlots;
+    (sizeof(CandLds) + 3) / 4 > kFusedResolverWords ? (sizeof(CandLds) + 3) / 4 : kFusedResolverWords;
 
 // A safety net, not a deadline: the role's general path with every capacity exhausted (16 384 chained
 // requests sorted in device memory by 256 threads) takes tens of milliseconds.
@@ -243,9 +243,16 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
   // memory and the LDS ranking of alloc_rank_role behind it, this took ~300 us per frame at 1280x720 /
   // 2 mm on a 400 MB map: the general path is for frames that are unusual in size, not in kind.)
   if (__builtin_expect(n_slow != 0, 0)) {  // uniform; the resolver's one call site in this role
-    resolve_slow_requests(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F,
-                          reinterpret_cast<unsigned long long*>(lds + 8), rb.sort_scratch, kFusedSlowCap,
-                          lds + 8 + 2 * kFusedSlowCap, kFusedLockSlots);
+    // (ordinary: keys and lock set in this workgroup's LDS; past kFusedSlowCap requests: in device memory)
+    unsigned long long* lds_keys = reinterpret_cast<unsigned long long*>(lds + 8);
+    SlowPlan* lds_chunk = nullptr;  // (batches of plans for a replaying thread: neither path below has one)
+    if (n_slow <= kFusedSlowCap)
+      resolve_slow_requests<true>(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F, lds_keys,
+                                  rb.sort_scratch, kFusedSlowCap, lds_chunk, lds + 8 + 2 * kFusedSlowCap,
+                                  kFusedLockSlots);
+    else
+      resolve_slow_requests<false>(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F, lds_keys,
+                                   rb.sort_scratch, 0u, lds_chunk);
     __syncthreads();
     first_round(std::true_type{});  // again rather than held in registers across the resolver (what it
                                     // placed sits behind the frame's own requests)
@@ -352,6 +359,9 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
 // waits expire: tests/test_gpu_errors.py::test_in_launch_waits_are_bounded)
 __device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint32_t nwords, uint32_t* lds,
                                                  bool withhold = false) {
+  // The frame's critical path runs in these four waves, each sharing its SIMD with seven waves of the voxel
+  // update: ask the instruction arbiter for the highest wave priority.
+  __builtin_amdgcn_s_setprio(3);
   const uint32_t how = serial_role256(E, par, nwords, lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
