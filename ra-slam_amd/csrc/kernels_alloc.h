@@ -326,6 +326,17 @@ __device__ inline void lockset_add(const LockSet<Lds>& L, uint32_t bucket) {
     }
   }
 }
+// ... by several lanes at once (distinct buckets): the slot is claimed with a compare-and-swap
+template <bool Lds>
+__device__ inline void lockset_add_shared(const LockSet<Lds>& L, uint32_t bucket) {
+  for (uint32_t h = (bucket * 2654435761u) & L.mask;; h = (h + 1) & L.mask) {
+    uint32_t expected = 0;
+    if (__hip_atomic_compare_exchange_strong(&L.slot[h], &expected, bucket + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP) ||
+        expected == bucket + 1)
+      return;
+  }
+}
 
 // Exact rank-ordered replay of VoxelHashTable::Allocate for the pass's chained requests (see above).
 // All threads of one workgroup.  Round 3 (at 1280x720 / 2 mm a map past 100 k blocks files 100-250 of them
@@ -801,30 +812,42 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
           if (!stale && ranged)
             for (uint32_t g = 0; g <= span && !stale; ++g) stale = lockset_has(locks, (lo + g) & tab.bucket_mask);
         }
-        unsigned long long act = 0;  // noted, not yet in memory
+        // A request whose plan holds keeps its outcome in its lane (`taken`, `slot`); locks and stores
+        // follow for the whole batch at once -- or earlier, before a stale request reads the directory
+        // and the lock set as they stand.
+        bool taken = false;  // this lane's turn has come, its plan held and it locked A
+        uint32_t slot = 0;   // its place in the request list (when it places)
+        auto settle = [&]() {
+          if (taken) {
+            lockset_add_shared(locks, A);
+            if (ok_b) lockset_add_shared(locks, B);
+            apply(load_plan(i), bits | ((unsigned long long)slot << 32));
+            taken = false;
+          }
+        };
+        const unsigned long long m_a = __builtin_amdgcn_ballot_w64(ok_a), m_b = __builtin_amdgcn_ballot_w64(ok_b);
+        const unsigned long long m_k = __builtin_amdgcn_ballot_w64((bits & 3u) != 0);
         unsigned long long todo = __builtin_amdgcn_ballot_w64(work);
+#ifdef RATSDF_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane == 0) { ctl->stamps[30] -= (unsigned long long)clock64(); ctl->stamps[31] += __popcll(todo); }
+#endif
         while (todo) {  // uniform
           const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
           todo &= todo - 1;
           uint32_t la = kNone, lb = kNone;  // the buckets request j locks (uniform)
           if (!((__builtin_amdgcn_ballot_w64(stale) >> j) & 1ull)) {
-            const unsigned long long m_a = __builtin_amdgcn_ballot_w64(ok_a), m_b = __builtin_amdgcn_ballot_w64(ok_b);
-            const unsigned long long m_k = __builtin_amdgcn_ballot_w64((bits & 3u) != 0);
             if ((m_a >> j) & 1ull) la = __builtin_amdgcn_readlane(A, j);
             if ((m_b >> j) & 1ull) lb = __builtin_amdgcn_readlane(B, j);
-            if (lane == j) {
-              if (ok_a) lockset_add(locks, A);
-              if (ok_b) lockset_add(locks, B);
-              if (ok_a) act = (1ull << 63) | bits | ((unsigned long long)n_req << 32);
-            }
+            taken = taken || (lane == j && ok_a);
+            slot = lane == j ? n_req : slot;
             n_req += (uint32_t)((m_k >> j) & 1ull);
           } else {
 #ifdef RATSDF_STAMPS
             if (lane == 0) ++n_stale;
 #endif
-            if (act) apply(load_plan(i), act & ~(1ull << 63));
-            act = 0;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            settle();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             uint32_t ta = kNone, tb = kNone;
             if (lane == j) replay_from_memory(slow[pidx], &ta, &tb);
             la = __builtin_amdgcn_readlane(ta, j);
@@ -833,7 +856,11 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
           }
           if ((la != kNone && reads(la)) || (lb != kNone && reads(lb))) stale = true;
         }
-        if (act) apply(load_plan(i), act & ~(1ull << 63));
+#ifdef RATSDF_STAMPS
+        if (lane == 0) ctl->stamps[30] += (unsigned long long)clock64();
+#endif
+        settle();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next batch probes the lock set)
       }
       if (lane == 0) {
         if (n_req != n_req_before)

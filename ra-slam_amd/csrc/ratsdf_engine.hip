@@ -1172,10 +1172,10 @@ extern "C" int ratsdf_debug_stamps(ratsdf_engine* e) {
           (double)(t[12] - t[11]) / n, (double)(t[13] - t[12]) / n, (double)t[16] / n, (double)t[17] / n,
           (double)t[18] / n);
   if (t[29])
-    fprintf(stderr, "[stamps] chained-bucket resolver, %llu passes (shader cycles/pass): order + duplicates %.0f | plans %.0f | replay %.0f | apply %.0f | per pass: requests %.1f distinct %.1f stale plans %.2f placed %.1f\n",
+    fprintf(stderr, "[stamps] chained-bucket resolver, %llu passes (shader cycles/pass): order + duplicates %.0f | plans %.0f | replay %.0f | apply %.0f | per pass: requests %.1f distinct %.1f stale plans %.2f placed %.1f | step loop %.0f cycles for %.1f steps\n",
             t[29], (double)(t[22] - t[20]) / t[29], (double)(t[23] - t[22]) / t[29], (double)(t[24] - t[23]) / t[29],
             (double)(t[21] - t[24]) / t[29], (double)t[25] / t[29], (double)t[26] / t[29], (double)t[27] / t[29],
-            (double)t[28] / t[29]);
+            (double)t[28] / t[29], (double)(long long)t[30] / t[29], (double)t[31] / t[29]);
   fprintf(stderr, "[stamps] ranks phase, first pass (cold code) %.0f cycles of the two\n", (double)t[19] / n);
   {
     const double m = t[17] ? (double)t[17] : 1.0;
