@@ -361,8 +361,10 @@ __device__ inline void lockset_add_shared(const LockSet<Lds>& L, uint32_t bucket
 // `global_keys`: kSlowSortCap * 8 bytes: sort keys of passes beyond `lds_cap` requests, plans otherwise.
 // kLds: keys and lock set in LDS (the caller has `lds_locks` and the pass at most min(lds_cap,
 // lds_lock_slots / 4) requests); else wherever they fit.  `lds_chunk`: 4 KiB of LDS in either case.
+// Returns false (uniform, nothing edited yet) when the LDS lock set is too small for the pass's distinct
+// requests: the caller then runs the <false> instantiation.
 template <bool kLds>
-__device__ inline void resolve_slow_requests(const Table& tab, Request* req, uint32_t req_cap,
+__device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uint32_t req_cap,
                                              const SlowRequest* slow, uint32_t slow_cap,
                                              XLock* xlocks, Ctl* ctl,
                                              FrameCtl* F, unsigned long long* lds_keys,
@@ -474,7 +476,16 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
         if ((dup_bits >> (t & 31)) & 1u) ((WordPtr)(skeys + i))[0] |= kDup;
     }
   }
-  // (nobody reads a block name past the last barrier above: the memory becomes the lock set)
+  __syncthreads();  // (the duplicate flags are in the keys)
+  if constexpr (kLds) {
+    // every distinct request takes at most two locks and the set is to stay at most half full
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < n; i += nt) mine += !((uint32_t)skeys[i] & kDup);
+    uint32_t distinct = 0;
+    for (uint32_t r = 0; r < 4; ++r) distinct += (uint32_t)__syncthreads_count(mine > r);  // (n <= 4 * blockDim.x)
+    if (4u * distinct > locks.mask + 1u) return false;  // uniform
+  }
+  // (nobody reads a block name past the barriers above: the memory becomes the lock set)
   for (uint32_t i = tid; i <= locks.mask; i += nt) locks.slot[i] = 0;
   __syncthreads();
   RATSDF_STAMP(ctl->stamps, 22);
@@ -559,7 +570,7 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
       q[1] = v[1];
       q[2] = v[2];
       q[3] = v[3];
-      skeys[i] = 0;  // from here on: the request's action word (none)
+      if (!kLds) skeys[i] = 0;  // from here on: the request's action word (none)
     }
     asm volatile("" ::"v"(touched));
   }
@@ -760,7 +771,7 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
     // in a single lane, each of which waited for its own LDS round trips.  The outcome stays in the lane
     // (an action word) and goes to memory when the batch is through -- or before a stale request reads
     // the directory again.
-    static_assert(!kLds || kSlowDistinctCap >= 512, "the LDS path takes at most 512 requests");
+    static_assert(!kLds || kSlowDistinctCap >= 1024, "the LDS path takes at most 1024 requests");
     if (planned && tid < 64) {
       constexpr uint32_t kNone = 0xFFFFFFFFu;
       const uint32_t lane = tid;
@@ -875,7 +886,7 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
 #endif
       }
     }
-    return;  // (n <= lds_cap on this path: always planned)
+    return true;  // (n <= lds_cap on this path: always planned)
   }
   if (planned) {
     constexpr uint32_t kBatch = 32;  // plans per LDS batch; lds_chunk holds two
@@ -932,7 +943,7 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
     ctl->stamps[29] += 1;
 #endif
   }
-  if (!planned) return;  // uniform
+  if (!planned) return true;  // uniform
 
   // ---- 4. the actions noted, whole workgroup ---------------------------------------------------------
   // (the replay's last batch ended with a barrier: the action words are visible)
@@ -941,6 +952,7 @@ __device__ inline void resolve_slow_requests(const Table& tab, Request* req, uin
     if (act) apply(load_plan(i), act);
   }
   RATSDF_STAMP(ctl->stamps, 21);  // (index 21: end of the pass)
+  return true;
 }
 
 // Exclusive scan of one value per thread across the workgroup: wave-level scan with cross-lane
@@ -1112,7 +1124,7 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
   const uint32_t n_slow = F->n_slow;
   if (n_slow != 0 && !resolved) {  // uniform
     // (LDS: sort keys of up to kSlowLdsCap requests, then 4 KiB for two batches of plans)
-    resolve_slow_requests<false>(tab, req, req_cap, slow, slow_cap, xlocks, ctl, F, skeys, sort_scratch,
+    (void)resolve_slow_requests<false>(tab, req, req_cap, slow, slow_cap, xlocks, ctl, F, skeys, sort_scratch,
                           (uint32_t)kSlowLdsCap, reinterpret_cast<SlowPlan*>(skeys + kSlowLdsCap));
     __syncthreads();
   }

@@ -106,10 +106,11 @@ struct VecIO<1> {
 // 1024-thread one re-cut for 256 threads; everything unusual calls the general functions with their
 // scratch in device memory instead of LDS (rare: first frames of a view, chained buckets).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kFusedSlowCap = 512;  // chained-bucket requests resolved with their keys in the role's LDS
-constexpr uint32_t kFusedLockSlots = 4 * kFusedSlowCap;  // ... and their lock set (resolve_slow_requests)
+constexpr uint32_t kFusedSlowCap = 1024;  // chained-bucket requests resolved with their keys in the role's LDS
+constexpr uint32_t kFusedLockSlots = 2 * kFusedSlowCap;  // ... and their lock set: 512 distinct requests (a third
+                                                         // of a pass's requests are, on the maps measured)
 // LDS words of a k_integrate workgroup: the candidate pass's lists, or the resolver's keys and lock set
-// behind the role's 8 counters (12 KiB: eight workgroups per CU use 96 of its 160 KiB)
+// behind the role's 8 counters (16 KiB: eight workgroups per CU use 128 of its 160 KiB)
 constexpr uint32_t kFusedResolverWords = 8 + 2 * kFusedSlowCap + kFusedLockSlots;
 constexpr uint32_t kIntegLdsWords =
     (sizeof(CandLds) + 3) / 4 > kFusedResolverWords ? (sizeof(CandLds) + 3) / 4 : kFusedResolverWords;
@@ -246,13 +247,12 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
     // (ordinary: keys and lock set in this workgroup's LDS; past kFusedSlowCap requests: in device memory)
     unsigned long long* lds_keys = reinterpret_cast<unsigned long long*>(lds + 8);
     SlowPlan* lds_chunk = nullptr;  // (batches of plans for a replaying thread: neither path below has one)
-    if (n_slow <= kFusedSlowCap)
-      resolve_slow_requests<true>(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F, lds_keys,
-                                  rb.sort_scratch, kFusedSlowCap, lds_chunk, lds + 8 + 2 * kFusedSlowCap,
-                                  kFusedLockSlots);
-    else
-      resolve_slow_requests<false>(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F, lds_keys,
-                                   rb.sort_scratch, 0u, lds_chunk);
+    if (n_slow > kFusedSlowCap ||
+        !resolve_slow_requests<true>(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F, lds_keys,
+                                     rb.sort_scratch, kFusedSlowCap, lds_chunk, lds + 8 + 2 * kFusedSlowCap,
+                                     kFusedLockSlots))
+      (void)resolve_slow_requests<false>(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F, lds_keys,
+                                         rb.sort_scratch, 0u, lds_chunk);
     __syncthreads();
     first_round(std::true_type{});  // again rather than held in registers across the resolver (what it
                                     // placed sits behind the frame's own requests)

@@ -121,18 +121,18 @@ def test_serial_role_as_a_launch_of_its_own(kw, monkeypatch, make_engine, make_o
 
 
 def test_more_chained_requests_than_the_lds_resolver_takes(make_engine, make_oracle):
-    """A 1 024-bucket directory that fills up while the camera jumps 60 degrees a frame: every new block asks
-    from several candidate workgroups and nearly every bucket is full or chained, so frames file 450 -
-    1 700 chained-bucket requests.  Up to 512 the resolver runs with its keys, lock set and stepped replay
-    in the serial workgroup's LDS (resolve_slow_requests<true>); beyond, keys and locks live in device
-    memory and one thread replays (<false>).  Both against the oracle, frame by frame."""
+    """A 2 048-bucket directory that fills up while the camera jumps 60 degrees a frame: every new block asks
+    from several candidate workgroups and most buckets are full or chained, so frames file 200 - 1 300
+    chained-bucket requests.  Up to 512: keys, lock set and stepped replay in the serial workgroup's LDS,
+    order by counting; up to 1 024: the same with a bitonic sort (resolve_slow_requests<true>); beyond, keys
+    and locks in device memory and one thread replays (<false>).  All against the oracle, frame by frame."""
     import torch
     vs, md = 0.01, 4.0
-    kw = dict(bucket_bits=10, block_bits=13)
+    kw = dict(bucket_bits=11, block_bits=13)
     gpu, cpu = make_engine(vs, 6 * vs, **kw), make_oracle(vs, 6 * vs, threads=8, **kw)
     dev = torch.device("cuda", 0)
     seen = []
-    for i in (0, 60, 120, 180, 240, 300, 30):
+    for i in (0, 60, 120, 180, 240, 300, 30, 90, 150, 210):
         f = synthetic.frame("room", i, scale=0.5, noise=True)
         d = [torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")]
         h, w = f["depth"].shape
@@ -142,7 +142,7 @@ def test_more_chained_requests_than_the_lds_resolver_takes(make_engine, make_ora
         assert_maps_equal(gpu, cpu)
         seen.append(gpu.last_frame_stats()["slow_requests"])
     check_totals(gpu, cpu)
-    assert any(0 < n <= 512 for n in seen) and max(seen) > 1000, seen
+    assert any(0 < n <= 512 for n in seen) and any(512 < n <= 1024 for n in seen) and max(seen) > 1024, seen
 
 
 def test_large_map_in_the_default_directory(make_engine, make_oracle):
