@@ -390,7 +390,11 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
   static_assert(sizeof(XLock) == 8 && (kXLockCap & (kXLockCap - 1)) == 0 && kXLockCap >= 2 * kSlowDistinctCap,
                 "xlocks holds 2 * kXLockCap set slots, at most half filled");
   LockSet<kLds> locks{(WordPtr) reinterpret_cast<uint32_t*>(xlocks), 2u * (uint32_t)kXLockCap - 1u};
-  if (kLds) locks = LockSet<kLds>{(WordPtr)lds_locks, lds_lock_slots - 1u};
+  if (kLds) {  // as many slots as the pass can need (4 per request), at most what the caller has
+    uint32_t slots = 64;
+    while (slots < 4u * n && slots < lds_lock_slots) slots <<= 1;
+    locks = LockSet<kLds>{(WordPtr)lds_locks, slots - 1u};
+  }
   constexpr uint32_t kDup = 0x80000000u;  // in the index half of a sorted key
   auto block_key = [](const SlowRequest& s) -> unsigned long long {
     return (unsigned long long)(uint16_t)s.x | ((unsigned long long)(uint16_t)s.y << 16) |
@@ -417,14 +421,24 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
     __syncthreads();
     uint32_t pos[2] = {0, 0};
     bool dup[2] = {false, false};
+    if (n <= nt) {  // uniform: one request per thread (the usual case)
+#pragma unroll 8
+      for (uint32_t j = 0; j < n; ++j) {  // (every lane reads the same words: LDS broadcasts)
+        const unsigned long long kj = skeys[j], bj = bk[j];
+        const bool before = kj < k[0];
+        pos[0] += before;
+        dup[0] |= before & (bj == b[0]);
+      }
+    } else {
 #pragma unroll 4
-    for (uint32_t j = 0; j < n; ++j) {  // (every lane reads the same words: LDS broadcasts)
-      const unsigned long long kj = skeys[j], bj = bk[j];
+      for (uint32_t j = 0; j < n; ++j) {
+        const unsigned long long kj = skeys[j], bj = bk[j];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const bool before = kj < k[u];
-        pos[u] += before;
-        dup[u] |= before && bj == b[u];
+        for (int u = 0; u < 2; ++u) {
+          const bool before = kj < k[u];
+          pos[u] += before;
+          dup[u] |= before & (bj == b[u]);
+        }
       }
     }
     __syncthreads();
@@ -479,11 +493,13 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
   __syncthreads();  // (the duplicate flags are in the keys)
   if constexpr (kLds) {
     // every distinct request takes at most two locks and the set is to stay at most half full
-    uint32_t mine = 0;
-    for (uint32_t i = tid; i < n; i += nt) mine += !((uint32_t)skeys[i] & kDup);
-    uint32_t distinct = 0;
-    for (uint32_t r = 0; r < 4; ++r) distinct += (uint32_t)__syncthreads_count(mine > r);  // (n <= 4 * blockDim.x)
-    if (4u * distinct > locks.mask + 1u) return false;  // uniform
+    if (4u * n > locks.mask + 1u) {  // uniform: more requests than a quarter of the slots -- count the distinct ones
+      uint32_t mine = 0;
+      for (uint32_t i = tid; i < n; i += nt) mine += !((uint32_t)skeys[i] & kDup);
+      uint32_t distinct = 0;
+      for (uint32_t r = 0; r < 4; ++r) distinct += (uint32_t)__syncthreads_count(mine > r);  // (n <= 4 * blockDim.x)
+      if (4u * distinct > locks.mask + 1u) return false;  // uniform
+    }
   }
   // (nobody reads a block name past the barriers above: the memory becomes the lock set)
   for (uint32_t i = tid; i <= locks.mask; i += nt) locks.slot[i] = 0;
@@ -780,64 +796,61 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
         const uint32_t i = base + lane;
         // (what the loop below needs of the plan, in a dozen registers: the record itself is read again
         // when its outcome is applied -- the update kernel this role rides in has none to spare)
-        uint32_t bucket, cb0, cb1, cb2, lo, span, A, B, bits, pidx;
-        bool work, stale, ok_a, ok_b;
-        uint32_t nchain;
-        bool ranged;
+        constexpr uint32_t kAbsent = 0xFFFFFFFEu;  // no such chain entry (never equal to a bucket or to kNone)
+        uint32_t bucket, cb0, cb1, cb2, lo, span1, lock_a, lock_b, bits, pidx, places;
+        bool work, stale;
         {
           SlowPlan pl = load_plan(i < n ? i : base);
           if (i >= n) pl.flags = kPlanDup;
-          const uint32_t flags = pl.flags;
-          nchain = (flags >> 8) & 3u;
+          const uint32_t flags = pl.flags, nchain = (flags >> 8) & 3u;
           work = !(flags & (kPlanDup | kPlanPresent));
           const bool home = (flags & kPlanHome) != 0;
-          ranged = (flags & kPlanFound) != 0;
           bucket = pl.bucket;
-          cb0 = pl.chain_b[0];
-          cb1 = pl.chain_b[1];
-          cb2 = pl.chain_b[2];
+          cb0 = nchain > 0 ? pl.chain_b[0] : kAbsent;
+          cb1 = nchain > 1 ? pl.chain_b[1] : kAbsent;
+          cb2 = nchain > 2 ? pl.chain_b[2] : kAbsent;
           pidx = pl.idx;
-          lo = ((pl.last >> 1) + 1) & tab.bucket_mask;       // buckets the probe looked at:
-          span = ((pl.next >> 1) - lo) & tab.bucket_mask;     // lo .. lo + span (circular)
+          // buckets the probe looked at: lo .. lo + span1 - 1 (circular); none: span1 = 0
+          lo = ((pl.last >> 1) + 1) & tab.bucket_mask;
+          span1 = (flags & kPlanFound) ? (((pl.next >> 1) - lo) & tab.bucket_mask) + 1u : 0u;
           stale = (flags & kPlanComplex) != 0;
           // what the plan does when it holds: try-lock A (home / tail), then B (`next`), voxel_hash.cu:67-70,93-94
-          A = home ? pl.bucket : pl.last >> 1;
-          B = pl.next >> 1;
+          const uint32_t A = home ? pl.bucket : pl.last >> 1, B = pl.next >> 1;
           const uint32_t c_a = home ? pl.c_home : pl.c_last;
-          ok_a = work && !(c_a != kInf && c_a < pl.rank);
-          ok_b = ok_a && !home && B != A && !(pl.c_next != kInf && pl.c_next < pl.rank);
+          const bool ok_a = work && !(c_a != kInf && c_a < pl.rank);
+          const bool ok_b = ok_a && !home && B != A && !(pl.c_next != kInf && pl.c_next < pl.rank);
+          lock_a = ok_a ? A : kNone;  // the locks it takes
+          lock_b = ok_b ? B : kNone;
           const uint32_t kind = home ? (ok_a ? 1u : 0u) : (ok_b ? 2u : 0u);
+          places = kind != 0;
           bits = kind | (ok_a && c_a != kInf && c_a > pl.rank ? 4u : 0u) |
                  (ok_b && pl.c_next != kInf && pl.c_next > pl.rank ? 8u : 0u);
         }
-        auto reads = [&](uint32_t x) -> bool {  // was the plan read from bucket x?
-          return x == bucket || (nchain > 0 && x == cb0) || (nchain > 1 && x == cb1) || (nchain > 2 && x == cb2) ||
-                 (ranged && ((x - lo) & tab.bucket_mask) <= span);
+        // was the plan read from bucket x?  (x: a bucket number; no branches: this runs in every step)
+        auto reads = [&](uint32_t x) -> bool {
+          return (x == bucket) | (x == cb0) | (x == cb1) | (x == cb2) | (((x - lo) & tab.bucket_mask) < span1);
         };
         // stale already?  (locks of the batches before)
         if (work && !stale) {
           stale = lockset_has(locks, bucket);
-          if (!stale && nchain > 0) stale = lockset_has(locks, cb0);
-          if (!stale && nchain > 1) stale = lockset_has(locks, cb1);
-          if (!stale && nchain > 2) stale = lockset_has(locks, cb2);
-          if (!stale && ranged)
-            for (uint32_t g = 0; g <= span && !stale; ++g) stale = lockset_has(locks, (lo + g) & tab.bucket_mask);
+          if (!stale && cb0 != kAbsent) stale = lockset_has(locks, cb0);
+          if (!stale && cb1 != kAbsent) stale = lockset_has(locks, cb1);
+          if (!stale && cb2 != kAbsent) stale = lockset_has(locks, cb2);
+          for (uint32_t g = 0; g < span1 && !stale; ++g) stale = lockset_has(locks, (lo + g) & tab.bucket_mask);
         }
         // A request whose plan holds keeps its outcome in its lane (`taken`, `slot`); locks and stores
         // follow for the whole batch at once -- or earlier, before a stale request reads the directory
         // and the lock set as they stand.
-        bool taken = false;  // this lane's turn has come, its plan held and it locked A
+        bool taken = false;  // this lane's turn has come and its plan held
         uint32_t slot = 0;   // its place in the request list (when it places)
         auto settle = [&]() {
-          if (taken) {
-            lockset_add_shared(locks, A);
-            if (ok_b) lockset_add_shared(locks, B);
+          if (taken && lock_a != kNone) {
+            lockset_add_shared(locks, lock_a);
+            if (lock_b != kNone) lockset_add_shared(locks, lock_b);
             apply(load_plan(i), bits | ((unsigned long long)slot << 32));
-            taken = false;
           }
+          taken = false;
         };
-        const unsigned long long m_a = __builtin_amdgcn_ballot_w64(ok_a), m_b = __builtin_amdgcn_ballot_w64(ok_b);
-        const unsigned long long m_k = __builtin_amdgcn_ballot_w64((bits & 3u) != 0);
         unsigned long long todo = __builtin_amdgcn_ballot_w64(work);
 #ifdef RATSDF_STAMPS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -846,13 +859,14 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
         while (todo) {  // uniform
           const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
           todo &= todo - 1;
-          uint32_t la = kNone, lb = kNone;  // the buckets request j locks (uniform)
-          if (!((__builtin_amdgcn_ballot_w64(stale) >> j) & 1ull)) {
-            if ((m_a >> j) & 1ull) la = __builtin_amdgcn_readlane(A, j);
-            if ((m_b >> j) & 1ull) lb = __builtin_amdgcn_readlane(B, j);
-            taken = taken || (lane == j && ok_a);
-            slot = lane == j ? n_req : slot;
-            n_req += (uint32_t)((m_k >> j) & 1ull);
+          uint32_t la, lb;  // the buckets request j locks (uniform)
+          if (__builtin_expect(!((__builtin_amdgcn_ballot_w64(stale) >> j) & 1ull), 1)) {
+            la = __builtin_amdgcn_readlane(lock_a, j);
+            lb = __builtin_amdgcn_readlane(lock_b, j);
+            const bool me = lane == j;
+            taken |= me;
+            slot = me ? n_req : slot;
+            n_req += __builtin_amdgcn_readlane(places, j);
           } else {
 #ifdef RATSDF_STAMPS
             if (lane == 0) ++n_stale;
@@ -865,7 +879,12 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
             lb = __builtin_amdgcn_readlane(tb, j);
             n_req = __builtin_amdgcn_readlane(n_req, j);
           }
-          if ((la != kNone && reads(la)) || (lb != kNone && reads(lb))) stale = true;
+          // every later request whose plan was read from a bucket locked just now is stale (earlier ones
+          // and j itself may set the flag too: their turn has passed)
+          bool hit = false;
+          if (la != kNone) hit = reads(la);  // uniform
+          if (lb != kNone) hit |= reads(lb);
+          stale |= hit;
         }
 #ifdef RATSDF_STAMPS
         if (lane == 0) ctl->stamps[30] += (unsigned long long)clock64();
