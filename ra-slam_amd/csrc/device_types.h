@@ -82,7 +82,12 @@ struct FrameCtl {
   // line of its own: the committing workgroups POLL it, and waves polling the line of the counters
   // above slow down the very atomics and loads (requests, deletes) that share it.
   uint32_t serial_done;
-  uint32_t pad2[31];
+  // A frame with thousands of requests (a new view): the serial workgroup shares its pass over the
+  // requests with the seven workgroups dispatched beside it (kernels_integrate.h: claim_pass).
+  uint32_t help_go;        // its decision: 1 = help, 2 = stay out
+  uint32_t help_winners;   // winners listed so far (append cursor of win_ranks)
+  uint32_t help_done;      // helpers that have finished and drained their stores
+  uint32_t pad2[28];
   // Counters of the carve pass, which k_integrate bumps with atomics while every one of its
   // workgroups reads the first line when it starts: a line of their own as well.
   uint32_t n_delcand;      // slot-0 deletes done by k_integrate (pool release pending)

@@ -44,6 +44,9 @@ __device__ inline void zero_frame_ctl(FrameCtl* F) {
   F->pending = 0;
   F->n_winlist = 0;
   F->serial_done = 0;
+  F->help_go = 0;
+  F->help_winners = 0;
+  F->help_done = 0;
   F->n_delcand = 0;
   F->n_slow_del = 0;
   F->slow_resolved = 0;

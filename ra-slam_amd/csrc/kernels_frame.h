@@ -350,6 +350,8 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((am
   if (blockIdx.x == 0) {  // the frame's serial role
     const uint32_t nwords = ((uint32_t)(J->P.W * J->P.H) * (uint32_t)J->P.S + 31u) / 32u;
     serial_workgroup(E, par, nwords, role_lds, RATSDF_DBG(J->P, 21));
+  } else {
+    serial_helper(E, par, role_lds, blockIdx.x, RATSDF_DBG(J->P, 22));
   }
 }
 

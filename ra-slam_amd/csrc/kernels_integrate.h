@@ -194,6 +194,74 @@ __device__ inline void mark_winner(Request* p, const Request& r) {
   st_agent(reinterpret_cast<uint32_t*>(p) + 1, (uint32_t)(uint16_t)r.z | ((uint32_t)kReqWinner << 16));
 }
 
+// The pass over the frame's requests that decides the winners: request -> its bucket's claim -> (winner:
+// flag in the request, rank into win_ranks).  Chunks of kClaimChunk requests, four per thread in flight;
+// this workgroup takes chunks first, first + stride, ...  The list position of a winner comes from the
+// workgroup's own LDS counter (`cursor` null: the serial workgroup alone, positions 0, 1, ...) or, when
+// several workgroups share the pass, from a device-wide cursor bumped once per chunk.
+// lds: [1] winners of this workgroup so far (caller zeroes), [4] / [5] scratch of the shared mode.
+constexpr uint32_t kClaimPerThread = 4;
+constexpr uint32_t kClaimChunk = kClaimPerThread * 256;
+constexpr uint32_t kHelpMin = 4 * kClaimChunk;  // requests from which the seven neighbours help
+constexpr uint32_t kSerialGroup = 8;            // workgroups of the serial group (the first is the role)
+__device__ __forceinline__ void claim_pass(const Table& tab, const RankBufs& rb, uint32_t n, uint32_t* lds,
+                                           uint32_t first, uint32_t stride, uint32_t* cursor,
+                                           const Request& r0, const Request& r1) {
+  constexpr uint32_t NT = 256;
+  constexpr int kU = (int)kClaimPerThread;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t base = first * kClaimChunk; base < n; base += stride * kClaimChunk) {  // uniform
+    Request r[kU];
+    uint32_t c[kU];
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {  // (agent scope: requests the resolver appended are read past this CU's L1)
+      const uint32_t i = base + (uint32_t)k * NT + tid;
+      r[k] = Request{0, 0, 0, 0, 0, 0};
+      if (base == 0 && k == 0) r[k] = r0;
+      else if (base == 0 && k == 1) r[k] = r1;
+      else if (i < n) r[k] = ld_agent_request(rb.req + i);
+    }
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      const uint32_t i = base + (uint32_t)k * NT + tid;
+      c[k] = kInf;
+      if (i < n) c[k] = tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)];
+    }
+    // the winners' ranks go to a compact list; the committing waves turn a rank into the winner's
+    // position in raster order (= order of the AquireBlock calls) by counting the smaller ones.
+    // A request the resolver placed is a winner as it stands (its bucket's claim is not its own).
+    uint32_t at[kU];
+    if (cursor) {  // uniform
+      if (tid == 0) lds[4] = 0;
+      lds_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      const uint32_t i = base + (uint32_t)k * NT + tid;
+      at[k] = kInf;
+      if (i >= n) continue;
+      const bool placed = (r[k].flags & kReqPlaced) != 0;
+      if (placed || c[k] == r[k].rank) {
+        if (!placed) mark_winner(rb.req + i, r[k]);
+        at[k] = atomicAdd(&lds[cursor ? 4 : 1], 1u);
+      }
+    }
+    uint32_t off = 0;
+    if (cursor) {
+      lds_barrier();
+      if (tid == 0) {
+        const uint32_t cnt = lds[4];
+        lds[5] = cnt ? __hip_atomic_fetch_add(cursor, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      }
+      lds_barrier();
+      off = lds[5];
+    }
+#pragma unroll
+    for (int k = 0; k < kU; ++k)
+      if (at[k] != kInf) st_agent(&rb.win_ranks[off + at[k]], r[k].rank);
+  }
+}
+
 __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, uint32_t nwords,
                                       uint32_t* lds /* >= 8 words */) {
   constexpr uint32_t NT = 256;
@@ -236,6 +304,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
     }
   };
   const uint32_t n_slow = F->n_slow;
+  RATSDF_STAMP(ctl->stamps, 8);
   first_round(std::false_type{});
   // Chained-bucket requests (a map of tens of thousands of blocks has a few in most frames): the
   // resolver replays them in rank order against the claim table and appends what it places to the
@@ -263,6 +332,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
 
   const bool fast = (!pend || nd + ns <= kSmallCarve) && n <= kFusedRank;
   if (__builtin_expect(!fast, 0)) {  // uniform: the general functions, scratch in device memory
+    if (tid == 0) st_agent(&F->help_go, 2u);  // (the neighbours stay out)
     serial_general(E, par, nwords, nf0, true);
     return 2u;
   }
@@ -276,38 +346,28 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
   if (pend) u = reinterpret_cast<const uint4*>(cb.upd_wg)[tid];
   if (tid < 3) lds[tid] = 0;  // [0] slow deletes that happened, [1] winners, [2] voxels updated
   lds_barrier();
-  constexpr int kU = 4;
-  for (uint32_t base = 0; base < n; base += kU * NT) {  // uniform
-    Request r[kU];
-    uint32_t c[kU];
-#pragma unroll
-    for (int k = 0; k < kU; ++k) {  // (agent scope: requests the resolver appended are read past this CU's L1)
-      const uint32_t i = base + (uint32_t)k * NT + tid;
-      r[k] = Request{0, 0, 0, 0, 0, 0};
-      if (base == 0 && k == 0) r[k] = r0;
-      else if (base == 0 && k == 1) r[k] = r1;
-      else if (i < n) r[k] = ld_agent_request(rb.req + i);  // (nothing is issued for the steady state's few hundred)
-    }
-#pragma unroll
-    for (int k = 0; k < kU; ++k) {
-      const uint32_t i = base + (uint32_t)k * NT + tid;
-      c[k] = kInf;
-      if (i < n) c[k] = tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)];
-    }
-    // the winners' ranks go to a compact list; the committing waves turn a rank into the winner's
-    // position in raster order (= order of the AquireBlock calls) by counting the smaller ones.
-    // A request the resolver placed is a winner as it stands (its bucket's claim is not its own).
-#pragma unroll
-    for (int k = 0; k < kU; ++k) {
-      const uint32_t i = base + (uint32_t)k * NT + tid;
-      if (i >= n) continue;
-      const bool placed = (r[k].flags & kReqPlaced) != 0;
-      if (placed || c[k] == r[k].rank) {
-        if (!placed) mark_winner(rb.req + i, r[k]);
-        st_agent(&rb.win_ranks[atomicAdd(&lds[1], 1u)], r[k].rank);
+  RATSDF_STAMP(ctl->stamps, 9);
+  // A frame with thousands of requests: the seven workgroups dispatched beside this one take seven eighths
+  // of the pass (serial_helper); this workgroup tells them (help_go), takes its share, and waits for them.
+  const bool helped = n > kHelpMin;  // uniform
+  if (tid == 0) st_agent(&F->help_go, helped ? 1u : 2u);
+  if (__builtin_expect(helped, 0)) {
+    claim_pass(tab, rb, n, lds, 0, kSerialGroup, &F->help_winners, r0, r1);
+    if (tid == 0) {  // bounded wait for the helpers' "done and drained"
+      const unsigned long long t0 = (unsigned long long)wall_clock64();
+      while (ld_agent(&F->help_done) < kSerialGroup - 1) {
+        if ((unsigned long long)wall_clock64() - t0 > kSerialWaitTicks) {
+          set_error(ctl, RATSDF_ERR_TIMEOUT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
       }
+      lds[1] = ld_agent(&F->help_winners);
     }
+  } else {
+    claim_pass(tab, rb, n, lds, 0, 1, nullptr, r0, r1);
   }
+  RATSDF_STAMP(ctl->stamps, 10);
   if (pend) {  // previous frame: count of its head / chain deletes, voxels-updated sum
     for (uint32_t j = tid; j < ns; j += NT)
       if (cb.slow[j].state == 2) atomicAdd(&lds[0], 1u);
@@ -350,6 +410,9 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
     F->pending = 1;  // this frame now owes a carve_finalize
     ctl->num_free = nf - (int32_t)take;
   }
+  RATSDF_STAMP(ctl->stamps, 11);
+  RATSDF_STAMP(ctl->stamps, 12);
+  RATSDF_STAMP(ctl->stamps, 13);
   return 1u;
 }
 
@@ -372,6 +435,37 @@ __device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint
     }
     if (!withhold) st_agent(&E->ctl->fr[par].serial_done, how);
   }
+}
+
+// Workgroups 1 .. 7 of the serial group: wait for the serial workgroup's word; when it asks, take every
+// eighth chunk of the pass over the requests; report when every store has drained.  (`withhold`:
+// diagnostic build only, RATSDF_DEBUG=22 -- never report, the serial workgroup's bounded wait expires.)
+__device__ __forceinline__ void serial_helper(EnginePtr E, uint32_t par, uint32_t* lds, uint32_t wg,
+                                              bool withhold = false) {
+  Ctl* ctl = E->ctl;
+  FrameCtl* F = &ctl->fr[par];
+  if (threadIdx.x == 0) {
+    uint32_t v = 0;
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    while ((v = ld_agent(&F->help_go)) == 0u) {
+      if ((unsigned long long)wall_clock64() - t0 > kSerialWaitTicks) break;  // (the role reports its own expiry)
+      __builtin_amdgcn_s_sleep(8);
+    }
+    lds[0] = v;
+    lds[1] = 0;
+  }
+  lds_barrier();
+  if (lds[0] != 1u) return;  // uniform: an ordinary frame
+  const Table tab = ld_const(&E->tab);
+  const RankBufs rb = ld_const(&E->rb);
+  uint32_t n = ld_agent(&F->n_req);  // (agent scope, here and for the requests: the chained-bucket resolver
+  if (n > rb.req_cap) n = rb.req_cap;  //  of this launch may have appended some)
+  const Request none{0, 0, 0, 0, 0, 0};
+  claim_pass(tab, rb, n, lds, wg, kSerialGroup, &F->help_winners, none, none);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0 && !withhold)
+    (void)__hip_atomic_fetch_add(&F->help_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // |(int)roundf(x)| in one instruction (see integrate_block)
@@ -821,6 +915,8 @@ __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((am
   }
   if (blockIdx.x == 0)
     serial_workgroup(E, A.par, ((uint32_t)(P.W * P.H) * (uint32_t)P.S + 31u) / 32u, role_lds, RATSDF_DBG(P, 21));
+  else
+    serial_helper(E, A.par, role_lds, blockIdx.x, RATSDF_DBG(P, 22));
 }
 
 }  // namespace ratsdf

@@ -114,11 +114,12 @@ def test_entry_points_work_from_another_thread(make_engine, make_oracle):
 
 
 @pytest.mark.parametrize("switch,what", [(20, "slow_resolved (carve_resolve_gate, k_front)"),
-                                         (21, "serial_done (the serial role's flag, k_integrate)")])
+                                         (21, "serial_done (the serial role's flag, k_integrate)"),
+                                         (22, "help_done (the serial role's helpers in a frame of a new view)")])
 def test_in_launch_waits_are_bounded(switch, what):
-    """The two in-launch waits between workgroups rely on dispatch order, which HIP
-    does not promise, so they are bounded.  The diagnostic build can withhold either flag
-    (RATSDF_DEBUG=20 / 21): the waiters must give up after the 2 s bound, the frame must END (no hung
+    """The in-launch waits between workgroups rely on dispatch order, which HIP
+    does not promise, so they are bounded.  The diagnostic build can withhold each flag
+    (RATSDF_DEBUG=20 / 21 / 22): the waiters must give up after the 2 s bound, the frame must END (no hung
     GPU), the error must surface as RATSDF_ERR_TIMEOUT (status 7, sticky), and the engine must still be
     queryable and destroyable.  Runs in a child process: the diagnostic library is selected at import."""
     import os
@@ -133,8 +134,12 @@ import sys, time
 sys.path.insert(0, r'{root / "ra-slam_amd"}')
 import ratsdf
 from ratsdf import synthetic
-e = ratsdf.TSDFGrid(0.02, 0.12, bucket_bits=9, block_bits=14)   # 512 buckets: chained deletes in most frames
-frames = [synthetic.frame('room', i, scale=0.25, noise=True, holes=True) for i in range(40)]
+if {switch} == 22:   # a whole new view: thousands of requests, the pass over them is shared
+    e = ratsdf.TSDFGrid(0.002, 0.012)
+    frames = [synthetic.frame('room', i, cam='l515_720p', noise=True, holes=True) for i in range(4)] * 10
+else:
+    e = ratsdf.TSDFGrid(0.02, 0.12, bucket_bits=9, block_bits=14)   # 512 buckets: chained deletes in most frames
+    frames = [synthetic.frame('room', i, scale=0.25, noise=True, holes=True) for i in range(40)]
 t0 = time.time()
 status = 0
 for i in range(0, 40, 4):      # back-to-back frames: the hand-offs only exist inside a batch

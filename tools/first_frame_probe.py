@@ -32,6 +32,9 @@ for rep in range(2):
         dt = time.perf_counter() - t0
         if stamps and f is frames[0]:
             ws(eng._h, 0)   # prints the wave stamps of the launch just finished
+            fn0 = eng.lib.dll.ratsdf_debug_stamps
+            fn0.argtypes = [ctypes.c_void_p]
+            fn0(eng._h)     # ... and the serial role's phases of this frame alone
         print(f"rep {rep}: frame wall {dt * 1e6:8.1f} us  {eng.last_frame_stats()}", flush=True)
     if "stamps" in os.environ["RATSDF_LIB"]:
         fn = eng.lib.dll.ratsdf_debug_stamps
