@@ -259,7 +259,7 @@ __global__ void k_alloc_list(Table tab, FrameParams P, const int16_t* pos, int n
 // fills the first empty home entry at that time unless an earlier slow request locked x first.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSlowSortCap = 16384;   // slow requests per pass (bitonic sort by rank)
-constexpr int kSlowLdsCap = 3584;     // ... sorted in LDS up to this many, in global scratch beyond
+constexpr int kSlowLdsCap = 4096;     // ... sorted in LDS up to this many, in global scratch beyond
 // dynamic LDS of the serial role: sort keys | rank lists (alloc_rank_role) | carve_finalize scratch
 constexpr int kSerialLdsBytes = 34 * 1024;
 constexpr int kSlowDistinctCap = 1024;
@@ -288,7 +288,7 @@ enum : uint32_t {
   kPlanComplex = 32,   // long chain or long probe: replayed from memory
 };
 constexpr uint32_t kPlanSpan = 8;  // buckets probed for a plan
-constexpr uint32_t kSlowPlanCap = (uint32_t)kSlowSortCap * 8u / 64u;  // plans that fit the sort scratch
+constexpr uint32_t kSlowPlanCap = 2048;  // requests of a pass that get a plan (their own 128 KiB behind the sort keys)
 
 // Pointer to T in LDS (address space 3: ds_read / ds_write) or anywhere (flat).  The resolver's tables sit
 // in LDS on its ordinary path; through generic pointers every access was a FLAT instruction, which waits
@@ -310,32 +310,28 @@ struct LockSet {
   typename PtrOf<Lds, uint32_t>::type slot;
   uint32_t mask;  // slots - 1 (a power of two); at most half of them are ever filled
 };
+// (a set in device memory is read and written past the CU's L1: its slots are claimed with atomics, which
+// act in L2)
+template <bool Lds>
+__device__ inline uint32_t lockset_slot(const LockSet<Lds>& L, uint32_t h) {
+  if constexpr (Lds) return L.slot[h];
+  else return __hip_atomic_load(&L.slot[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <bool Lds>
 __device__ inline bool lockset_has(const LockSet<Lds>& L, uint32_t bucket) {
   for (uint32_t h = (bucket * 2654435761u) & L.mask;; h = (h + 1) & L.mask) {
-    const uint32_t v = L.slot[h];
+    const uint32_t v = lockset_slot(L, h);
     if (v == 0) return false;
     if (v == bucket + 1) return true;
   }
 }
+// (several lanes may add at once -- distinct buckets: the slot is claimed with a compare-and-swap)
 template <bool Lds>
 __device__ inline void lockset_add(const LockSet<Lds>& L, uint32_t bucket) {
   for (uint32_t h = (bucket * 2654435761u) & L.mask;; h = (h + 1) & L.mask) {
-    const uint32_t v = L.slot[h];
-    if (v == bucket + 1) return;
-    if (v == 0) {
-      L.slot[h] = bucket + 1;
-      return;
-    }
-  }
-}
-// ... by several lanes at once (distinct buckets): the slot is claimed with a compare-and-swap
-template <bool Lds>
-__device__ inline void lockset_add_shared(const LockSet<Lds>& L, uint32_t bucket) {
-  for (uint32_t h = (bucket * 2654435761u) & L.mask;; h = (h + 1) & L.mask) {
     uint32_t expected = 0;
     if (__hip_atomic_compare_exchange_strong(&L.slot[h], &expected, bucket + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_WORKGROUP) ||
+                                             Lds ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT) ||
         expected == bucket + 1)
       return;
   }
@@ -361,7 +357,8 @@ __device__ inline void lockset_add_shared(const LockSet<Lds>& L, uint32_t bucket
 //  4. the noted actions are applied by the whole workgroup.
 // `xlocks`: kXLockCap * 8 bytes of device memory, the lock set unless the caller has LDS for it
 // (`lds_locks`, `lds_lock_slots` words, a power of two) and the pass at most a quarter as many requests.
-// `global_keys`: kSlowSortCap * 8 bytes: sort keys of passes beyond `lds_cap` requests, plans otherwise.
+// `global_keys`: kSlowSortCap * 8 bytes for the sort keys of passes beyond `lds_cap` requests, followed by
+// kSlowPlanCap plans.
 // kLds: keys and lock set in LDS (the caller has `lds_locks` and the pass at most min(lds_cap,
 // lds_lock_slots / 4) requests); else wherever they fit.  `lds_chunk`: 4 KiB of LDS in either case.
 // Returns false (uniform, nothing edited yet) when the LDS lock set is too small for the pass's distinct
@@ -372,12 +369,10 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
                                              XLock* xlocks, Ctl* ctl,
                                              FrameCtl* F, unsigned long long* lds_keys,
                                              unsigned long long* global_keys,
-                                             uint32_t lds_cap, SlowPlan* lds_chunk,
+                                             uint32_t lds_cap,
                                              uint32_t* lds_locks = nullptr, uint32_t lds_lock_slots = 0) {
   using KeyPtr = typename PtrOf<kLds, unsigned long long>::type;
   using WordPtr = typename PtrOf<kLds, uint32_t>::type;
-  using ChunkPtr = typename PtrOf<true, u32x4>::type;
-  const ChunkPtr chunk = (ChunkPtr)lds_chunk;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   uint32_t n = F->n_slow;
   if (n > slow_cap) n = slow_cap;
@@ -512,8 +507,8 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
   // ---- 2. plans ----------------------------------------------------------------------------------
   // (in the sort scratch, which a pass of at most lds_cap requests leaves unused; a pass without plans
   // still does the loads: they warm the caches for the replay from memory)
-  const bool planned = n <= lds_cap && n <= kSlowPlanCap;  // uniform
-  SlowPlan* plans = reinterpret_cast<SlowPlan*>(global_keys);
+  const bool planned = n <= kSlowPlanCap;  // uniform
+  SlowPlan* plans = reinterpret_cast<SlowPlan*>(global_keys + kSlowSortCap);
   for (uint32_t i = tid; i < n; i += nt) {
     const uint32_t key_lo = (uint32_t)skeys[i];
     SlowPlan pl;
@@ -589,7 +584,6 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
       q[1] = v[1];
       q[2] = v[2];
       q[3] = v[3];
-      if (!kLds) skeys[i] = 0;  // from here on: the request's action word (none)
     }
     asm volatile("" ::"v"(touched));
   }
@@ -648,18 +642,21 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
   };
 
   // ---- 3. replay ---------------------------------------------------------------------------------
-  // Thread 0 replays; the plans reach it through LDS, 32 at a time, fetched by the second wave one batch
-  // ahead (a plan fetched from memory by the replaying thread itself cost it a full memory latency per
-  // request -- ~1 600 cycles beside a running voxel update -- however early the load was issued).
+  // The first wave replays, 64 requests at a time, one per lane, in rank order.  What a request decides
+  // from its plan is known beforehand (its claims against its rank); what the serial order adds is only
+  // this: a request whose plan was read from a bucket that an EARLIER request has locked is stale.  So the
+  // wave steps through the batch in order; the request whose turn it is announces the locks it takes
+  // (readlane) and every later lane tests them against the buckets its plan was read from -- two readlanes
+  // and ten compares per request, no branch, instead of ~300 instructions in a single lane each of which
+  // waited for its own LDS round trips.  The outcome stays in the lane; locks and stores follow for the
+  // whole batch at once -- or earlier, before a stale request reads the directory and the lock set as they
+  // stand (replay_from_memory: the reference's code path, one lane).
   // The pass's only writer of the request list (the frame's ordinary requests were filed by the launch
   // before): the list's counter lives in a register and is published once at the end.
-  uint32_t n_x = 0, n_d = 0, n_req = 0, n_req_before = 0;
-  uint32_t unapplied = 0;  // actions noted for requests [unapplied, si) are not in memory yet
-  bool stop = false;
+  uint32_t n_x = 0, n_req = 0, n_req_before = 0;
 #ifdef RATSDF_STAMPS
   uint32_t n_stale = 0;
 #endif
-  if (tid == 0) n_req = n_req_before = F->n_req;
   // Allocate's try-lock of `bucket` at time `time` (voxel_hash.cu:67-70,93-94) given the bucket's claim
   // `c`: fails when the bucket's leader (claim earlier than `time`) or an earlier chained request of
   // the pass holds it; a later leader must find the lock taken (*clear: its claim is to be reset).
@@ -732,66 +729,16 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
     write_link(last, last_w1, next);
     write_placed(next, k0, k1, time, n_req++);
   };
-  // one request of the pass, its plan in hand
-  auto replay_planned = [&](uint32_t si, const SlowPlan& pl) {
-    if (pl.flags & kPlanDup) return;  // same block, later rank: irrelevant
-    if (n_d++ >= (uint32_t)kSlowDistinctCap) {
-      set_error(ctl, RATSDF_ERR_CAPACITY);
-      stop = true;
-      return;
-    }
-    if (pl.flags & kPlanPresent) return;  // nothing the pass does removes a block
-    bool stale = (pl.flags & kPlanComplex) != 0 || lockset_has(locks, pl.bucket);
-    const uint32_t nchain = (pl.flags >> 8) & 3u;
-    if (!stale && nchain > 0) stale = lockset_has(locks, pl.chain_b[0]);
-    if (!stale && nchain > 1) stale = lockset_has(locks, pl.chain_b[1]);
-    if (!stale && nchain > 2) stale = lockset_has(locks, pl.chain_b[2]);
-    if (!stale && (pl.flags & kPlanFound)) {
-      const uint32_t bn = pl.next >> 1;
-      for (uint32_t bq = ((pl.last >> 1) + 1) & tab.bucket_mask;; bq = (bq + 1) & tab.bucket_mask) {
-        stale = lockset_has(locks, bq);
-        if (stale || bq == bn) break;
-      }
-    }
-    if (stale) {
-#ifdef RATSDF_STAMPS
-      ++n_stale;
-#endif
-      for (uint32_t j = unapplied; j < si; ++j) {
-        const unsigned long long act = skeys[j];
-        if (act) {
-          apply(load_plan(j), act);
-          skeys[j] = 0;
-        }
-      }
-      unapplied = si + 1;
-      uint32_t ta, tb;
-      replay_from_memory(slow[pl.idx], &ta, &tb);
-      return;
-    }
-    bool clear_a = false, clear_b = false;
-    unsigned long long act = 0;
-    if (pl.flags & kPlanHome) {
-      if (try_lock(pl.bucket, pl.c_home, pl.rank, &clear_a)) act = 1u | ((unsigned long long)n_req++ << 32);
-    } else if (try_lock(pl.last >> 1, pl.c_last, pl.rank, &clear_a)) {
-      if (try_lock(pl.next >> 1, pl.c_next, pl.rank, &clear_b)) act = 2u | ((unsigned long long)n_req++ << 32);
-      else act = 1ull << 63;  // (so that the word is not zero when only the claim is to be cleared)
-    }
-    if (act) skeys[si] = act | (clear_a ? 4u : 0u) | (clear_b ? 8u : 0u);
-  };
-
-  if constexpr (kLds) {
-    // Keys and locks in LDS: the first wave replays, 64 requests at a time, one per lane, in rank order.
-    // What a request decides from its plan is known beforehand (its claims against its rank); what
-    // the serial order adds is only this: a request whose plan was read from a bucket that an EARLIER
-    // request has locked is stale.  So the lanes step through the batch in order, the request whose turn
-    // it is adds its locks to the set (one lane) and announces them (readlane), and every later lane
-    // tests them against the buckets its plan was read from: ~50 instructions per request instead of ~300
-    // in a single lane, each of which waited for its own LDS round trips.  The outcome stays in the lane
-    // (an action word) and goes to memory when the batch is through -- or before a stale request reads
-    // the directory again.
-    static_assert(!kLds || kSlowDistinctCap >= 1024, "the LDS path takes at most 1024 requests");
-    if (planned && tid < 64) {
+  bool by_wave = planned;  // uniform
+  if (planned && !kLds) {  // (the LDS path has counted already) at most kSlowDistinctCap distinct requests
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < n; i += nt) mine += !((uint32_t)skeys[i] & kDup);
+    uint32_t distinct = 0;
+    for (uint32_t r = 0; r < (kSlowPlanCap + 255u) / 256u; ++r) distinct += (uint32_t)__syncthreads_count(mine > r);
+    by_wave = distinct <= (uint32_t)kSlowDistinctCap;
+  }
+  if (by_wave) {
+    if (tid < 64) {
       constexpr uint32_t kNone = 0xFFFFFFFFu;
       const uint32_t lane = tid;
       n_req = n_req_before = F->n_req;  // (uniform)
@@ -848,8 +795,8 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
         uint32_t slot = 0;   // its place in the request list (when it places)
         auto settle = [&]() {
           if (taken && lock_a != kNone) {
-            lockset_add_shared(locks, lock_a);
-            if (lock_b != kNone) lockset_add_shared(locks, lock_b);
+            lockset_add(locks, lock_a);
+            if (lock_b != kNone) lockset_add(locks, lock_b);
             apply(load_plan(i), bits | ((unsigned long long)slot << 32));
           }
           taken = false;
@@ -908,40 +855,12 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
 #endif
       }
     }
-    return true;  // (n <= lds_cap on this path: always planned)
+    return true;
   }
-  if (planned) {
-    constexpr uint32_t kBatch = 32;  // plans per LDS batch; lds_chunk holds two
-    const uint32_t nbatch = (n + kBatch - 1) / kBatch;
-    const bool fetcher = tid >= 64 && tid < 64 + kBatch;  // (blockDim.x >= 128)
-    auto fetch = [&](uint32_t bi) {
-      const uint32_t i = bi * kBatch + (tid - 64);
-      if (i >= n) return;
-      const u32x4* q = reinterpret_cast<const u32x4*>(plans + i);
-      const ChunkPtr d = chunk + ((bi & 1u) * kBatch + (tid - 64)) * 4u;
-      const u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
-      d[0] = v0;
-      d[1] = v1;
-      d[2] = v2;
-      d[3] = v3;
-    };
-    if (fetcher) fetch(0);
-    __syncthreads();
-    for (uint32_t bi = 0; bi < nbatch; ++bi) {  // uniform
-      if (fetcher && bi + 1 < nbatch) fetch(bi + 1);
-      if (tid == 0 && !stop) {
-        const uint32_t lo = bi * kBatch, hi = lo + kBatch < n ? lo + kBatch : n;
-        for (uint32_t si = lo; si < hi && !stop; ++si) {
-          SlowPlan pl;
-          const ChunkPtr q = chunk + ((bi & 1u) * kBatch + (si - lo)) * 4u;
-          const u32x4 v[4] = {q[0], q[1], q[2], q[3]};
-          __builtin_memcpy(&pl, v, sizeof(pl));
-          replay_planned(si, pl);
-        }
-      }
-      __syncthreads();
-    }
-  } else if (tid == 0) {
+  // more requests than plans (or than locks): one thread, everything from memory, as in round 2
+  if (tid == 0) {
+    n_req = n_req_before = F->n_req;
+    uint32_t n_d = 0;
     for (uint32_t si = 0; si < n; ++si) {
       const uint32_t key_lo = (uint32_t)skeys[si];
       if (key_lo & kDup) continue;  // same block, later rank: irrelevant
@@ -952,28 +871,10 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
       uint32_t ta, tb;
       replay_from_memory(slow[key_lo], &ta, &tb);
     }
-  }
-  if (tid == 0) {
     if (n_req != n_req_before)
       __hip_atomic_store(&F->n_req, n_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     RATSDF_STAMP(ctl->stamps, 24);
-#ifdef RATSDF_STAMPS
-    ctl->stamps[25] += n;
-    ctl->stamps[26] += n_d;
-    ctl->stamps[27] += n_stale;
-    ctl->stamps[28] += n_req - n_req_before;
-    ctl->stamps[29] += 1;
-#endif
   }
-  if (!planned) return true;  // uniform
-
-  // ---- 4. the actions noted, whole workgroup ---------------------------------------------------------
-  // (the replay's last batch ended with a barrier: the action words are visible)
-  for (uint32_t i = tid; i < n; i += nt) {
-    const unsigned long long act = skeys[i];
-    if (act) apply(load_plan(i), act);
-  }
-  RATSDF_STAMP(ctl->stamps, 21);  // (index 21: end of the pass)
   return true;
 }
 
@@ -1145,9 +1046,8 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
   RATSDF_STAMP(ctl->stamps, 8);
   const uint32_t n_slow = F->n_slow;
   if (n_slow != 0 && !resolved) {  // uniform
-    // (LDS: sort keys of up to kSlowLdsCap requests, then 4 KiB for two batches of plans)
     (void)resolve_slow_requests<false>(tab, req, req_cap, slow, slow_cap, xlocks, ctl, F, skeys, sort_scratch,
-                          (uint32_t)kSlowLdsCap, reinterpret_cast<SlowPlan*>(skeys + kSlowLdsCap));
+                                       (uint32_t)kSlowLdsCap);
     __syncthreads();
   }
   uint32_t n = n_slow ? ld_agent_u32(&F->n_req) : F->n_req;  // the resolver appends requests

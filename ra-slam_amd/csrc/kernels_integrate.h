@@ -315,13 +315,11 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
   if (__builtin_expect(n_slow != 0, 0)) {  // uniform; the resolver's one call site in this role
     // (ordinary: keys and lock set in this workgroup's LDS; past kFusedSlowCap requests: in device memory)
     unsigned long long* lds_keys = reinterpret_cast<unsigned long long*>(lds + 8);
-    SlowPlan* lds_chunk = nullptr;  // (batches of plans for a replaying thread: neither path below has one)
     if (n_slow > kFusedSlowCap ||
         !resolve_slow_requests<true>(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F, lds_keys,
-                                     rb.sort_scratch, kFusedSlowCap, lds_chunk, lds + 8 + 2 * kFusedSlowCap,
-                                     kFusedLockSlots))
+                                     rb.sort_scratch, kFusedSlowCap, lds + 8 + 2 * kFusedSlowCap, kFusedLockSlots))
       (void)resolve_slow_requests<false>(tab, rb.req, rb.req_cap, rb.slow, rb.slow_cap, rb.xlocks, ctl, F, lds_keys,
-                                         rb.sort_scratch, 0u, lds_chunk);
+                                         rb.sort_scratch, 0u);
     __syncthreads();
     first_round(std::true_type{});  // again rather than held in registers across the resolver (what it
                                     // placed sits behind the frame's own requests)

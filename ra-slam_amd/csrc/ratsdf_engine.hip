@@ -764,7 +764,8 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->d_eng, sizeof(EngineDev)));
   CREATE_CHK(hipMalloc(&e->slow, (size_t)kSlowCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->xlocks, (size_t)kXLockCap * sizeof(XLock)));
-  CREATE_CHK(hipMalloc(&e->sort_scratch, (size_t)kSlowSortCap * sizeof(unsigned long long)));
+  CREATE_CHK(hipMalloc(&e->sort_scratch, (size_t)kSlowSortCap * sizeof(unsigned long long) +
+                                               (size_t)kSlowPlanCap * sizeof(SlowPlan)));  // sort keys | plans
   CREATE_CHK(hipMalloc(&e->serial_scratch, (size_t)kSerialLdsBytes));
   CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * kVisWG * 8));
   CREATE_CHK(hipMalloc(&e->wg_count, (size_t)e->nwg * 4));
