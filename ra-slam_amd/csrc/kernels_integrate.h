@@ -202,30 +202,49 @@ __device__ inline void mark_winner(Request* p, const Request& r) {
 // lds: [1] winners of this workgroup so far (caller zeroes), [4] / [5] scratch of the shared mode.
 constexpr uint32_t kClaimPerThread = 4;
 constexpr uint32_t kClaimChunk = kClaimPerThread * 256;
+constexpr uint32_t kClaimPre = 3;  // requests per thread that ride in the serial role's first round of loads
+                                   // (768 requests: a frame of the 640x480 stream files 700 - 1 000)
 constexpr uint32_t kHelpMin = 4 * kClaimChunk;  // requests from which the seven neighbours help
 constexpr uint32_t kSerialGroup = 8;            // workgroups of the serial group (the first is the role)
+// (what the pass needs of a request: block, flags, rank -- its first three words)
+struct RequestHead {
+  uint32_t w0, w1, rank;  // x | y << 16, z | flags << 16, raster rank
+};
+__device__ inline RequestHead ld_agent_request_head(const Request* p) {
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+  const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  return RequestHead{(uint32_t)a, (uint32_t)(a >> 32),
+                     __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+}
+__device__ inline RequestHead ld_request_head(const Request* p) {
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+  const uint2 a = *reinterpret_cast<const uint2*>(q);
+  return RequestHead{a.x, a.y, q[2]};
+}
 __device__ __forceinline__ void claim_pass(const Table& tab, const RankBufs& rb, uint32_t n, uint32_t* lds,
                                            uint32_t first, uint32_t stride, uint32_t* cursor,
-                                           const Request& r0, const Request& r1) {
+                                           const RequestHead (&pre)[kClaimPre]) {
   constexpr uint32_t NT = 256;
   constexpr int kU = (int)kClaimPerThread;
   const uint32_t tid = threadIdx.x;
   for (uint32_t base = first * kClaimChunk; base < n; base += stride * kClaimChunk) {  // uniform
-    Request r[kU];
+    RequestHead r[kU];
     uint32_t c[kU];
 #pragma unroll
     for (int k = 0; k < kU; ++k) {  // (agent scope: requests the resolver appended are read past this CU's L1)
       const uint32_t i = base + (uint32_t)k * NT + tid;
-      r[k] = Request{0, 0, 0, 0, 0, 0};
-      if (base == 0 && k == 0) r[k] = r0;
-      else if (base == 0 && k == 1) r[k] = r1;
-      else if (i < n) r[k] = ld_agent_request(rb.req + i);
+      r[k] = RequestHead{0, 0, 0};
+      if (base == 0 && k < kClaimPre) r[k] = pre[k];  // (rode in the caller's first round of loads)
+      else if (i < n) r[k] = ld_agent_request_head(rb.req + i);
     }
 #pragma unroll
     for (int k = 0; k < kU; ++k) {
       const uint32_t i = base + (uint32_t)k * NT + tid;
       c[k] = kInf;
-      if (i < n) c[k] = tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)];
+      if (i < n)
+        c[k] = tab.claim[block_hash((int16_t)(r[k].w0 & 0xFFFFu), (int16_t)(r[k].w0 >> 16), (int16_t)(r[k].w1 & 0xFFFFu),
+                                    tab.bucket_mask)];
     }
     // the winners' ranks go to a compact list; the committing waves turn a rank into the winner's
     // position in raster order (= order of the AquireBlock calls) by counting the smaller ones.
@@ -240,9 +259,10 @@ __device__ __forceinline__ void claim_pass(const Table& tab, const RankBufs& rb,
       const uint32_t i = base + (uint32_t)k * NT + tid;
       at[k] = kInf;
       if (i >= n) continue;
-      const bool placed = (r[k].flags & kReqPlaced) != 0;
+      const bool placed = ((r[k].w1 >> 16) & kReqPlaced) != 0;
       if (placed || c[k] == r[k].rank) {
-        if (!placed) mark_winner(rb.req + i, r[k]);
+        if (!placed)  // word 1 = z | flags << 16: the winner flag as one agent-scope word store
+          st_agent(reinterpret_cast<uint32_t*>(rb.req + i) + 1, (r[k].w1 & 0xFFFFu) | ((uint32_t)kReqWinner << 16));
         at[k] = atomicAdd(&lds[cursor ? 4 : 1], 1u);
       }
     }
@@ -280,7 +300,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
   // ---- one round of loads ----
   int32_t nf0;
   uint32_t pend, nd, ns, p_win, p_slow, nv, n;
-  Request r0, r1;
+  RequestHead pre[kClaimPre];  // the first requests (the slots exist whatever the count is)
   auto first_round = [&](auto after_resolver) {
     nf0 = ctl->num_free;
     pend = Fp->pending;
@@ -291,17 +311,13 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
     nv = p_win;
 #pragma unroll
     for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l * kListStride];
-    const Request* q0 = rb.req + (tid < rb.req_cap ? tid : 0);  // the first requests ride in the first round
-    const Request* q1 = rb.req + (tid + NT < rb.req_cap ? tid + NT : 0);
-    if (decltype(after_resolver)::value) {  // what it appended: past this CU's L1
-      n = ld_agent(&F->n_req);
-      r0 = ld_agent_request(q0);
-      r1 = ld_agent_request(q1);
-    } else {
-      n = F->n_req;
-      r0 = *q0;
-      r1 = *q1;
+#pragma unroll
+    for (uint32_t k = 0; k < kClaimPre; ++k) {  // the first requests ride in the first round
+      const Request* q = rb.req + (tid + k * NT < rb.req_cap ? tid + k * NT : 0);
+      if (decltype(after_resolver)::value) pre[k] = ld_agent_request_head(q);  // what it appended: past this CU's L1
+      else pre[k] = ld_request_head(q);
     }
+    n = decltype(after_resolver)::value ? ld_agent(&F->n_req) : F->n_req;
   };
   const uint32_t n_slow = F->n_slow;
   RATSDF_STAMP(ctl->stamps, 8);
@@ -350,7 +366,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
   const bool helped = n > kHelpMin;  // uniform
   if (tid == 0) st_agent(&F->help_go, helped ? 1u : 2u);
   if (__builtin_expect(helped, 0)) {
-    claim_pass(tab, rb, n, lds, 0, kSerialGroup, &F->help_winners, r0, r1);
+    claim_pass(tab, rb, n, lds, 0, kSerialGroup, &F->help_winners, pre);
     if (tid == 0) {  // bounded wait for the helpers' "done and drained"
       const unsigned long long t0 = (unsigned long long)wall_clock64();
       while (ld_agent(&F->help_done) < kSerialGroup - 1) {
@@ -363,7 +379,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
       lds[1] = ld_agent(&F->help_winners);
     }
   } else {
-    claim_pass(tab, rb, n, lds, 0, 1, nullptr, r0, r1);
+    claim_pass(tab, rb, n, lds, 0, 1, nullptr, pre);
   }
   RATSDF_STAMP(ctl->stamps, 10);
   if (pend) {  // previous frame: count of its head / chain deletes, voxels-updated sum
@@ -458,8 +474,8 @@ __device__ __forceinline__ void serial_helper(EnginePtr E, uint32_t par, uint32_
   const RankBufs rb = ld_const(&E->rb);
   uint32_t n = ld_agent(&F->n_req);  // (agent scope, here and for the requests: the chained-bucket resolver
   if (n > rb.req_cap) n = rb.req_cap;  //  of this launch may have appended some)
-  const Request none{0, 0, 0, 0, 0, 0};
-  claim_pass(tab, rb, n, lds, wg, kSerialGroup, &F->help_winners, none, none);
+  const RequestHead none[kClaimPre] = {};  // (chunk 0 is the serial workgroup's)
+  claim_pass(tab, rb, n, lds, wg, kSerialGroup, &F->help_winners, none);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0 && !withhold)
