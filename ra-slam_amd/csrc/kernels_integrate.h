@@ -189,11 +189,6 @@ __device__ __forceinline__ void serial_general(EnginePtr E, uint32_t par, uint32
                   reinterpret_cast<unsigned long long*>(scratch), resolved);
 }
 
-// word 1 of a request = z | flags << 16: the winner flag as one agent-scope word store
-__device__ inline void mark_winner(Request* p, const Request& r) {
-  st_agent(reinterpret_cast<uint32_t*>(p) + 1, (uint32_t)(uint16_t)r.z | ((uint32_t)kReqWinner << 16));
-}
-
 // The pass over the frame's requests that decides the winners: request -> its bucket's claim -> (winner:
 // flag in the request, rank into win_ranks).  Chunks of kClaimChunk requests, four per thread in flight;
 // this workgroup takes chunks first, first + stride, ...  The list position of a winner comes from the
