@@ -347,20 +347,22 @@ __device__ inline void lockset_add(const LockSet<Lds>& L, uint32_t bucket) {
 //  2. one PLAN per request, whole workgroup: the replay's reads (home entries, chain, the probe for a
 //     free slot and the claims beside them) done against the directory as it stands BEFORE the pass, with
 //     their answer and the buckets that answer came from;
-//  3. the replay proper, one thread, registers and LDS only: a plan holds unless one of its buckets has
-//     been locked by an earlier request of the pass -- every edit of the pass (an entry placed, a tail
-//     linked, a claim cleared) is made under that bucket's lock -- and its outcome is noted as an action
-//     word in LDS.  No store is issued here: on this hardware a wave's loads and stores share one counter,
-//     so waiting for the next plan also waited for the write-through stores of the last request (2.5 us
-//     per request).  A stale plan (one pass in ten has one) first has the noted actions applied, then
-//     reads the directory again from memory as the reference would;
-//  4. the noted actions are applied by the whole workgroup.
+//  3. the replay proper, the first wave, 64 requests per batch and one per lane, in rank order: a plan
+//     holds unless one of its buckets has been locked by an earlier request of the pass -- every edit of
+//     the pass (an entry placed, a tail linked, a claim cleared) is made under that bucket's lock -- and
+//     what a holding plan does is known beforehand (its claims against its rank).  The wave steps through
+//     the batch; the request whose turn it is announces its locks (readlane), every later lane tests them
+//     against its plan's buckets.  A stale plan (one pass in ten has one) has the batch's outcomes so far
+//     stored, then reads the directory again from memory as the reference would (one lane);
+//  4. locks into the set and outcomes into memory, by all lanes of the batch at once.  (No store is issued
+//     inside the step loop: on this hardware a wave's loads and stores share one counter, and a loop that
+//     waited for its next plan also waited for the write-through stores of the last request.)
 // `xlocks`: kXLockCap * 8 bytes of device memory, the lock set unless the caller has LDS for it
-// (`lds_locks`, `lds_lock_slots` words, a power of two) and the pass at most a quarter as many requests.
+// (`lds_locks`, `lds_lock_slots` words, a power of two).
 // `global_keys`: kSlowSortCap * 8 bytes for the sort keys of passes beyond `lds_cap` requests, followed by
 // kSlowPlanCap plans.
-// kLds: keys and lock set in LDS (the caller has `lds_locks` and the pass at most min(lds_cap,
-// lds_lock_slots / 4) requests); else wherever they fit.  `lds_chunk`: 4 KiB of LDS in either case.
+// kLds: keys and lock set in LDS (the pass has at most lds_cap requests); else keys in LDS up to lds_cap
+// requests, in `global_keys` beyond, and the lock set in `xlocks`.
 // Returns false (uniform, nothing edited yet) when the LDS lock set is too small for the pass's distinct
 // requests: the caller then runs the <false> instantiation.
 template <bool kLds>
@@ -617,7 +619,7 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
     __hip_atomic_store(&pl[1], (last_w1 & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   };
-  // action word of a planned request: [1:0] 1 = fill the home slot, 2 = link the tail and fill `next`;
+  // outcome of a request whose plan held: [1:0] 1 = fill the home slot, 2 = link the tail and fill `next`;
   // [2] clear the claim of the first bucket locked (home / tail), [3] of `next`'s; [63:32] request slot
   auto apply = [&](const SlowPlan& pl, unsigned long long act) {
     const uint32_t kind = (uint32_t)act & 3u, slot = (uint32_t)(act >> 32);
