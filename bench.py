@@ -604,11 +604,19 @@ def main():
                               "stream sync per frame included; batched = ratsdf_integrate_batch, "
                               "8 frames per call from pageable memory")
         # page-locked copies of the stream's frames
-        pin = []
+        # (one block per frame, its images side by side as depth | ht | lt | rgb: the order of the engine's
+        # staging slot, so a frame goes up as ONE copy -- include/ratsdf.h, ratsdf_integrate_batch)
+        pin, blocks = [], []
+        npx = frames[0]["depth"].size
         for f in frames:
+            blk = hp.host_alloc((npx * 15,), np.uint8)
+            blocks.append(blk)
             g = dict(f)
+            g["depth"] = blk[:npx * 4].view(np.float32).reshape(f["depth"].shape)
+            g["ht"] = blk[npx * 4:npx * 8].view(np.float32).reshape(f["ht"].shape)
+            g["lt"] = blk[npx * 8:npx * 12].view(np.float32).reshape(f["lt"].shape)
+            g["rgb"] = blk[npx * 12:].reshape(f["rgb"].shape)
             for k in ("rgb", "depth", "ht", "lt"):
-                g[k] = hp.host_alloc(f[k].shape, f[k].dtype)
                 g[k][...] = f[k]
             pin.append(g)
         C = 32
@@ -625,11 +633,11 @@ def main():
         pinned_path = dict(frames_per_s=round(npin / tp, 1), frames=npin,
                            h2d_gbps=round(npin * bytes_per_frame / tp / 1e9, 1), link_gbps_spec=63.0,
                            note=f"ratsdf_integrate_batch(pinned=1), {len(chunks[0])} frames per call from "
-                                "ratsdf_host_alloc buffers: uploads on the engine's copy stream up to 7 "
-                                "frames ahead of the integration, one sync per call")
-        for g in pin:
-            for k in ("rgb", "depth", "ht", "lt"):
-                hp.host_free(g[k])
+                                "ratsdf_host_alloc blocks (one per frame, depth | ht | lt | rgb: one copy per "
+                                "frame): uploads on the engine's two copy streams up to 7 frames ahead of the "
+                                "integration, one sync per call")
+        for blk in blocks:
+            hp.host_free(blk)
         hp.close()
 
     # ---- S streams on this GPU through one launch triple per frame step ------------------------

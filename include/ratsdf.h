@@ -159,7 +159,9 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
  * host pointers (ht / lt may be NULL = all-ones images); uploads are enqueued ahead of the frames
  * that use them, frame i+1's map-independent part runs while frame i is integrated, and the call
  * blocks until all n frames are integrated (like n calls of ratsdf_integrate).  `pinned` != 0 says
- * that every image buffer comes from ratsdf_host_alloc (uploaded without a staging copy). */
+ * that every image buffer comes from ratsdf_host_alloc (uploaded without a staging copy); a frame
+ * whose four images lie side by side in one such block in the order depth | ht | lt | rgb goes up as
+ * one copy instead of four (~10 us of copy-engine overhead each). */
 int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
                            const float* const* depth, const float* const* ht,
                            const float* const* lt, int height, int width, float max_depth,
