@@ -434,6 +434,9 @@ __device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint
   // The frame's critical path runs in these four waves, each sharing its SIMD with seven waves of the voxel
   // update: ask the instruction arbiter for the highest wave priority.
   __builtin_amdgcn_s_setprio(3);
+#ifdef RATSDF_STAMPS
+  if (threadIdx.x == 0) E->ctl->stamps[par * 3u] = (unsigned long long)wall_clock64();
+#endif
   const uint32_t how = serial_role256(E, par, nwords, lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -443,6 +446,9 @@ __device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (!withhold) st_agent(&E->ctl->fr[par].serial_done, how);
+#ifdef RATSDF_STAMPS
+    E->ctl->stamps[par * 3u + 1u] = (unsigned long long)wall_clock64();  // (timeline: ratsdf_debug_wave_stamps)
+#endif
   }
 }
 

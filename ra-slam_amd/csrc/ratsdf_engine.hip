@@ -1162,6 +1162,23 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
           ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt);
   fprintf(stderr, "[wave stamps] start spread: p50 %llu p99 %llu max %llu ; end: p1 %llu p50 %llu (relative to first start)\n",
           starts[cnt / 2] - t0, starts[cnt * 99 / 100] - t0, starts[cnt - 1] - t0, ends[cnt / 100] - t0, ends[cnt / 2] - t0);
+  {  // the whole launch: when the serial role published, when the waves' LAST passes ended
+    unsigned long long st[6], last = 0;
+    std::vector<unsigned long long> done;
+    for (size_t w = 0; w < 16384; ++w)
+      if (h[w * 8 + 7]) done.push_back(h[w * 8 + 7]);
+    HIPCHK(hipMemcpyAsync(st, e->ctl->stamps, sizeof(st), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!done.empty()) {
+      std::sort(done.begin(), done.end());
+      last = done.back();
+      for (int par = 0; par < 2; ++par)
+        if (st[par * 3 + 1] > t0 && st[par * 3 + 1] < last)
+          fprintf(stderr, "[wave stamps] serial role: started %lld, published at %lld; waves' last passes end: p50 %llu p99 %llu max %llu (10 ns ticks after the first update wave started)\n",
+                  (long long)(st[par * 3] - t0), (long long)(st[par * 3 + 1] - t0), done[done.size() / 2] - t0,
+                  done[done.size() * 99 / 100] - t0, last - t0);
+    }
+  }
   return RATSDF_OK;
 }
 
