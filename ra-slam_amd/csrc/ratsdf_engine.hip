@@ -1108,7 +1108,7 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
   if (!guard.ok()) return RATSDF_ERR_DEVICE;
   static unsigned long long* buf = nullptr;
   const size_t n = 16384 * 8;
-  if (enable) {
+  if (enable > 0) {
     if (!buf) HIPCHK(hipMalloc(&buf, n * 8));
     HIPCHK(hipMemsetAsync(buf, 0, n * 8, e->stream));
     HIPCHK(hipMemcpyAsync(&e->ctl->debug_buf, &buf, sizeof(buf), hipMemcpyHostToDevice, e->stream));
@@ -1118,6 +1118,14 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
   std::vector<unsigned long long> h(n);
   HIPCHK(hipMemcpyAsync(h.data(), buf, n * 8, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  // k_integrate keeps one half of the buffer per frame parity (the last two frames of a batch stay apart):
+  // enable = -1 / -2 reports the half of parity 0 / 1 alone
+  if (enable < 0) {
+    const size_t keep = (size_t)(-enable - 1);
+    for (size_t w = 0; w < 16384; ++w)
+      if ((w >> 13) != keep)
+        for (int k = 0; k < 8; ++k) h[w * 8 + k] = 0;
+  }
   unsigned long long t0 = ~0ull, t1 = 0;
   double ph[4] = {0, 0, 0, 0};
   size_t cnt = 0;
@@ -1173,7 +1181,7 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
       std::sort(done.begin(), done.end());
       last = done.back();
       for (int par = 0; par < 2; ++par)
-        if (st[par * 3 + 1] > t0 && st[par * 3 + 1] < last)
+        if ((enable == 0 || par == -enable - 1) && st[par * 3 + 1] > t0 && st[par * 3 + 1] < last)
           fprintf(stderr, "[wave stamps] serial role: started %lld, published at %lld; waves' last passes end: p50 %llu p99 %llu max %llu (10 ns ticks after the first update wave started)\n",
                   (long long)(st[par * 3] - t0), (long long)(st[par * 3 + 1] - t0), done[done.size() / 2] - t0,
                   done[done.size() * 99 / 100] - t0, last - t0);
