@@ -346,9 +346,10 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
     return 2u;
   }
 
-  // second dependent round: the claim of every request's bucket.  Four requests per thread are in
-  // flight at once (the first two rode in the first round): a frame with n requests costs
-  // ceil(n / 1024) times two dependent round trips, ~35 of them for a whole new view of 30 k requests.
+  // second dependent round: the claim of every request's bucket (claim_pass).  Four requests per thread are
+  // in flight at once (the heads of the first three rode in the first round): n requests cost this workgroup
+  // ceil(n / 1024) times two dependent round trips -- or an eighth of that from 4 096 requests on, where the
+  // seven workgroups dispatched beside it share the pass (a whole new view files 30 k).
   // (the previous frame's update counters ride in this round: nothing depends on them but a sum)
   uint4 u = make_uint4(0, 0, 0, 0);
   static_assert(UPT == 4, "one uint4 of update counters per thread");
