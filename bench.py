@@ -656,7 +656,8 @@ def main():
         nthr = min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16")))
         secondary = [bench_secondary(ratsdf, torch, dev, dev_index, a.max_depth, nthr, "hd2mm"),
                      bench_secondary(ratsdf, torch, dev, dev_index, a.max_depth, nthr, "bigmap")]
-        flythrough = bench_flythrough(ratsdf, torch, dev, dev_index, a.cam, vs, a.max_depth, a.flythrough_frames, nthr)
+        flythrough = bench_flythrough(ratsdf, torch, dev, dev_index, a.cam, vs, a.max_depth, a.flythrough_frames, nthr,
+                                      n_par=a.flythrough_frames)  # checked against the oracle over the whole pass
         system_path = bench_tsdf_system(frames, a.max_depth, vs)
 
     nframes = a.steps * len(frames)
