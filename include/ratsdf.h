@@ -199,6 +199,14 @@ int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out);
  * deleted blocks}; used to turn a timed run into algorithmic bytes (15 W H + 12 V + 24 U per frame). */
 int ratsdf_totals(ratsdf_engine* e, int64_t* out5, int reset);
 
+/* Which form of a frame's serial allocation-order pass (TSDFGrid::Allocate's AquireBlock order,
+ * voxel_tsdf.cu:454-463 + voxel_hash.cu:46-108) the frames took since creation / the last reset -- a
+ * property of the MI355X engine's launch layout, no reference counterpart (the oracle reports
+ * RATSDF_ERR_NOT_IMPLEMENTED): out4 = {frames whose pass ran at the tail of the frame's first launch,
+ * frames whose pass ran beside the voxel update (ordinary path), ... with the chained-bucket resolver,
+ * ... through the general path}. */
+int ratsdf_pipeline_counters(ratsdf_engine* e, int64_t* out4, int reset);
+
 /* ---- query side ---------------------------------------------------------------------------- */
 /* TSDFGrid::GatherVoxels(BoundingCube<float>) == TSDFSystem::Query, voxel_tsdf.cu:532-559,
  * modules/tsdf_module.cc:39-43.  Output: every voxel of every allocated block that lies wholly

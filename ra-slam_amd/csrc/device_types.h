@@ -73,7 +73,10 @@ struct FrameCtl {
   uint32_t n_winlist;      // > 0: the winners' raster ranks are listed in win_ranks[0, n_winlist) and
                            // k_integrate derives each winner's order from the list (few winners);
                            // 0: req_k holds the order (many winners, rank bitmap path)
-  uint32_t pad[26];
+  // new blocks of the frame per XCD list, filed by front_tail_role (kernels_frame.h) behind the visible
+  // lists; written once, before k_integrate starts
+  uint32_t n_fresh[8];
+  uint32_t pad[18];
   // visible blocks per XCD list (image-tile buckets): list l counts in n_list[l * kListStride], one
   // 128-byte line per counter (they take ~2000 atomics per frame; sharing a line serialises them)
   uint32_t n_list[8 * 32];
@@ -94,9 +97,29 @@ struct FrameCtl {
   uint32_t n_slow_del;     // head / chain deletes waiting for carve_resolve_slow
   uint32_t slow_resolved;  // carve_resolve_slow has run for this frame
   uint32_t pad3[29];
+  // The frame's serial role at the TAIL of k_front (kernels_frame.h: front_tail_role): every workgroup of the
+  // launch's directory roles (visible list, candidate consumers, pool releases) reports here when its stores
+  // have drained; the one that arrives last decides the winners, commits the new blocks and files them in
+  // the work lists -- the launch boundary is the hand-off, nothing in k_integrate waits or polls.
+  // Two levels (a single address takes ~90 atomics per microsecond and hundreds of workgroups finish
+  // together): workgroup b bumps arrive[(b % kArriveSubs) * kListStride], the last one of a sub-counter
+  // bumps arrive_top.  One 128-byte line per counter.
+  uint32_t arrive[32 * 32];
+  uint32_t arrive_top;
+  uint32_t front_done;     // 1: the tail role did the frame's allocation pass (k_integrate has no commits to
+                           // make and its serial group nothing to do); 0: the role runs inside k_integrate
+  uint32_t pad4[30];
 };
 constexpr int kListStride = 32;
-static_assert(sizeof(FrameCtl) == 128 + 1024 + 2 * 128, "frame counters: one line + one line per list counter + flag line");
+constexpr uint32_t kArriveSubs = 32;
+static_assert(sizeof(FrameCtl) == 128 + 1024 + 2 * 128 + 32 * 128 + 128,
+              "frame counters: one line + one line per list counter + flag lines + arrival counters");
+// New blocks a frame's tail role can file (kernels_frame.h: kTailWinMax), per work list.  Segment l of the
+// frame's work lists is seg_cap items long (EngineDev::seg_cap = the segment stride): kFreshCap items for the
+// list's new blocks IN FRONT of the segment's start (items -kFreshCap .. -1 of &vis[l * seg_cap]; EngineDev::vis
+// points kFreshCap items into its allocation), then up to seg_cap - kFreshCap visible blocks.  k_integrate
+// reaches both through one base address (its scalar registers are all in use).
+constexpr uint32_t kFreshCap = 768;
 
 // Device-resident control block.
 struct Ctl {
@@ -107,6 +130,8 @@ struct Ctl {
   uint32_t n_sel;         // selected blocks of a query / export
   uint32_t pad0;
   unsigned long long totals[5];  // frames, sum V, sum U, sum allocated, sum deleted
+  // frames by where their serial role ran: tail of k_front | in k_integrate: ordinary, resolver, general path
+  unsigned long long paths[4];
   uint32_t pad1[4];
   unsigned long long stamps[32];  // diagnostic build only
   unsigned long long* debug_buf;  // diagnostic build only: per-wave stamps of k_integrate

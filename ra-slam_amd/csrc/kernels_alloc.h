@@ -50,8 +50,21 @@ __device__ inline void zero_frame_ctl(FrameCtl* F) {
   F->n_delcand = 0;
   F->n_slow_del = 0;
   F->slow_resolved = 0;
+  F->arrive_top = 0;
+  F->front_done = 0;
 #pragma unroll
   for (int l = 0; l < kNumLists; ++l) F->n_list[l * kListStride] = 0;
+#pragma unroll
+  for (uint32_t l = 0; l < kArriveSubs; ++l) F->arrive[l * kListStride] = 0;
+#pragma unroll
+  for (int l = 0; l < kNumLists; ++l) F->n_fresh[l] = 0;
+}
+// visible blocks of a frame for the statistics: the blocks listed by the visible role + the frame's new blocks
+__device__ inline uint32_t frame_visible_blocks(const FrameCtl* F) {
+  uint32_t nv = F->n_win;
+#pragma unroll
+  for (int l = 0; l < kNumLists; ++l) nv += F->n_list[l * kListStride];
+  return nv;
 }
 __device__ inline uint32_t ld_agent_u32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -169,6 +182,15 @@ struct ReqBuf {
   Request item[kReqBufCap];
   uint32_t n, base;
 };
+// A request goes to the frame's list with write-through stores: the workgroup of the same launch that runs
+// the frame's serial role (front_tail_role, kernels_frame.h) reads the list past the caches.
+__device__ inline void st_agent_request(Request* p, const Request& r) {
+  unsigned long long w[2];
+  __builtin_memcpy(w, &r, sizeof(r));
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  __hip_atomic_store(q, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // alloc_request_absent for a whole wave (every lane calls it; `want` selects the lanes that have an
 // absent, visible block).
@@ -206,7 +228,7 @@ __device__ inline void alloc_request_absent_wave(bool want, const Table& t, int 
       if (in_lds) {
         B.item[slot] = r;
       } else if (slot < req_cap) {
-        req[slot] = r;
+        st_agent_request(req + slot, r);
       } else {
         set_error(ctl, RATSDF_ERR_CAPACITY);
       }
@@ -232,7 +254,7 @@ __device__ inline void req_buf_flush(ReqBuf& B, Request* req, uint32_t req_cap, 
   const uint32_t base = B.base;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     if (base + i < req_cap) {
-      req[base + i] = B.item[i];
+      st_agent_request(req + base + i, B.item[i]);
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
     }
@@ -621,10 +643,17 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
   };
   // outcome of a request whose plan held: [1:0] 1 = fill the home slot, 2 = link the tail and fill `next`;
   // [2] clear the claim of the first bucket locked (home / tail), [3] of `next`'s; [63:32] request slot
+  // (a claim reset is read by the OTHER workgroups of the serial group -- claim_pass, kernels_integrate.h, one
+  // per XCD -- in a frame that has both chained requests and thousands of ordinary ones: write-through like
+  // every other store of the pass, or a helper would read the old claim from memory and list a leader whose
+  // claim this pass has defeated)
+  auto clear_claim = [&](uint32_t bucket) {
+    __hip_atomic_store(&tab.claim[bucket], kInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   auto apply = [&](const SlowPlan& pl, unsigned long long act) {
     const uint32_t kind = (uint32_t)act & 3u, slot = (uint32_t)(act >> 32);
-    if (act & 4u) tab.claim[(pl.flags & kPlanHome) ? pl.bucket : pl.last >> 1] = kInf;
-    if (act & 8u) tab.claim[pl.next >> 1] = kInf;
+    if (act & 4u) clear_claim((pl.flags & kPlanHome) ? pl.bucket : pl.last >> 1);
+    if (act & 8u) clear_claim(pl.next >> 1);
     if (kind == 1u) {
       write_placed((pl.bucket << 1) + ((pl.flags & kPlanHomeSlot1) ? 1u : 0u), pl.k0, pl.k1, pl.rank, slot);
     } else if (kind == 2u) {
@@ -700,7 +729,7 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
     if (a.idx < 0 || b.idx < 0) {                                        // :67-78
       if (try_lock(bucket, c_home, time, &clear)) {
         *took_a = bucket;
-        if (clear) tab.claim[bucket] = kInf;
+        if (clear) clear_claim(bucket);
         write_placed(e0 + (a.idx < 0 ? 0u : 1u), k0, k1, time, n_req++);
       }
       return;
@@ -724,10 +753,10 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
     // second's: only when both buckets are the same one, and then the second try fails on the lock set.
     if (!try_lock(bucket_last, c_last, time, &clear)) return;
     *took_a = bucket_last;
-    if (clear) tab.claim[bucket_last] = kInf;
+    if (clear) clear_claim(bucket_last);
     if (!try_lock(next >> 1, c_next, time, &clear)) return;
     *took_b = next >> 1;
-    if (clear) tab.claim[next >> 1] = kInf;
+    if (clear) clear_claim(next >> 1);
     write_link(last, last_w1, next);
     write_placed(next, k0, k1, time, n_req++);
   };

@@ -307,7 +307,8 @@ __device__ inline void carve_release_role(const Pool& pool, const CarveBufs& cb,
       k += (x.x < mine) + (x.y < mine) + (x.z < mine) + (x.w < mine);
     }
     k = dpp_sum16(k);  // over the 16 lanes that share the delete
-    if (sub == 0 && item < n) pool.heap[(uint32_t)nf + k] = del_pool[item];
+    // (write-through: the frame's serial role at the tail of the same launch pops these, front_tail_role)
+    if (sub == 0 && item < n) st_agent(reinterpret_cast<uint32_t*>(&pool.heap[(uint32_t)nf + k]), (uint32_t)del_pool[item]);
   }
 }
 
@@ -405,9 +406,7 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
     // (the frame's counters are read here, not at the top: ten values held across the bitmap passes
     // pushed the kernels that inline this function into scratch memory)
     const uint32_t n_win = F->n_win, n_slow_req = F->n_slow;
-    uint32_t nv = n_win;
-#pragma unroll
-    for (int l = 0; l < kNumLists; ++l) nv += F->n_list[l * kListStride];
+    const uint32_t nv = frame_visible_blocks(F);
     if (stats) {
       stats->visible_blocks = (int32_t)nv;
       stats->updated_voxels = (int32_t)upd;

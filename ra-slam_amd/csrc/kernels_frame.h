@@ -60,18 +60,231 @@ __device__ inline CandJob make_cand_job(EnginePtr E, JobPtr J, const AheadGeom& 
   return j;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The frame's serial role at the TAIL of k_front (ordinary frames).
+//
+// Until round 4 the role always ran as workgroup 0 of k_integrate, beside the voxel update: the blocks that
+// existed before the frame were through ~7 us into that launch, the role published at 7.3 us, and the
+// frame's NEW blocks (a tenth of its blocks) finished at 14 us behind five dependent round trips (request ->
+// winners counted -> pool index -> voxel words / texels -> stores).  Everything the role needs exists when
+// the last directory workgroup of k_front (visible list, candidate consumers, pool releases) has finished,
+// so that workgroup -- whichever it is: they count themselves in, FrameCtl::arrive -- now runs it: winners
+// (claim == own rank), their order (smaller ranks counted in LDS), pool indices, directory entries,
+// occupancy bits, claim resets, and one work-list item per new block (per-XCD lists of their own behind the
+// visible ones: the update of such a block starts from AquireBlock's initial values).  The launch boundary is
+// the hand-off: k_integrate sees work lists, nothing in it waits or polls (FrameCtl::front_done tells its
+// serial group to stay out).
+// Also here, as in serial_role256: the previous frame's statistics and the reset of its counters.
+// Frames the tail does NOT take (it returns before it has changed anything, front_done stays 0 and the role
+// runs inside k_integrate as before): chained-bucket requests (the resolver), more than kTailReqMax requests
+// or kTailWinMax winners (a new view), a previous frame with more deletes than the release role takes.
+// What other workgroups of THIS launch wrote is read past the caches (agent-scope loads; the writers use
+// write-through stores and drain them before they report); what the tail writes is read by later launches.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kFrontLdsWords = 2 * kSmallCarve + 16;  // LDS of a k_front workgroup, whatever its role
+constexpr uint32_t kTailPerThread = 8;
+constexpr uint32_t kTailReqMax = kTailPerThread * 256;  // requests of a frame (all in registers at once)
+constexpr uint32_t kTailWinMax = kFreshCap;             // winners (ordered in LDS)
+// LDS words: [0, 32) counters | ranks (+16 of padding) | x,y | z | entry | pool indices
+constexpr uint32_t kTailLdsWords = 32 + (kTailWinMax + 16) + 4 * kTailWinMax;
+
+// Every wave of a directory workgroup of k_front calls this when its role is done; true (uniform) in the
+// workgroup that reports last.  `wg`: its index among the n_wg directory workgroups.
+__device__ inline bool front_arrive(FrameCtl* F, uint32_t wg, uint32_t n_wg) {
+  __shared__ uint32_t arrived_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU ...
+  __syncthreads();                                  // ... and every other wave's
+  if (threadIdx.x == 0) {
+    const uint32_t sub = wg % kArriveSubs;
+    const uint32_t members = (n_wg - sub + kArriveSubs - 1) / kArriveSubs;  // workgroups b < n_wg, b % subs == sub
+    uint32_t last = 0;
+    if (__hip_atomic_fetch_add(&F->arrive[sub * kListStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+        members - 1u) {
+      const uint32_t tops = n_wg < kArriveSubs ? n_wg : kArriveSubs;
+      last = __hip_atomic_fetch_add(&F->arrive_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tops - 1u;
+    }
+    arrived_last = last;
+  }
+  __syncthreads();
+  return arrived_last != 0u;
+}
+
+__device__ __forceinline__ void front_tail_role(const Table& tab, const FrameParams& P, const CandSet& cand,
+                                                const Request* req, uint32_t req_cap, VisItem* vis,
+                                                uint32_t seg_cap, const Pool& pool, const CarveBufs& cb, Ctl* ctl,
+                                                uint32_t par, ratsdf_frame_stats* stats, uint32_t* lds) {
+  static_assert(kTailLdsWords <= kFrontLdsWords, "the tail role works in the launch's role buffer");
+  constexpr uint32_t NT = 256;
+  constexpr int kU = (int)kTailPerThread;
+  const uint32_t tid = threadIdx.x;
+  FrameCtl* F = &ctl->fr[par];
+  FrameCtl* Fp = &ctl->fr[par ^ 1u];
+  uint32_t* win_rank = lds + 32;
+  uint32_t* win_w0 = win_rank + kTailWinMax + 16;
+  uint32_t* win_z = win_w0 + kTailWinMax;
+  uint32_t* win_e = win_z + kTailWinMax;
+  uint32_t* hc = win_e + kTailWinMax;
+  // lds: [0] head / chain deletes of the previous frame that happened, [1] winners, [2] voxels updated,
+  //      [4 + l] new blocks filed in list l
+
+  // ---- one round of loads ----
+  const int32_t nf0 = ctl->num_free;                 // (previous launches: plain)
+  const uint32_t pend = Fp->pending;
+  uint32_t nd = Fp->n_delcand, ns = Fp->n_slow_del;
+  const uint32_t p_win = Fp->n_win, p_slow = Fp->n_slow;
+  const uint32_t nv = frame_visible_blocks(Fp);
+  const uint32_t n_slow = ld_agent(&F->n_slow);      // (this launch's consumers: past the caches)
+  uint32_t n = ld_agent(&F->n_req);
+  Request r[kU];  // the frame's requests: the slots exist whatever the count is
+#pragma unroll
+  for (int k = 0; k < kU; ++k) {
+    const uint32_t i = tid + (uint32_t)k * NT;
+    r[k] = ld_agent_request(req + (i < req_cap ? i : 0u));
+  }
+  uint4 u = make_uint4(0, 0, 0, 0);
+  static_assert(kUpdCounters / NT == 4, "one uint4 of update counters per thread");
+  if (pend) u = reinterpret_cast<const uint4*>(cb.upd_wg)[tid];
+  if (tid < 32) lds[tid] = 0;
+  for (uint32_t i = tid; i < kTailWinMax + 16; i += NT) win_rank[i] = kInf;  // (padding of the 16-byte reads)
+  if (nd > cb.del_cap) nd = cb.del_cap;
+  if (ns > cb.slow_cap) ns = cb.slow_cap;
+  if (n > req_cap) n = req_cap;
+  // uniform: not a frame for the tail -- nothing has been changed
+  if (n_slow != 0 || n > kTailReqMax || (pend && nd + ns > kSmallCarve)) return;
+  lds_barrier();
+  if (pend && ns) {  // rare: states written by carve_resolve_slow in workgroup 0 of this launch
+    for (uint32_t j = tid; j < ns; j += NT)
+      if ((ld_agent(reinterpret_cast<const uint32_t*>(&cb.slow[j]) + 1) >> 16) == 2u) atomicAdd(&lds[0], 1u);
+  }
+  // ---- second dependent round: the claim of every request's bucket ----
+  uint32_t c[kU];
+#pragma unroll
+  for (int k = 0; k < kU; ++k) {
+    const uint32_t i = tid + (uint32_t)k * NT;
+    c[k] = kInf;
+    if (i < n) c[k] = ld_agent(&tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)]);
+  }
+  lds_barrier();
+  const uint32_t n_del = pend ? nd + lds[0] : 0u;
+  const int32_t nf = nf0 + (int32_t)n_del;
+  // ... and, riding in the same round, the pool indices the winners will pop: heap[nf - 1 - k] (AquireBlock,
+  // voxel_mem.cu:37-41; the release role of this launch may have pushed them moments ago: past the caches)
+  int32_t hv[kTailWinMax / NT];
+#pragma unroll
+  for (uint32_t q = 0; q < kTailWinMax / NT; ++q) {
+    const uint32_t j = tid + q * NT;
+    hv[q] = -1;
+    if ((int32_t)j < nf) hv[q] = (int32_t)ld_agent(reinterpret_cast<const uint32_t*>(&pool.heap[nf - 1 - (int32_t)j]));
+  }
+  // winners: first requester of a bucket in raster order (claim == own rank)
+#pragma unroll
+  for (int k = 0; k < kU; ++k) {
+    const uint32_t i = tid + (uint32_t)k * NT;
+    if (i < n && c[k] == r[k].rank) {
+      const uint32_t slot = atomicAdd(&lds[1], 1u);
+      if (slot < kTailWinMax) {
+        win_rank[slot] = r[k].rank;
+        win_w0[slot] = key0(r[k].x, r[k].y);
+        win_z[slot] = key1(r[k].z);
+        win_e[slot] = r[k].entry;
+      }
+    }
+  }
+#pragma unroll
+  for (uint32_t q = 0; q < kTailWinMax / NT; ++q) hc[tid + q * NT] = (uint32_t)hv[q];
+  lds_barrier();
+  const uint32_t total = lds[1];
+  if (total > kTailWinMax) return;  // uniform: a new view -- still nothing changed
+  const uint32_t take = (int64_t)total > (int64_t)nf ? (uint32_t)(nf > 0 ? nf : 0) : total;  // voxel_mem.cu:39
+
+  // ---- ResetLocks: every request's bucket (voxel_hash.cu:35-38) ----
+#pragma unroll
+  for (int k = 0; k < kU; ++k) {
+    const uint32_t i = tid + (uint32_t)k * NT;
+    if (i < n) tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)] = kInf;
+  }
+  // ---- commit, one winner per thread and pass: order = winners of smaller rank (every lane reads the same
+  // 16 bytes of the list at a time: LDS broadcasts), pool index, directory entry, occupancy bit, work-list item
+  const uint4* wl = reinterpret_cast<const uint4*>(win_rank);
+  const uint32_t nchunks = (total + 3u) >> 2;
+  for (uint32_t base = 0; base < total; base += NT) {  // uniform
+    const uint32_t w = base + tid;
+    const uint32_t mine = w < total ? win_rank[w] : 0u;
+    uint32_t k = 0;
+#pragma unroll 4
+    for (uint32_t q = 0; q < nchunks; ++q) {
+      const uint4 x = wl[q];
+      k += (x.x < mine) + (x.y < mine) + (x.z < mine) + (x.w < mine);
+    }
+    if (w < total && k < take) {
+      const uint32_t w0 = win_w0[w], w1 = win_z[w], e = win_e[w];
+      const int32_t idx = (int32_t)hc[k];
+      uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + e);
+      pe[0] = w0;                                                       // voxel_hash.cu:72-74
+      pe[1] = w1;                                                       // offset 0
+      pe[2] = (uint32_t)idx;
+      atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
+      const int bx = (int16_t)(w0 & 0xFFFFu), by = (int16_t)(w0 >> 16), bz = (int16_t)(w1 & 0xFFFFu);
+      const uint32_t l = (uint32_t)block_list_of(bx, by, bz, P);
+      const uint32_t pos = atomicAdd(&lds[4 + l], 1u);  // < kFreshCap: total <= kTailWinMax
+      reinterpret_cast<uint4*>(vis)[(ptrdiff_t)((size_t)l * seg_cap + pos) - (ptrdiff_t)kFreshCap] =
+          make_uint4(w0, w1, (uint32_t)idx, e);
+    }
+  }
+  // ---- previous frame: voxels-updated sum ----
+  if (pend) {
+    uint32_t up = u.x + u.y + u.z + u.w;
+    if (up) reinterpret_cast<uint4*>(cb.upd_wg)[tid] = make_uint4(0, 0, 0, 0);
+    up = wave_sum(up);
+    if ((tid & 63) == 0 && up) atomicAdd(&lds[2], up);
+  }
+  // the frame's candidate lists have been consumed (every consumer has reported): empty them for the frame
+  // after next
+  if (tid < (uint32_t)kCandSegs) cand.count[tid * kCandCountStride] = 0;
+  lds_barrier();
+  if (tid < (uint32_t)kNumLists) F->n_fresh[tid] = lds[4 + tid];
+  if (tid == 0) {
+    const uint32_t upd = lds[2];
+    if (pend) {
+      if (stats) {
+        stats->visible_blocks = (int32_t)nv;
+        stats->updated_voxels = (int32_t)upd;
+        stats->allocated_blocks = (int32_t)p_win;
+        stats->deleted_blocks = (int32_t)n_del;
+        stats->active_blocks = tab.num_block - nf;
+        stats->slow_requests = (int32_t)p_slow;
+        atomicAdd(&ctl->totals[0], 1ull);
+        atomicAdd(&ctl->totals[1], (unsigned long long)nv);
+        atomicAdd(&ctl->totals[2], (unsigned long long)upd);
+        atomicAdd(&ctl->totals[3], (unsigned long long)p_win);
+        atomicAdd(&ctl->totals[4], (unsigned long long)n_del);
+      }
+      zero_frame_ctl(Fp);  // counters ready for the frame after next (every reader of this launch has reported)
+    }
+    if ((int64_t)total > (int64_t)nf) set_error(ctl, RATSDF_ERR_POOL_EXHAUSTED);
+    F->alloc_base = (uint32_t)nf;
+    F->n_win = take;
+    F->n_winlist = total;
+    F->pending = 1;  // this frame now owes a carve_finalize
+    F->front_done = 1;
+    ctl->num_free = nf - (int32_t)take;
+    atomicAdd(&ctl->paths[0], 1ull);
+  }
+}
+
 // workgroups [0, n_vis_wg)               visible list of the blocks that exist before this frame
 //                                        (longest dependency chain, so it is dispatched first)
 // workgroups [.., +kCandSegs * parts)    allocation requests from the frame's candidate lists
 // workgroups [.., +kReleaseWGs)          pool releases of the previous frame (carve_release_role)
 // workgroups beyond                      look-ahead candidate pass of the next frame (`ahead()`)
-constexpr uint32_t kFrontLdsWords = 2 * kSmallCarve + 16;
+// The directory workgroup that finishes last runs the frame's serial role (front_tail_role) when `tail`.
 template <typename Ahead>
 __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32_t n_vis_wg,
                                   const CandSet& cand, uint32_t cand_parts, Request* req,
                                   uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap, VisItem* vis,
                                   uint32_t seg_cap, const Pool& pool, const CarveBufs& cb, Ctl* ctl,
-                                  uint32_t par, Ahead ahead, uint32_t* role_lds) {
+                                  uint32_t par, ratsdf_frame_stats* stats, uint32_t tail, Ahead ahead,
+                                  uint32_t* role_lds) {
   static_assert(sizeof(CandLds) <= kFrontLdsWords * 4 && kVisListCap <= 2 * kSmallCarve &&
                     sizeof(ReqBuf) <= kFrontLdsWords * 4,
                 "role LDS");
@@ -86,36 +299,44 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
   FrameCtl* Fp = &ctl->fr[par ^ 1u];
   // (diagnostic build, RATSDF_DEBUG=20: workgroup 0 never publishes -- the waiters' bounded wait is what
   // tests/test_gpu_errors.py::test_in_launch_waits_are_bounded exercises)
-  auto gate = [&]() { return carve_resolve_gate(tab, cb, ctl, Fp, RATSDF_DBG(P, 20)); };  // uniform per workgroup
+  bool expired = false;  // uniform per workgroup
+  auto gate = [&]() {
+    const GateResult g = carve_resolve_gate(tab, cb, ctl, Fp, RATSDF_DBG(P, 20));
+    expired = expired || g == kGateExpired;
+    return g;
+  };
   if (blockIdx.x >= n_vis_wg + n_cons_wg) {
-    if (RATSDF_DBG(P, 12)) return;  // diagnostic ablations 3 / 11 / 12: skip one role
-    if (gate() == kGateExpired) return;  // uniform
-    carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - n_cons_wg, role_lds);
+    if (!RATSDF_DBG(P, 12) && gate() != kGateExpired)  // diagnostic ablations 3 / 11 / 12: skip one role
+      carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - n_cons_wg, role_lds);
   } else if (blockIdx.x >= n_vis_wg) {
-    if (RATSDF_DBG(P, 11)) return;
-    const uint32_t c = blockIdx.x - n_vis_wg;
-    cand_consume_role(tab, P, cand, c % kCandSegs, c / kCandSegs, cand_parts, req, req_cap, slow,
-                      slow_cap, ctl, F, gate, *reinterpret_cast<ReqBuf*>(role_lds));
+    if (!RATSDF_DBG(P, 11)) {
+      const uint32_t c = blockIdx.x - n_vis_wg;
+      cand_consume_role(tab, P, cand, c % kCandSegs, c / kCandSegs, cand_parts, req, req_cap, slow,
+                        slow_cap, ctl, F, gate, *reinterpret_cast<ReqBuf*>(role_lds));
+    }
   } else {
-    if (RATSDF_DBG(P, 3)) return;
-    visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F, gate, role_lds);
+    if (!RATSDF_DBG(P, 3)) visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F, gate, role_lds);
   }
+  // (a workgroup whose gate expired does not report: the directory may be half-edited, the tail must not
+  // run on it -- the sticky error says the frame is incomplete)
+  if (tail && !expired && front_arrive(F, blockIdx.x, n_dir_wg))
+    front_tail_role(tab, P, cand, req, req_cap, vis, seg_cap, pool, cb, ctl, par, stats, role_lds);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(
     Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, uint32_t cand_parts, Request* req,
     uint32_t req_cap,
     SlowRequest* slow, uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Pool pool, CarveBufs cb,
-    Ctl* ctl, uint32_t par, CandJob ahead) {
+    Ctl* ctl, uint32_t par, ratsdf_frame_stats* stats, uint32_t tail, CandJob ahead) {
   // one LDS buffer for whichever role the workgroup plays
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
   front_body(tab, P, n_vis_wg, cand, cand_parts, req, req_cap, slow, slow_cap, vis, seg_cap, pool, cb,
-             ctl, par, [&]() { return ahead; }, role_lds);
+             ctl, par, stats, tail, [&]() { return ahead; }, role_lds);
 }
 
 // the same launch for several engines: engine blockIdx.y, operands from its record and its job
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front_g(
-    EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_vis_wg, uint32_t cand_parts, AheadGeom ag) {
+    EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_vis_wg, uint32_t cand_parts, uint32_t tail, AheadGeom ag) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
   EnginePtr E = engs + blockIdx.y;
   JobPtr J = cur + blockIdx.y;
@@ -123,8 +344,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fr
   const RankBufs rb = ld_const(&E->rb);
   front_body(ld_const(&E->tab), ld_const(&J->P), n_vis_wg, ld_const(&E->cand[par]), cand_parts, rb.req,
              rb.req_cap, E->slow, E->slow_cap, E->vis, E->seg_cap, ld_const(&E->pool),
-             ld_const(&E->cb[par ^ 1u]), E->ctl, par, [&]() { return make_cand_job(E, nxt + blockIdx.y, ag); },
-             role_lds);
+             ld_const(&E->cb[par ^ 1u]), E->ctl, par, E->stats, tail,
+             [&]() { return make_cand_job(E, nxt + blockIdx.y, ag); }, role_lds);
 }
 
 // The serial bookkeeping of a frame in its steady-state shape (few deletes, few requests, no chained
@@ -157,9 +378,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
   const uint32_t pend = Fp->pending;
   uint32_t nd = Fp->n_delcand, ns = Fp->n_slow_del;
   const uint32_t p_win = Fp->n_win, p_slow = Fp->n_slow;
-  uint32_t nv = p_win;
-#pragma unroll
-  for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l * kListStride];
+  const uint32_t nv = frame_visible_blocks(Fp);
   const uint32_t n_slow = F->n_slow;
   uint32_t n = F->n_req;
   const uint32_t u = cb.upd_wg[tid & (kUpdCounters - 1)];  // NT == kUpdCounters

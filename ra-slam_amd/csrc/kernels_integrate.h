@@ -237,9 +237,13 @@ __device__ __forceinline__ void claim_pass(const Table& tab, const RankBufs& rb,
     for (int k = 0; k < kU; ++k) {
       const uint32_t i = base + (uint32_t)k * NT + tid;
       c[k] = kInf;
-      if (i < n)
-        c[k] = tab.claim[block_hash((int16_t)(r[k].w0 & 0xFFFFu), (int16_t)(r[k].w0 >> 16), (int16_t)(r[k].w1 & 0xFFFFu),
-                                    tab.bucket_mask)];
+      if (i < n) {
+        // (shared pass: past this XCD's L2 -- the resolver of the same launch, on workgroup 0's XCD, may have
+        // reset this claim; its resets are write-through stores, drained before help_go went out)
+        const uint32_t* pc = &tab.claim[block_hash((int16_t)(r[k].w0 & 0xFFFFu), (int16_t)(r[k].w0 >> 16),
+                                                   (int16_t)(r[k].w1 & 0xFFFFu), tab.bucket_mask)];
+        c[k] = cursor ? ld_agent(pc) : *pc;
+      }
     }
     // the winners' ranks go to a compact list; the committing waves turn a rank into the winner's
     // position in raster order (= order of the AquireBlock calls) by counting the smaller ones.
@@ -303,9 +307,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
     ns = Fp->n_slow_del;
     p_win = Fp->n_win;
     p_slow = Fp->n_slow;
-    nv = p_win;
-#pragma unroll
-    for (int l = 0; l < kNumLists; ++l) nv += Fp->n_list[l * kListStride];
+    nv = frame_visible_blocks(Fp);
 #pragma unroll
     for (uint32_t k = 0; k < kClaimPre; ++k) {  // the first requests ride in the first round
       const Request* q = rb.req + (tid + k * NT < rb.req_cap ? tid + k * NT : 0);
@@ -341,7 +343,10 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
 
   const bool fast = (!pend || nd + ns <= kSmallCarve) && n <= kFusedRank;
   if (__builtin_expect(!fast, 0)) {  // uniform: the general functions, scratch in device memory
-    if (tid == 0) st_agent(&F->help_go, 2u);  // (the neighbours stay out)
+    if (tid == 0) {
+      st_agent(&F->help_go, 2u);  // (the neighbours stay out)
+      atomicAdd(&ctl->paths[3], 1ull);
+    }
     serial_general(E, par, nwords, nf0, true);
     return 2u;
   }
@@ -419,6 +424,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
     st_agent(&F->n_winlist, total);
     F->pending = 1;  // this frame now owes a carve_finalize
     ctl->num_free = nf - (int32_t)take;
+    atomicAdd(&ctl->paths[n_slow ? 2 : 1], 1ull);
   }
   RATSDF_STAMP(ctl->stamps, 11);
   RATSDF_STAMP(ctl->stamps, 12);
@@ -432,6 +438,8 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
 // waits expire: tests/test_gpu_errors.py::test_in_launch_waits_are_bounded)
 __device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint32_t nwords, uint32_t* lds,
                                                  bool withhold = false) {
+  // (an ordinary frame: the role ran at the tail of k_front, kernels_frame.h: front_tail_role)
+  if (E->ctl->fr[par].front_done) return;  // uniform
   // The frame's critical path runs in these four waves, each sharing its SIMD with seven waves of the voxel
   // update: ask the instruction arbiter for the highest wave priority.
   __builtin_amdgcn_s_setprio(3);
@@ -460,6 +468,7 @@ __device__ __forceinline__ void serial_helper(EnginePtr E, uint32_t par, uint32_
                                               bool withhold = false) {
   Ctl* ctl = E->ctl;
   FrameCtl* F = &ctl->fr[par];
+  if (F->front_done) return;  // uniform: no serial role in this launch (front_tail_role did the frame's)
   if (threadIdx.x == 0) {
     uint32_t v = 0;
     const unsigned long long t0 = (unsigned long long)wall_clock64();

@@ -146,7 +146,7 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
       if (!(t & 0x10000000u)) continue;
       const uint32_t e = t & 0x0FFFFFFFu, l = t >> 29;
       const uint32_t pos = base[l] + atomicAdd(&cnt2[l], 1u);
-      if (pos < seg_cap) {
+      if (pos < seg_cap - kFreshCap) {  // (the next segment's new-block items start there)
         const EntryWords ew = i == tid ? first : load_entry(tab.entries, e);
         uint4 v;
         v.x = ew.w0;

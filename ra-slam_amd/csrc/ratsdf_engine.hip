@@ -108,6 +108,7 @@ struct ratsdf_engine {
   unsigned cand_split = 20;              // percent of the look-ahead pass placed in k_front,
   unsigned cand_split_b = 0;             // in k_alloc_rank; the rest rides in k_integrate
   bool fused_serial = true;              // the frame's serial role rides in k_integrate (no k_alloc_rank)
+  bool front_tail = true;                // ... or, in ordinary frames, at the tail of k_front (front_tail_role)
   int commit_rot_env = -1;               // RATSDF_COMMIT_ROT: first committing workgroup (measurements)
   // With the serial role in the launch: which update workgroups take the frame's commits.  A grid of
   // at most two rounds of resident workgroups (256 CUs x 8): the first ones, which wait for the role
@@ -290,7 +291,7 @@ EngineDev ratsdf_engine::record() const {
   r.serial_scratch = serial_scratch;
   r.slow_cap = kSlowCap;
   r.seg_cap = seg_cap;
-  r.vis = vis;
+  r.vis = vis + kFreshCap;  // (the frame kernels' view: device_types.h, kFreshCap)
   for (int i = 0; i < 2; ++i) {
     r.texA[i] = texA[i];
     r.texB[i] = texB[i];
@@ -566,10 +567,10 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   cand_ready = next != nullptr;
 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
-  hipLaunchKernelGGL(k_front, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
-                     (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis, seg_cap, pool, carve_bufs(par ^ 1u),
-                     ctl, (uint32_t)par, ahead_a);
   const bool fused = fused_serial && vpl != 1;
+  hipLaunchKernelGGL(k_front, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
+                     (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis + kFreshCap, seg_cap, pool, carve_bufs(par ^ 1u),
+                     ctl, (uint32_t)par, d_stats, (uint32_t)(fused && front_tail), ahead_a);
   if (!fused) {
     st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
     if (st != RATSDF_OK) return st;
@@ -602,7 +603,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   ia.segm = pool.segm;
   ia.texA = texA[par];
   ia.texB = texB[par];
-  ia.vis = vis;
+  ia.vis = vis + kFreshCap;
   ia.seg_cap = seg_cap;
   ia.F = &ctl->fr[par];
   ia.upd_wg = upd_wg[par];
@@ -715,6 +716,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   }
   if (const char* v = getenv("RATSDF_COMMIT_ROT")) e->commit_rot_env = atoi(v);
   if (const char* v = getenv("RATSDF_FUSED_SERIAL")) e->fused_serial = atoi(v) != 0;  // 0: k_alloc_rank launch
+  if (const char* v = getenv("RATSDF_FRONT_TAIL")) e->front_tail = atoi(v) != 0;  // 0: the role always in k_integrate
   if (const char* v = getenv("RATSDF_SERIAL_LDS")) {
     const int x = atoi(v);
     if (x >= kSerialLdsBytes && x <= 160 * 1024) e->serial_lds = (unsigned)x;
@@ -769,8 +771,10 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->serial_scratch, (size_t)kSerialLdsBytes));
   CREATE_CHK(hipMalloc(&e->masks, (size_t)e->nwg * kVisWG * 8));
   CREATE_CHK(hipMalloc(&e->wg_count, (size_t)e->nwg * 4));
-  e->seg_cap = (uint32_t)t.num_block;              // any list can hold every block
-  e->vis_cap = (kNumLists + 1) * e->seg_cap;       // 8 per-XCD lists + this frame's new blocks
+  // 8 per-XCD work lists; a segment = kFreshCap items for the list's new blocks (front_tail_role) in front of
+  // room for every block of the pool (device_types.h: kFreshCap); queries use the buffer as one flat list
+  e->seg_cap = (uint32_t)t.num_block + kFreshCap;
+  e->vis_cap = kFreshCap + kNumLists * e->seg_cap;
   CREATE_CHK(hipMalloc(&e->vis, (size_t)e->vis_cap * sizeof(VisItem)));
   for (int i = 0; i < 2; ++i) {
     CREATE_CHK(hipMalloc(&e->del_list[i], (size_t)t.num_block * sizeof(DelItem)));
@@ -1229,6 +1233,19 @@ int ratsdf_totals(ratsdf_engine* e, int64_t* out5, int reset) {
   HIPCHK(hipStreamSynchronize(e->stream));
   if (out5)
     for (int i = 0; i < 5; ++i) out5[i] = (int64_t)t[i];
+  return RATSDF_OK;
+}
+
+int ratsdf_pipeline_counters(ratsdf_engine* e, int64_t* out4, int reset) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  unsigned long long t[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(t, e->ctl->paths, sizeof(t), hipMemcpyDeviceToHost, e->stream));
+  if (reset) HIPCHK(hipMemsetAsync(e->ctl->paths, 0, sizeof(t), e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (out4)
+    for (int i = 0; i < 4; ++i) out4[i] = (int64_t)t[i];
   return RATSDF_OK;
 }
 
@@ -1997,7 +2014,7 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
     JobPtr cur = (JobPtr)(g->d_jobs + (size_t)f * S);
     JobPtr nxt = (JobPtr)(g->d_jobs + (size_t)(has_next ? f + 1 : f) * S);
     hipLaunchKernelGGL(k_front_g, dim3(gg.n_front_wg, S), dim3(256), 0, g->stream, engs, cur, nxt,
-                       (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, gg.a);
+                       (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, (uint32_t)(fused && e0->front_tail), gg.a);
     if (!fused) {
       const unsigned extra_b = gg.b.n_tiles ? (gg.b.n_tiles + gg.b.tiles_per_wg - 1) / gg.b.tiles_per_wg : 0;
       hipLaunchKernelGGL(k_alloc_rank_g, dim3(1 + extra_b, S), dim3(1024), kSerialLdsBytes, g->stream,

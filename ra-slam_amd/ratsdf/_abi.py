@@ -68,7 +68,7 @@ assert VOXEL_SEGM_DTYPE.itemsize == 20 and RGBW_DTYPE.itemsize == 4
 SYMBOLS = [
     "create", "create_ex", "destroy", "integrate", "integrate_device", "integrate_device_batch",
     "integrate_batch", "host_alloc", "host_free", "synchronize", "stream",
-    "profile_enable", "profile_read", "profile_read_frames", "totals",
+    "profile_enable", "profile_read", "profile_read_frames", "totals", "pipeline_counters",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "raycast", "raycast_device", "gather_valid_mesh", "download_all_mesh",
     "export_directory_device", "group_create", "group_destroy", "group_size",
@@ -117,6 +117,7 @@ class Library:
         self.fn["profile_read_frames"].argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                                     C.POINTER(C.c_int)]
         self.fn["totals"].argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
+        self.fn["pipeline_counters"].argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
         self.fn["num_active_blocks"].argtypes = [vp, C.POINTER(C.c_int32)]
         self.fn["last_frame_stats"].argtypes = [vp, C.POINTER(FrameStats)]
         self.fn["query"].argtypes = [vp, C.POINTER(Bounds), C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -340,6 +341,14 @@ class Engine:
         _check(self.lib.fn["totals"](self._h, t, 1 if reset else 0), "totals")
         return dict(zip(("frames", "visible_blocks", "updated_voxels", "allocated_blocks",
                          "deleted_blocks"), [int(v) for v in t]))
+
+    def pipeline_counters(self, reset=False):
+        """dict(front_tail, in_launch, in_launch_resolver, in_launch_general): frames by where their serial
+        allocation-order pass ran (HIP engine only)."""
+        t = (C.c_int64 * 4)()
+        _check(self.lib.fn["pipeline_counters"](self._h, t, 1 if reset else 0), "pipeline_counters")
+        return dict(zip(("front_tail", "in_launch", "in_launch_resolver", "in_launch_general"),
+                        [int(v) for v in t]))
 
     def num_active_blocks(self):
         n = C.c_int32()

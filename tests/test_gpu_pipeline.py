@@ -61,6 +61,77 @@ def test_batches_match_oracle(chunks, make_engine, make_oracle):
     assert_stats_equal(gpu, cpu)
 
 
+@pytest.mark.parametrize("front_tail", ["1", "0"])
+def test_where_the_serial_role_runs(front_tail, monkeypatch, make_engine, make_oracle):
+    """Ordinary frames (no chained buckets, at most 2 048 requests / 768 winners) have their allocation-order
+    pass done by the last directory workgroup of k_front (front_tail_role) and their new blocks handed to
+    k_integrate as work-list items; RATSDF_FRONT_TAIL=0 keeps the pass inside k_integrate (the form every
+    other frame takes).  Same map either way, and the engine says which form the frames took."""
+    monkeypatch.setenv("RATSDF_FRONT_TAIL", front_tail)
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    monkeypatch.delenv("RATSDF_FRONT_TAIL")
+    frames = synthetic.stream("room", 14, scale=0.25, noise=True, holes=True)
+    frames = frames + frames[::-1][:6]
+    dev = device_frames(frames)
+    lo = 0
+    for n in (1, 2, 9, 8):
+        gpu.integrate_device_batch(make_batch(gpu, frames, dev, lo, lo + n, md))
+        oracle_run(cpu, frames[lo:lo + n], md)
+        lo += n
+        assert_maps_equal(gpu, cpu)
+        assert_stats_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+    c = gpu.pipeline_counters()
+    assert sum(c.values()) == len(frames), c
+    if front_tail == "1":
+        assert c["front_tail"] >= len(frames) - 1, c   # (the first frame of the view may be too large)
+    else:
+        assert c["front_tail"] == 0 and c["in_launch"] == len(frames), c
+
+
+def test_front_tail_at_full_size_with_fallbacks(make_engine, make_oracle):
+    """640x480 / 5 mm, the benchmark's stream: the first frame of the view files thousands of requests (the
+    role runs inside k_integrate), the following ones are ordinary (tail of k_front); a 60-degree jump in the
+    middle of the batch sends one frame back to the in-launch form.  Parity over the whole sequence."""
+    vs, md = 0.005, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+    idx = [0, 1, 2, 3, 4, 64, 65, 66, 5, 6]
+    frames = [synthetic.frame("room", i, noise=True, holes=True) for i in idx]
+    dev = device_frames(frames)
+    gpu.integrate_device_batch(make_batch(gpu, frames, dev, 0, len(frames), md))
+    oracle_run(cpu, frames, md)
+    assert_maps_equal(gpu, cpu)
+    assert_stats_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+    c = gpu.pipeline_counters()
+    assert sum(c.values()) == len(frames) and c["front_tail"] >= 5 and c["in_launch"] + c["in_launch_general"] >= 2, c
+
+
+def test_resolver_and_shared_claim_pass_in_one_frame(make_engine, make_oracle):
+    """A frame with chained-bucket requests AND more than 4 096 ordinary ones: the resolver (workgroup 0 of
+    k_integrate) resets claims of buckets it locks, and the pass over the requests is shared with the seven
+    workgroups beside it, one per XCD -- they must see those resets (write-through stores).  A
+    32 768-bucket directory under full-resolution views 90 degrees apart: the second view allocates 5 036
+    blocks, some of them in buckets the first view filled."""
+    vs, md = 0.004, 4.0
+    kw = dict(bucket_bits=15)
+    gpu, cpu = make_engine(vs, 6 * vs, **kw), make_oracle(vs, 6 * vs, threads=16, **kw)
+    seen = []
+    for i in (0, 90):
+        f = synthetic.frame("room", i, noise=True, holes=True)
+        d = device_frames([f])[0]
+        h, w = f["depth"].shape
+        gpu.integrate_device(d["rgb"].data_ptr(), d["depth"].data_ptr(), d["ht"].data_ptr(), d["lt"].data_ptr(),
+                             h, w, md, f["intrinsics"], f["pose"])
+        cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+        assert_maps_equal(gpu, cpu)
+        s = cpu.last_frame_stats()
+        seen.append((s["slow_requests"], s["allocated_blocks"]))
+    # (allocated blocks are a lower bound of the frame's ordinary requests)
+    assert any(slow > 0 and alloc > 4096 for slow, alloc in seen), seen
+
+
 def test_single_frame_calls_without_queries(make_engine, make_oracle):
     """ratsdf_integrate_device frame after frame: no look-ahead, but the deferred carve tail."""
     vs, md = 0.02, 4.0
