@@ -85,15 +85,24 @@ constexpr uint32_t kFrontLdsWords = 2 * kSmallCarve + 16;  // LDS of a k_front w
 constexpr uint32_t kTailPerThread = 8;
 constexpr uint32_t kTailReqMax = kTailPerThread * 256;  // requests of a frame (all in registers at once)
 constexpr uint32_t kTailWinMax = kFreshCap;             // winners (ordered in LDS)
-// LDS words: [0, 32) counters | ranks (+16 of padding) | x,y | z | entry | pool indices
-constexpr uint32_t kTailLdsWords = 32 + (kTailWinMax + 16) + 4 * kTailWinMax;
+constexpr uint32_t kTailBins = 512;                     // bins of the winners' counting sort by raster rank
+// LDS words: [0, 32) counters | rank | x,y | z, entry slot | ranks sorted by bin | bin cursors, then pool indices
+constexpr uint32_t kTailLdsWords = 32 + 5 * kTailWinMax;
+static_assert(kTailBins <= kTailWinMax && kTailBins == 2 * 256, "two bins per thread; the cursors' memory is reused");
 
 // Every wave of a directory workgroup of k_front calls this when its role is done; true (uniform) in the
 // workgroup that reports last.  `wg`: its index among the n_wg directory workgroups.
-__device__ inline bool front_arrive(FrameCtl* F, uint32_t wg, uint32_t n_wg) {
+__device__ inline bool front_arrive(FrameCtl* F, uint32_t wg, uint32_t n_wg, Ctl* ctl) {
   __shared__ uint32_t arrived_last;
+#ifdef RATSDF_STAMPS
+  __shared__ unsigned long long arrive_t[3];
+  if (threadIdx.x == 0) arrive_t[0] = wall_clock64();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU ...
   __syncthreads();                                  // ... and every other wave's
+#ifdef RATSDF_STAMPS
+  if (threadIdx.x == 0) arrive_t[1] = wall_clock64();
+#endif
   if (threadIdx.x == 0) {
     const uint32_t sub = wg % kArriveSubs;
     const uint32_t members = (n_wg - sub + kArriveSubs - 1) / kArriveSubs;  // workgroups b < n_wg, b % subs == sub
@@ -104,8 +113,17 @@ __device__ inline bool front_arrive(FrameCtl* F, uint32_t wg, uint32_t n_wg) {
       last = __hip_atomic_fetch_add(&F->arrive_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tops - 1u;
     }
     arrived_last = last;
+#ifdef RATSDF_STAMPS
+    arrive_t[2] = wall_clock64();
+#endif
   }
   __syncthreads();
+#ifdef RATSDF_STAMPS
+  if (arrived_last && threadIdx.x == 0) {  // timeline of the last arriver, relative to the launch's first stamp
+    const unsigned long long T0 = __hip_atomic_load(&ctl->tstamps[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 3; ++i) ctl->tstamps[1 + i] += arrive_t[i] - T0;
+  }
+#endif
   return arrived_last != 0u;
 }
 
@@ -120,12 +138,15 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
   FrameCtl* F = &ctl->fr[par];
   FrameCtl* Fp = &ctl->fr[par ^ 1u];
   uint32_t* win_rank = lds + 32;
-  uint32_t* win_w0 = win_rank + kTailWinMax + 16;
-  uint32_t* win_z = win_w0 + kTailWinMax;
-  uint32_t* win_e = win_z + kTailWinMax;
-  uint32_t* hc = win_e + kTailWinMax;
+  uint32_t* win_w0 = win_rank + kTailWinMax;
+  uint32_t* win_ze = win_w0 + kTailWinMax;   // z | (entry & 1) << 16 (the entry's bucket is the block's hash)
+  uint32_t* srt = win_ze + kTailWinMax;      // the winners' ranks, grouped by bin
+  uint32_t* bins = srt + kTailWinMax;        // kTailBins cursors; later the pool indices the winners pop
   // lds: [0] head / chain deletes of the previous frame that happened, [1] winners, [2] voxels updated,
-  //      [4 + l] new blocks filed in list l
+  //      [4 + l] new blocks filed in list l, [16, 20) wave totals of the scan
+  // bin of a raster rank: rank >> sh, below kTailBins for every rank of the frame (pixel * S + sample)
+  const uint32_t nranks = (uint32_t)(P.W * P.H) * (uint32_t)P.S;
+  const uint32_t sh = nranks > kTailBins ? 32u - (uint32_t)__builtin_clz((nranks - 1u) >> 9) : 0u;
 
   // ---- one round of loads ----
   const int32_t nf0 = ctl->num_free;                 // (previous launches: plain)
@@ -145,12 +166,18 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
   static_assert(kUpdCounters / NT == 4, "one uint4 of update counters per thread");
   if (pend) u = reinterpret_cast<const uint4*>(cb.upd_wg)[tid];
   if (tid < 32) lds[tid] = 0;
-  for (uint32_t i = tid; i < kTailWinMax + 16; i += NT) win_rank[i] = kInf;  // (padding of the 16-byte reads)
+  bins[tid] = 0;
+  bins[tid + NT] = 0;
   if (nd > cb.del_cap) nd = cb.del_cap;
   if (ns > cb.slow_cap) ns = cb.slow_cap;
   if (n > req_cap) n = req_cap;
   // uniform: not a frame for the tail -- nothing has been changed
   if (n_slow != 0 || n > kTailReqMax || (pend && nd + ns > kSmallCarve)) return;
+#ifdef RATSDF_STAMPS
+  unsigned long long tt[5];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  tt[0] = wall_clock64();
+#endif
   lds_barrier();
   if (pend && ns) {  // rare: states written by carve_resolve_slow in workgroup 0 of this launch
     for (uint32_t j = tid; j < ns; j += NT)
@@ -185,52 +212,104 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
       if (slot < kTailWinMax) {
         win_rank[slot] = r[k].rank;
         win_w0[slot] = key0(r[k].x, r[k].y);
-        win_z[slot] = key1(r[k].z);
-        win_e[slot] = r[k].entry;
+        win_ze[slot] = key1(r[k].z) | ((r[k].entry & 1u) << 16);
+        atomicAdd(&bins[(r[k].rank >> sh) & (kTailBins - 1u)], 1u);
       }
     }
   }
-#pragma unroll
-  for (uint32_t q = 0; q < kTailWinMax / NT; ++q) hc[tid + q * NT] = (uint32_t)hv[q];
   lds_barrier();
+#ifdef RATSDF_STAMPS
+  tt[1] = wall_clock64();
+#endif
   const uint32_t total = lds[1];
   if (total > kTailWinMax) return;  // uniform: a new view -- still nothing changed
   const uint32_t take = (int64_t)total > (int64_t)nf ? (uint32_t)(nf > 0 ? nf : 0) : total;  // voxel_mem.cu:39
 
+  // ---- the winners' order (= order of the AquireBlock calls): a counting sort by bins of the raster rank.
+  // (Until this was a count of the smaller ranks over the whole list per winner -- 270 winners: 74 k compares --
+  // the tail spent 6.6 us of vector ALU time here, beside the look-ahead candidate workgroups the launch hosts.)
+  {  // exclusive prefix of the bin counts, in place: two bins per thread
+    const uint32_t a = bins[2u * tid], b = bins[2u * tid + 1u];
+    uint32_t x = a + b;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(x, o);
+      if (lane >= (uint32_t)o) x += t;
+    }
+    if (lane == 63u) lds[16 + wave] = x;
+    lds_barrier();
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < NT / 64; ++w)
+      if (w < wave) before += lds[16 + w];
+    const uint32_t excl = before + x - (a + b);
+    bins[2u * tid] = excl;
+    bins[2u * tid + 1u] = excl + a;
+  }
+  lds_barrier();
+  constexpr uint32_t kSlots = kTailWinMax / NT;  // winners per thread
+  uint32_t mine[kSlots], ord[kSlots];
+#pragma unroll
+  for (uint32_t q = 0; q < kSlots; ++q) {  // placement: a bin's cursor ends up at the bin's end
+    const uint32_t w = tid + q * NT;
+    mine[q] = w < total ? win_rank[w] : 0u;
+    if (w < total) srt[atomicAdd(&bins[(mine[q] >> sh) & (kTailBins - 1u)], 1u)] = mine[q];
+  }
+  lds_barrier();
+#pragma unroll
+  for (uint32_t q = 0; q < kSlots; ++q) {  // winners of smaller rank = those in lower bins + the smaller ones of its own
+    const uint32_t w = tid + q * NT;
+    ord[q] = kInf;
+    if (w < total) {
+      const uint32_t bin = (mine[q] >> sh) & (kTailBins - 1u);
+      const uint32_t lo = bin ? bins[bin - 1u] : 0u, hi = bins[bin];
+      uint32_t k = lo;
+      for (uint32_t j = lo; j < hi; ++j) k += srt[j] < mine[q];
+      ord[q] = k;
+    }
+  }
+  lds_barrier();  // (the cursors have been read: their memory takes the pool indices)
+#pragma unroll
+  for (uint32_t q = 0; q < kSlots; ++q) bins[tid + q * NT] = (uint32_t)hv[q];
+  lds_barrier();
+  // ---- commit: pool index, directory entry, occupancy bit, work-list item ----
+#pragma unroll
+  for (uint32_t q = 0; q < kSlots; ++q) {
+    const uint32_t w = tid + q * NT;
+    if (w < total && ord[q] < take) {
+      const uint32_t w0 = win_w0[w], ze = win_ze[w], w1 = ze & 0xFFFFu;
+      const int bx = (int16_t)(w0 & 0xFFFFu), by = (int16_t)(w0 >> 16), bz = (int16_t)w1;
+      const uint32_t e = (block_hash(bx, by, bz, tab.bucket_mask) << 1) + (ze >> 16);
+      const int32_t idx = (int32_t)bins[ord[q]];
+      uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + e);
+      pe[0] = w0;                                                       // voxel_hash.cu:72-74
+      pe[1] = w1;                                                       // offset 0
+      pe[2] = (uint32_t)idx;
+      atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
+      // Which of the 8 per-XCD lists: the image tile of the pixel that asked first (block_list_of projects the
+      // block's centre -- ~100 vector instructions; placement only affects speed, any list is correct).
+      // Approximate float arithmetic on purpose; the same on every run.
+      const float fpix = floorf((float)mine[q] * (1.f / (float)P.S));
+      const float fy = floorf(fpix * (1.f / (float)P.W)), fx = fpix - fy * (float)P.W;
+      int tx = (int)(fx * (8.f / (float)P.W)), ty = (int)(fy * (8.f / (float)P.H));
+      tx = tx < 0 ? 0 : (tx > 7 ? 7 : tx);
+      ty = ty < 0 ? 0 : (ty > 7 ? 7 : ty);
+      const uint32_t l = (uint32_t)(tx + 3 * ty) & 7u;
+      const uint32_t pos = atomicAdd(&lds[4 + l], 1u);  // < kFreshCap: total <= kTailWinMax
+      reinterpret_cast<uint4*>(vis)[(ptrdiff_t)((size_t)l * seg_cap + pos) - (ptrdiff_t)kFreshCap] =
+          make_uint4(w0, w1, (uint32_t)idx, e);
+    }
+  }
   // ---- ResetLocks: every request's bucket (voxel_hash.cu:35-38) ----
 #pragma unroll
   for (int k = 0; k < kU; ++k) {
     const uint32_t i = tid + (uint32_t)k * NT;
     if (i < n) tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)] = kInf;
   }
-  // ---- commit, one winner per thread and pass: order = winners of smaller rank (every lane reads the same
-  // 16 bytes of the list at a time: LDS broadcasts), pool index, directory entry, occupancy bit, work-list item
-  const uint4* wl = reinterpret_cast<const uint4*>(win_rank);
-  const uint32_t nchunks = (total + 3u) >> 2;
-  for (uint32_t base = 0; base < total; base += NT) {  // uniform
-    const uint32_t w = base + tid;
-    const uint32_t mine = w < total ? win_rank[w] : 0u;
-    uint32_t k = 0;
-#pragma unroll 4
-    for (uint32_t q = 0; q < nchunks; ++q) {
-      const uint4 x = wl[q];
-      k += (x.x < mine) + (x.y < mine) + (x.z < mine) + (x.w < mine);
-    }
-    if (w < total && k < take) {
-      const uint32_t w0 = win_w0[w], w1 = win_z[w], e = win_e[w];
-      const int32_t idx = (int32_t)hc[k];
-      uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + e);
-      pe[0] = w0;                                                       // voxel_hash.cu:72-74
-      pe[1] = w1;                                                       // offset 0
-      pe[2] = (uint32_t)idx;
-      atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
-      const int bx = (int16_t)(w0 & 0xFFFFu), by = (int16_t)(w0 >> 16), bz = (int16_t)(w1 & 0xFFFFu);
-      const uint32_t l = (uint32_t)block_list_of(bx, by, bz, P);
-      const uint32_t pos = atomicAdd(&lds[4 + l], 1u);  // < kFreshCap: total <= kTailWinMax
-      reinterpret_cast<uint4*>(vis)[(ptrdiff_t)((size_t)l * seg_cap + pos) - (ptrdiff_t)kFreshCap] =
-          make_uint4(w0, w1, (uint32_t)idx, e);
-    }
-  }
+#ifdef RATSDF_STAMPS
+  tt[2] = wall_clock64();
+#endif
   // ---- previous frame: voxels-updated sum ----
   if (pend) {
     uint32_t up = u.x + u.y + u.z + u.w;
@@ -269,6 +348,14 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
     F->front_done = 1;
     ctl->num_free = nf - (int32_t)take;
     atomicAdd(&ctl->paths[0], 1ull);
+#ifdef RATSDF_STAMPS
+    tt[3] = wall_clock64();
+    const unsigned long long T0 = __hip_atomic_load(&ctl->tstamps[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 4; ++i) ctl->tstamps[4 + i] += tt[i] - T0;
+    ctl->tstamps[8] += 1;
+    ctl->tstamps[9] += n;
+    ctl->tstamps[10] += total;
+#endif
   }
 }
 
@@ -297,6 +384,14 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
   }
   FrameCtl* F = &ctl->fr[par];
   FrameCtl* Fp = &ctl->fr[par ^ 1u];
+  // The launch's critical path runs in these workgroups -- chains of dependent round trips with a little
+  // arithmetic in between -- while the look-ahead candidate workgroups it hosts keep the vector ALUs busy:
+  // ask the instruction arbiter for priority over them.
+  if (tail & 2u) __builtin_amdgcn_s_setprio(3);
+#ifdef RATSDF_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(&ctl->tstamps[0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   // (diagnostic build, RATSDF_DEBUG=20: workgroup 0 never publishes -- the waiters' bounded wait is what
   // tests/test_gpu_errors.py::test_in_launch_waits_are_bounded exercises)
   bool expired = false;  // uniform per workgroup
@@ -319,7 +414,7 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
   }
   // (a workgroup whose gate expired does not report: the directory may be half-edited, the tail must not
   // run on it -- the sticky error says the frame is incomplete)
-  if (tail && !expired && front_arrive(F, blockIdx.x, n_dir_wg))
+  if ((tail & 1u) && !expired && front_arrive(F, blockIdx.x, n_dir_wg, ctl))
     front_tail_role(tab, P, cand, req, req_cap, vis, seg_cap, pool, cb, ctl, par, stats, role_lds);
 }
 

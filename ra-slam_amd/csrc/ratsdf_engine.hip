@@ -108,7 +108,12 @@ struct ratsdf_engine {
   unsigned cand_split = 20;              // percent of the look-ahead pass placed in k_front,
   unsigned cand_split_b = 0;             // in k_alloc_rank; the rest rides in k_integrate
   bool fused_serial = true;              // the frame's serial role rides in k_integrate (no k_alloc_rank)
-  bool front_tail = true;                // ... or, in ordinary frames, at the tail of k_front (front_tail_role)
+  // ... or, in ordinary frames, at the tail of k_front (front_tail_role, RATSDF_FRONT_TAIL=1).  Off by default:
+  // measured (profiles/r04_front_tail.txt) it shortens k_integrate to the pure voxel update (16.8 -> 12.1 us
+  // at 640x480 with the whole look-ahead pass in k_front) but lengthens k_front by more (8.6 -> 15.8 us): the
+  // role is ~7 us of dependent round trips wherever it runs, and inside k_integrate it hides behind the update.
+  bool front_tail = false;
+  uint32_t front_prio = 0u;              // 2: k_front's directory workgroups run at raised wave priority (+1 %)
   int commit_rot_env = -1;               // RATSDF_COMMIT_ROT: first committing workgroup (measurements)
   // With the serial role in the launch: which update workgroups take the frame's commits.  A grid of
   // at most two rounds of resident workgroups (256 CUs x 8): the first ones, which wait for the role
@@ -570,7 +575,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   const bool fused = fused_serial && vpl != 1;
   hipLaunchKernelGGL(k_front, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
                      (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis + kFreshCap, seg_cap, pool, carve_bufs(par ^ 1u),
-                     ctl, (uint32_t)par, d_stats, (uint32_t)(fused && front_tail), ahead_a);
+                     ctl, (uint32_t)par, d_stats, (uint32_t)((fused && front_tail) ? 1u : 0u) | front_prio, ahead_a);
   if (!fused) {
     st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
     if (st != RATSDF_OK) return st;
@@ -717,6 +722,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   if (const char* v = getenv("RATSDF_COMMIT_ROT")) e->commit_rot_env = atoi(v);
   if (const char* v = getenv("RATSDF_FUSED_SERIAL")) e->fused_serial = atoi(v) != 0;  // 0: k_alloc_rank launch
   if (const char* v = getenv("RATSDF_FRONT_TAIL")) e->front_tail = atoi(v) != 0;  // 0: the role always in k_integrate
+  if (const char* v = getenv("RATSDF_FRONT_PRIO")) e->front_prio = atoi(v) ? 2u : 0u;
   if (const char* v = getenv("RATSDF_SERIAL_LDS")) {
     const int x = atoi(v);
     if (x >= kSerialLdsBytes && x <= 160 * 1024) e->serial_lds = (unsigned)x;
@@ -1191,6 +1197,24 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
                   done[done.size() * 99 / 100] - t0, last - t0);
     }
   }
+  return RATSDF_OK;
+}
+
+// diagnostic: timeline of k_front's tail (stamps build only): sums over frames of wall-clock ticks (10 ns)
+// since the launch's first workgroup started
+extern "C" int ratsdf_debug_tail_stamps(ratsdf_engine* e) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  unsigned long long t[16];
+  HIPCHK(hipMemcpyAsync(t, e->ctl->tstamps, sizeof(t), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemsetAsync(e->ctl->tstamps, 0, sizeof(t), e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const double n = t[8] ? (double)t[8] : 1.0;
+  fprintf(stderr, "[tail stamps] %llu tail frames; us after the launch's first workgroup started: last directory workgroup "
+          "done %.2f | its stores drained %.2f | it knows it is last %.2f | tail: first round of loads in %.2f | claims + "
+          "winners listed %.2f | commits issued %.2f | end %.2f ; requests %.1f winners %.1f per frame\n",
+          t[8], t[1] / n / 100, t[2] / n / 100, t[3] / n / 100, t[4] / n / 100, t[5] / n / 100, t[6] / n / 100,
+          t[7] / n / 100, t[9] / n, t[10] / n);
   return RATSDF_OK;
 }
 
@@ -2014,7 +2038,7 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
     JobPtr cur = (JobPtr)(g->d_jobs + (size_t)f * S);
     JobPtr nxt = (JobPtr)(g->d_jobs + (size_t)(has_next ? f + 1 : f) * S);
     hipLaunchKernelGGL(k_front_g, dim3(gg.n_front_wg, S), dim3(256), 0, g->stream, engs, cur, nxt,
-                       (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, (uint32_t)(fused && e0->front_tail), gg.a);
+                       (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, (uint32_t)((fused && e0->front_tail) ? 1u : 0u) | e0->front_prio, gg.a);
     if (!fused) {
       const unsigned extra_b = gg.b.n_tiles ? (gg.b.n_tiles + gg.b.tiles_per_wg - 1) / gg.b.tiles_per_wg : 0;
       hipLaunchKernelGGL(k_alloc_rank_g, dim3(1 + extra_b, S), dim3(1024), kSerialLdsBytes, g->stream,

@@ -90,12 +90,14 @@ def test_where_the_serial_role_runs(front_tail, monkeypatch, make_engine, make_o
         assert c["front_tail"] == 0 and c["in_launch"] == len(frames), c
 
 
-def test_front_tail_at_full_size_with_fallbacks(make_engine, make_oracle):
+def test_front_tail_at_full_size_with_fallbacks(monkeypatch, make_engine, make_oracle):
     """640x480 / 5 mm, the benchmark's stream: the first frame of the view files thousands of requests (the
     role runs inside k_integrate), the following ones are ordinary (tail of k_front); a 60-degree jump in the
     middle of the batch sends one frame back to the in-launch form.  Parity over the whole sequence."""
     vs, md = 0.005, 4.0
+    monkeypatch.setenv("RATSDF_FRONT_TAIL", "1")
     gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
+    monkeypatch.delenv("RATSDF_FRONT_TAIL")
     idx = [0, 1, 2, 3, 4, 64, 65, 66, 5, 6]
     frames = [synthetic.frame("room", i, noise=True, holes=True) for i in idx]
     dev = device_frames(frames)
