@@ -7,7 +7,8 @@ A step = one batch of `--frames-per-step` synthetic 640x480 frames (depth + rgb 
 truncation 30 mm, max depth 4 m, ScanNet intrinsics; the "room" stream of ratsdf.synthetic)
 integrated through the C ABI (ratsdf_integrate_device_batch) with every input already resident in
 HBM; `--reps` timed repetitions of K steps each, `value` = the median.  For N > 1 the driver launches
-one process per GPU with torch.distributed.run; each rank integrates its own stream into its own map
+one process per GPU with torch.distributed.run (started plainly as `python bench.py --gpus N`, the script
+starts those N ranks itself, as child processes, before it touches the GPU); each rank integrates its own stream into its own map
 (frame-batched config of BASELINE.json) and the ranks all-gather the deltas of their block directories
 over RCCL once per step (ratsdf.multi.DirectoryDeltaExchange).  Rank 0 prints ONE JSON line.
 
@@ -371,15 +372,32 @@ def bench_tsdf_system(frames, md, vs, nframes=3000):
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as CHILD processes through
+    torch.distributed.run (one rank per GPU over RCCL, rendezvous on 127.0.0.1), forward what they print and
+    exit with their status.  Called before this process has imported torch or touched the GPU: nothing here
+    initialises HIP, and nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:   # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes of one node)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N "
-                             "--master-addr 127.0.0.1 bench.py --gpus N ...")
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            self_launch(a)   # does not return
         a.gpus = world
     import torch
     import torch.distributed as dist
@@ -585,10 +603,16 @@ def main():
         nh = min(a.host_frames, len(frames))
         for f in frames[:4]:
             hp.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"], f["pose"])
+        hp.synchronize()
+        nh_total = 0
         th = time.perf_counter()
-        for f in frames[:nh]:
-            hp.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"], f["pose"])
+        for _ in range(5):   # (the calls do not wait for their frames: the timed region ends with a synchronisation)
+            for f in frames[:nh]:
+                hp.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"], f["pose"])
+            nh_total += nh
+        hp.synchronize()
         th = time.perf_counter() - th
+        nh = nh_total
         hp.integrate_batch(frames[:8], a.max_depth)
         nb = 0
         tb = time.perf_counter()
@@ -600,9 +624,11 @@ def main():
         bytes_per_frame = sum(frames[0][k].nbytes for k in ("rgb", "depth", "ht", "lt"))
         host_path = dict(frames_per_s=round(nh / th, 1), frames=nh, batched_frames_per_s=round(nb / tb, 1),
                          batched_frames=nb, batched_h2d_gbps=round(nb * bytes_per_frame / tb / 1e9, 1),
-                         note="ratsdf_integrate with host images: H2D copy (4.6 MB/frame) and a "
-                              "stream sync per frame included; batched = ratsdf_integrate_batch, "
-                              "8 frames per call from pageable memory")
+                         note="ratsdf_integrate with pageable host images, one call per frame (the calling "
+                              "convention of examples/tsdf/offline.cc:169): staging copy into the engine's "
+                              "page-locked ring (4.6 MB/frame, 4 threads), H2D on a copy stream, frame enqueued; "
+                              "one synchronisation at the end of the timed region; batched = "
+                              "ratsdf_integrate_batch, 8 frames per call from pageable memory")
         # page-locked copies of the stream's frames
         # (one block per frame, its images side by side as depth | ht | lt | rgb: the order of the engine's
         # staging slot, so a frame goes up as ONE copy -- include/ratsdf.h, ratsdf_integrate_batch)

@@ -132,7 +132,13 @@ int ratsdf_destroy(ratsdf_engine* e);
  * voxel_tsdf.cu:416-452.  Host buffers: rgb = H*W*3 u8 (RGB order), depth/ht/lt = H*W f32
  * (metres / probabilities).  ht == NULL or lt == NULL means all-ones images, as
  * TSDFSystem::Integrate substitutes (modules/tsdf_module.cc:27-31).  Caller buffers are not
- * retained after return.  Blocks until the frame is integrated, like the reference. */
+ * retained after return (they are copied into the engine's page-locked staging ring before the call
+ * returns).  The HIP engine does NOT wait for the frame: upload and kernels are enqueued, and a device
+ * error of this frame is reported by the next entry point that synchronises (ratsdf_synchronize, every
+ * query / statistics call) -- the reference ends Integrate with a stream synchronisation
+ * (voxel_tsdf.cu:450) but returns nothing, so its callers (examples/tsdf/offline.cc:169,
+ * examples/scannet_evaluation/eval_one.cc:75) cannot tell the difference.  RATSDF_SYNC_INTEGRATE=1 in the
+ * environment restores the wait; the oracle integrates synchronously. */
 int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, const float* ht,
                      const float* lt, int height, int width, float max_depth,
                      const ratsdf_intrinsics* intrinsics, const ratsdf_pose* cam_T_world);

@@ -1,0 +1,51 @@
+"""`python bench.py --gpus N` with no launcher around it starts its N ranks itself (child processes through
+torch.distributed.run, rendezvous on 127.0.0.1), forwards rank 0's JSON line and exits with the ranks' status.
+
+Without a GPU the ranks cannot integrate anything (the engine has no CPU path), so the CPU test checks the
+launch itself: N ranks really start with RANK / WORLD_SIZE set, each refuses for the right reason, and the
+failure reaches the caller's exit status.  On the GPU box the same entry runs the N = 2 control flow end to end
+(both ranks on the one device, gloo instead of RCCL: RATSDF_BENCH_DEVICE / RATSDF_BENCH_BACKEND)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(args, extra_env, timeout):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=str(ROOT))
+
+
+def test_gpus_n_starts_n_ranks_and_propagates_their_status():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by test_two_ranks_through_the_plain_entry_point")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {}, 300)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0, out[-2000:]
+    # both ranks started and stopped at the engine's "no GPU" refusal (not at an argument or rendezvous error)
+    assert out.count("needs an MI355X") >= 2, out[-2000:]
+    assert "launch N > 1 with" not in out
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_the_plain_entry_point():
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reps", "1", "--frames-per-step", "12",
+              "--cpu-frames", "0", "--host-frames", "0", "--no-secondary", "--streams", "0"],
+             {"RATSDF_BENCH_DEVICE": "0", "RATSDF_BENCH_BACKEND": "gloo"}, 600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line, rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["streams"] == 2
+    assert d["directory_blocks_all_ranks"] > 0          # the directory exchange ran
