@@ -108,8 +108,8 @@ def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", en
     k_avg_s = k_ms / k_n / 1e3
     achieved = b_alg_per_launch / k_avg_s / 1e9
     traffic, src = None, None
-    tpath = traffic_file(config)
-    if engines == 1 and tpath.exists():  # PMC passes made on this very workload (tools/traffic.sh)
+    tpath = traffic_file(config) if engines == 1 else ROOT / "profiles" / f"traffic_group{engines}.json"
+    if tpath.exists():  # PMC passes made on this very workload (tools/traffic.sh, tools/traffic_group.sh)
         try:
             traffic = json.loads(tpath.read_text()).get("k_integrate_bytes_per_launch")
             src = f"profiles/{tpath.name} (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"

@@ -215,6 +215,71 @@ def test_edge_case_inputs(make_engine, make_oracle):
     assert_maps_equal(gpu, cpu)
 
 
+def test_probability_edge_cases(make_engine, make_oracle):
+    """The probability update is the one place where the kernel evaluates a different expression of the same
+    function (log-odds on v_log / v_exp / v_rcp instead of two exponentials of two logs, voxel_tsdf.cu:241-248):
+    its special values must come out as the reference's do.  Regions of the image, over several frames:
+      lt = 0            -> neg = 0, p = 1, and p stays 1 under ordinary observations (log(1 - p) = -inf)
+      ht = 0            -> p = 0, stays 0
+      p = 1, then ht = 0  -> 0 / 0 = NaN, which then propagates
+      ht = lt = 0       -> NaN at once
+      d = max_depth (w_new = 0) with ht = 0: 0 * -inf = NaN; with ordinary ht / lt: p (almost) unchanged
+    NaN in exactly the oracle's voxels, everything else within 1e-4, weights / colours / tsdf as ever."""
+    vs = 0.02
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    h, w = 96, 128
+    base = np.full((h, w), 1.5, np.float32)
+
+    def frame(seed, edits, depth=None):
+        f = _frame_like(base if depth is None else depth, seed)
+        for (r0, r1, c0, c1, ht, lt) in edits:
+            if ht is not None:
+                f["ht"][r0:r1, c0:c1] = ht
+            if lt is not None:
+                f["lt"][r0:r1, c0:c1] = lt
+        return f
+
+    A = (0, 24, 0, 64)        # lt = 0 for three frames, then ordinary
+    B = (24, 48, 0, 64)       # ht = 0 for two frames, then ordinary
+    C = (48, 72, 0, 64)       # lt = 0 (p -> 1), then ht = 0 (NaN), then ordinary (stays NaN)
+    D = (72, 96, 0, 64)       # ht = lt = 0
+    E = (0, 48, 64, 128)      # depth = max_depth with ht = 0
+    F = (48, 96, 64, 128)     # depth = max_depth with ordinary ht / lt, after two ordinary frames
+    d_far = base.copy()
+    d_far[E[0]:E[1], E[2]:E[3]] = 4.0
+    d_far[F[0]:F[1], F[2]:F[3]] = 4.0
+    frames = [
+        frame(1, [A + (None, 0.0), B + (0.0, None), C + (None, 0.0), D + (0.0, 0.0)]),
+        frame(2, [A + (None, 0.0), B + (0.0, None), C + (0.0, None), D + (0.0, 0.0)]),
+        frame(3, [A + (None, 0.0), E + (0.0, None)], depth=d_far),
+        frame(4, []),
+        frame(5, [E + (0.0, 0.0)], depth=d_far),
+        frame(6, []),
+    ]
+    saw_one = saw_zero = saw_nan = False
+    for i, f in enumerate(frames):
+        for e in (gpu, cpu):
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+        assert_stats_equal(gpu, cpu)
+        ei, bl = gpu.dump_directory()
+        eo, bo = cpu.dump_directory()
+        assert np.array_equal(ei, eo) and np.array_equal(bl, bo), f"frame {i}"
+        tg, cg, pg = gpu.dump_voxels(bl["idx"])
+        to, co, po = cpu.dump_voxels(bo["idx"])
+        assert np.array_equal(cg, co), f"frame {i}: rgbw"
+        assert np.array_equal(tg, to), f"frame {i}: tsdf"
+        assert np.array_equal(np.isnan(pg), np.isnan(po)), f"frame {i}: NaN probabilities in different voxels"
+        assert np.nanmax(np.abs(pg - po), initial=0) <= 1e-4, f"frame {i}"
+        # saturated values are exact, not merely close
+        assert np.array_equal(pg == 1.0, po == 1.0) and np.array_equal(pg == 0.0, po == 0.0), f"frame {i}"
+        saw_one |= bool((po == 1.0).any())
+        saw_zero |= bool((po == 0.0).any())
+        saw_nan |= bool(np.isnan(po).any())
+    assert saw_one and saw_zero and saw_nan   # the regions really produced the special values
+    from parity import assert_heap_equal
+    assert_heap_equal(gpu, cpu)
+
+
 def test_rotated_poses_and_long_motion(make_engine, make_oracle):
     """Poses whose rotation matrix takes the trace <= 0 branches of the matrix->quaternion conversion
     (180 degree turns about each axis) and a 40-frame sphere sequence with carving churn."""
