@@ -37,6 +37,8 @@ struct Request {
 static_assert(sizeof(Request) == 16, "request is 16 bytes");
 constexpr uint16_t kReqWinner = 1;
 constexpr uint16_t kReqPlaced = 2;
+constexpr uint16_t kReqSlot1 = 4;  // `entry` is the second entry of the home bucket (filed requests; lets a reader
+                                   // that has only the request's first three words rebuild `entry` from the hash)
 
 struct SlowRequest {
   int16_t x, y, z;

@@ -143,7 +143,7 @@ __device__ inline void alloc_request(const Table& t, int x, int y, int z, uint32
       const uint32_t e = (bucket << 1) + (a.idx < 0 ? 0u : 1u);
       const uint32_t slot = atomicAdd(&F->n_req, 1u);
       if (slot < req_cap) {
-        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, e};
+        req[slot] = Request{(int16_t)x, (int16_t)y, (int16_t)z, (uint16_t)(a.idx < 0 ? 0 : kReqSlot1), rank, e};
       } else {
         set_error(ctl, RATSDF_ERR_CAPACITY);
       }
@@ -224,7 +224,7 @@ __device__ inline void alloc_request_absent_wave(bool want, const Table& t, int 
       // the leader of an ordinary bucket fills its first empty home entry (voxel_hash.cu:67-78);
       // nothing else can take that slot during the pass, so it is fixed here
       const uint32_t e = (bucket << 1) + (a.idx < 0 ? 0u : 1u);
-      const Request r{(int16_t)x, (int16_t)y, (int16_t)z, 0, rank, e};
+      const Request r{(int16_t)x, (int16_t)y, (int16_t)z, (uint16_t)(a.idx < 0 ? 0 : kReqSlot1), rank, e};
       if (in_lds) {
         B.item[slot] = r;
       } else if (slot < req_cap) {

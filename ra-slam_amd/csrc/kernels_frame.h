@@ -156,12 +156,17 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
   const uint32_t nv = frame_visible_blocks(Fp);
   const uint32_t n_slow = ld_agent(&F->n_slow);      // (this launch's consumers: past the caches)
   uint32_t n = ld_agent(&F->n_req);
-  Request r[kU];  // the frame's requests: the slots exist whatever the count is
+  // the frame's requests (the slots exist whatever the count is): block, flags and rank -- the entry a
+  // request fills is its home bucket's first or second one (kReqSlot1)
+  RequestHead r[kU];
 #pragma unroll
   for (int k = 0; k < kU; ++k) {
     const uint32_t i = tid + (uint32_t)k * NT;
-    r[k] = ld_agent_request(req + (i < req_cap ? i : 0u));
+    r[k] = ld_agent_request_head(req + (i < req_cap ? i : 0u));
   }
+  auto bucket_of = [&](const RequestHead& q) {
+    return block_hash((int16_t)(q.w0 & 0xFFFFu), (int16_t)(q.w0 >> 16), (int16_t)(q.w1 & 0xFFFFu), tab.bucket_mask);
+  };
   uint4 u = make_uint4(0, 0, 0, 0);
   static_assert(kUpdCounters / NT == 4, "one uint4 of update counters per thread");
   if (pend) u = reinterpret_cast<const uint4*>(cb.upd_wg)[tid];
@@ -189,7 +194,7 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
   for (int k = 0; k < kU; ++k) {
     const uint32_t i = tid + (uint32_t)k * NT;
     c[k] = kInf;
-    if (i < n) c[k] = ld_agent(&tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)]);
+    if (i < n) c[k] = ld_agent(&tab.claim[bucket_of(r[k])]);
   }
   lds_barrier();
   const uint32_t n_del = pend ? nd + lds[0] : 0u;
@@ -211,8 +216,8 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
       const uint32_t slot = atomicAdd(&lds[1], 1u);
       if (slot < kTailWinMax) {
         win_rank[slot] = r[k].rank;
-        win_w0[slot] = key0(r[k].x, r[k].y);
-        win_ze[slot] = key1(r[k].z) | ((r[k].entry & 1u) << 16);
+        win_w0[slot] = r[k].w0;
+        win_ze[slot] = (r[k].w1 & 0xFFFFu) | (((r[k].w1 >> 16) & kReqSlot1) ? 1u << 16 : 0u);
         atomicAdd(&bins[(r[k].rank >> sh) & (kTailBins - 1u)], 1u);
       }
     }
@@ -305,7 +310,7 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
 #pragma unroll
   for (int k = 0; k < kU; ++k) {
     const uint32_t i = tid + (uint32_t)k * NT;
-    if (i < n) tab.claim[block_hash(r[k].x, r[k].y, r[k].z, tab.bucket_mask)] = kInf;
+    if (i < n) tab.claim[bucket_of(r[k])] = kInf;
   }
 #ifdef RATSDF_STAMPS
   tt[2] = wall_clock64();
@@ -418,7 +423,7 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
     front_tail_role(tab, P, cand, req, req_cap, vis, seg_cap, pool, cb, ctl, par, stats, role_lds);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8))) void k_front(
     Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, uint32_t cand_parts, Request* req,
     uint32_t req_cap,
     SlowRequest* slow, uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Pool pool, CarveBufs cb,
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fr
 }
 
 // the same launch for several engines: engine blockIdx.y, operands from its record and its job
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_front_g(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8))) void k_front_g(
     EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_vis_wg, uint32_t cand_parts, uint32_t tail, AheadGeom ag) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
   EnginePtr E = engs + blockIdx.y;

@@ -258,11 +258,33 @@ struct ratsdf_engine {
   bool sync_integrate = false;         // RATSDF_SYNC_INTEGRATE=1: wait for every frame (the round-3 behaviour)
   HostCopyPool* copy_pool = nullptr;
 
+  // HIP graphs of the batch entry point (ratsdf_integrate_device_batch): the launches of an n-frame batch are
+  // captured once per (image size, n) -- the kernels of the group path with one member, which take every
+  // per-frame operand (pose, intrinsics, image pointers, counter-set parity) from a FrameJob table in device
+  // memory -- and replayed with a fresh table.  Host cost per frame: a table row instead of two launches.
+  struct BatchGraph {
+    int H = 0, W = 0, n = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    FrameJob* d_jobs = nullptr;
+    FrameJob* h_jobs[2] = {nullptr, nullptr};  // page-locked, used alternately
+    hipEvent_t ev[2] = {nullptr, nullptr};     // the copy out of h_jobs[i] has been executed
+    unsigned turn = 0;
+    uint64_t last_use = 0;
+  };
+  std::vector<BatchGraph> graphs;
+  bool use_graphs = true;                // RATSDF_GRAPH=0: every frame launched by itself
+  uint64_t graph_clock = 0;
+  void free_graph(BatchGraph& g);
+  int batch_graph(int n, int H, int W, BatchGraph** out);
+  int record_version = 0;                // bumped by upload_record (graphs read the record through d_eng)
+
   // profiling of the dominant kernel
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
   uint64_t prof_frame = 0;
+  uint64_t prof_batch = 0;
   double prof_ms = 0;
   int64_t prof_n = 0;
   int prof_mode = 1;                     // 1: every 4th frame, sums only; 2: every frame, per-frame records
@@ -288,7 +310,7 @@ struct ratsdf_engine {
   CandJob cand_job(const FrameIn& in, const FrameParams& P, unsigned par) const;
   int frame(const FrameIn& cur, const FrameIn* next, int H, int W, float md);
   int sticky();
-  int drain_profile();
+  int drain_profile(bool final = true);
   FrameParams base_params() const;
   struct Geom {
     unsigned n_vis_wg, parts, n_front_wg, n_cand_wg, grid;
@@ -330,6 +352,8 @@ int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
   delete copy_pool;
   copy_pool = nullptr;
+  for (auto& g : graphs) free_graph(g);
+  graphs.clear();
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h_stage) (void)hipHostFree(h_stage);
@@ -714,28 +738,32 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
 
   HIPCHK(hipGetLastError());
   pending = true;
-  if (profiling && prof_used >= (prof_mode == 2 ? 60000u : 4096u)) return drain_profile();
+  if (profiling && prof_used >= (prof_mode == 2 ? 60000u : 4096u)) return drain_profile(false);
   return RATSDF_OK;
 }
 
-int ratsdf_engine::drain_profile() {
+// `final`: nothing follows the timed frames (a read-out).  An intermediate drain in mode 2 (the event pool is
+// full) keeps the LAST pair for the next drain: its period ends at the start of a frame that has not been
+// launched yet, and prof_k_us / prof_period_us must stay index-aligned (ratsdf_profile_read_frames).
+int ratsdf_engine::drain_profile(bool final) {
   if (!prof_used) return RATSDF_OK;
   HIPCHK(hipStreamSynchronize(stream));
-  for (size_t i = 0; i < prof_used; ++i) {
+  const bool keep_last = prof_mode == 2 && !final && prof_used > 1;
+  const size_t n = keep_last ? prof_used - 1 : prof_used;
+  for (size_t i = 0; i < n; ++i) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, prof_events[i].first, prof_events[i].second));
     prof_ms += ms;
     ++prof_n;
     if (prof_mode == 2) {
       prof_k_us.push_back(ms * 1e3f);
-      if (i + 1 < prof_used) {  // consecutive frames: start of this frame's k_integrate to the next one's
-        float gap = 0;
-        HIPCHK(hipEventElapsedTime(&gap, prof_events[i].first, prof_events[i + 1].first));
-        prof_period_us.push_back(gap * 1e3f);
-      }
+      float gap = 0;  // consecutive frames: start of this frame's k_integrate to the next one's (last frame: 0)
+      if (i + 1 < prof_used) HIPCHK(hipEventElapsedTime(&gap, prof_events[i].first, prof_events[i + 1].first));
+      prof_period_us.push_back(gap * 1e3f);
     }
   }
-  prof_used = 0;
+  if (keep_last) std::swap(prof_events[0], prof_events[prof_used - 1]);
+  prof_used = keep_last ? 1 : 0;
   return RATSDF_OK;
 }
 
@@ -756,6 +784,98 @@ static bool finite_frame(const ratsdf_intrinsics& K, const ratsdf_pose& T, float
   for (float x : v)
     if (!std::isfinite(x)) return false;
   return true;
+}
+
+void ratsdf_engine::free_graph(BatchGraph& g) {
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  if (g.d_jobs) (void)hipFree(g.d_jobs);
+  for (int i = 0; i < 2; ++i) {
+    if (g.h_jobs[i]) (void)hipHostFree(g.h_jobs[i]);
+    if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
+  }
+  g = BatchGraph();
+}
+
+// The graph of an n-frame batch at H x W (built on first use, a few kept): k_cand_g for the first frame, then
+// k_front_g / k_integrate_g per frame with the look-ahead shares frame() would choose, one member (blockIdx.y = 0),
+// operands from d_eng and the graph's own job table.
+int ratsdf_engine::batch_graph(int n, int H, int W, BatchGraph** out) {
+  *out = nullptr;
+  for (auto& g : graphs)
+    if (g.H == H && g.W == W && g.n == n) {
+      g.last_use = ++graph_clock;
+      *out = &g;
+      return RATSDF_OK;
+    }
+  if (graphs.size() >= 6) {  // least recently used out
+    size_t victim = 0;
+    for (size_t i = 1; i < graphs.size(); ++i)
+      if (graphs[i].last_use < graphs[victim].last_use) victim = i;
+    HIPCHK(hipStreamSynchronize(stream));
+    free_graph(graphs[victim]);
+    graphs.erase(graphs.begin() + (long)victim);
+  }
+  BatchGraph g;
+  g.H = H;
+  g.W = W;
+  g.n = n;
+  auto fail = [&](const char* what) {
+    fprintf(stderr, "[ratsdf] batch graph %dx%d x %d: %s failed; batches of this shape are launched frame by frame\n",
+            W, H, n, what);
+    free_graph(g);
+    return RATSDF_ERR_DEVICE;
+  };
+  if (hipMalloc(&g.d_jobs, (size_t)n * sizeof(FrameJob)) != hipSuccess) return fail("hipMalloc");
+  for (int i = 0; i < 2; ++i)
+    if (hipHostMalloc(&g.h_jobs[i], (size_t)n * sizeof(FrameJob), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&g.ev[i], hipEventDisableTiming) != hipSuccess)
+      return fail("staging allocation");
+  const size_t npix = (size_t)H * W;
+  const int split = vpl == 1 ? 100 : (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
+  const Geom g1 = geometry(H, W, true, split, 0);
+  const Geom g0 = geometry(H, W, false, 0, 0);
+  const uint32_t n_serial_wg = 8u;
+  const uint32_t commit_rot = commit_rotation(g0.grid, g0.grid);
+  const uint32_t tail = (front_tail ? 1u : 0u) | front_prio;
+  EnginePtr engs = (EnginePtr)d_eng;
+  if (hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) != hipSuccess) return fail("hipStreamBeginCapture");
+  {
+    AheadGeom all = g0.a;
+    all.first_tile = 0;
+    all.n_tiles = g0.n_cand_wg * 4;
+    hipLaunchKernelGGL(k_cand_g, dim3(g0.n_cand_wg, 1), dim3(256), 0, stream, engs, (JobPtr)g.d_jobs, all);
+  }
+  for (int f = 0; f < n; ++f) {
+    const bool has_next = f + 1 < n;
+    const Geom& gg = has_next ? g1 : g0;
+    JobPtr cur = (JobPtr)(g.d_jobs + f);
+    JobPtr nxt = (JobPtr)(g.d_jobs + (has_next ? f + 1 : f));
+    hipLaunchKernelGGL(k_front_g, dim3(gg.n_front_wg, 1), dim3(256), 0, stream, engs, cur, nxt,
+                       (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, tail, gg.a);
+    const unsigned extra_c = ((gg.c.n_tiles + 3) / 4 + 7u) & ~7u;
+    switch (vpl) {
+      case 8:
+        hipLaunchKernelGGL(k_integrate_g<8>, dim3(gg.grid + n_serial_wg + extra_c, 1), dim3(RATSDF_INTEG_NT), 0, stream,
+                           engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg, (uint32_t)extra_c, commit_rot, gg.c);
+        break;
+      case 4:
+        hipLaunchKernelGGL(k_integrate_g<4>, dim3(gg.grid + n_serial_wg + extra_c, 1), dim3(RATSDF_INTEG_NT), 0, stream,
+                           engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg, (uint32_t)extra_c, commit_rot, gg.c);
+        break;
+      default:
+        hipLaunchKernelGGL(k_integrate_g<2>, dim3(gg.grid + n_serial_wg + extra_c, 1), dim3(RATSDF_INTEG_NT), 0, stream,
+                           engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg, (uint32_t)extra_c, commit_rot, gg.c);
+    }
+  }
+  const hipError_t launch_err = hipGetLastError();
+  if (hipStreamEndCapture(stream, &g.graph) != hipSuccess || launch_err != hipSuccess || !g.graph)
+    return fail("capture");
+  if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) return fail("hipGraphInstantiate");
+  g.last_use = ++graph_clock;
+  graphs.push_back(g);
+  *out = &graphs.back();
+  return RATSDF_OK;
 }
 
 // ================================== C ABI =====================================================
@@ -811,6 +931,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   if (const char* v = getenv("RATSDF_FRONT_TAIL")) e->front_tail = atoi(v) != 0;  // 0: the role always in k_integrate
   if (const char* v = getenv("RATSDF_FRONT_PRIO")) e->front_prio = atoi(v) ? 2u : 0u;
   if (const char* v = getenv("RATSDF_SYNC_INTEGRATE")) e->sync_integrate = atoi(v) != 0;
+  if (const char* v = getenv("RATSDF_GRAPH")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("RATSDF_SERIAL_LDS")) {
     const int x = atoi(v);
     if (x >= kSerialLdsBytes && x <= 160 * 1024) e->serial_lds = (unsigned)x;
@@ -962,6 +1083,45 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
     if (!ht || !lt) ht = lt = nullptr;
     return ratsdf_engine::FrameIn{d_rgb[i], d_depth[i], ht, lt, &K[i], &T[i]};
   };
+  // The captured form: one graph launch for the whole batch (not while individual launches carry profiling
+  // events, not for the 512-thread voxel-per-lane variant, not with the serial role as a launch of its own).
+  // (profiling, mode 1: every fourth batch is launched frame by frame and carries the events -- a sample of the
+  // same stream inside the same timed region; mode 2 times every frame: no graphs)
+  const bool sampled = e->profiling && (e->prof_mode == 2 || (e->prof_batch++ & 3u) == 0);
+  if (e->use_graphs && n >= 2 && !sampled && !e->cand_ready && e->fused_serial && e->vpl != 1 &&
+      (size_t)height * width * (size_t)e->S < 0xFFFFFFFFull) {
+    const size_t npix = (size_t)height * width;
+    int st = e->ensure_image(npix, npix * (size_t)e->S);
+    if (st != RATSDF_OK) return st;
+    ratsdf_engine::BatchGraph* g = nullptr;
+    if (e->batch_graph(n, height, width, &g) == RATSDF_OK && g) {
+      const unsigned turn = g->turn++ & 1u;
+      HIPCHK(hipEventSynchronize(g->ev[turn]));  // the copy that last used this staging table is done
+      FrameJob* hj = g->h_jobs[turn];
+      for (int i = 0; i < n; ++i) {
+        const ratsdf_engine::FrameIn in = input(i);
+        FrameJob& j = hj[i];
+        j.P = e->frame_params(in, height, width, max_depth);
+        j.depth = (const float*)in.depth;
+        j.rgb = (const uint8_t*)in.rgb;
+        j.ht = (const float*)in.ht;
+        j.lt = (const float*)in.lt;
+        j.par = (e->parity + (unsigned)i) & 1u;
+        j.pad = 0;
+      }
+      if (hipMemcpyAsync(g->d_jobs, hj, (size_t)n * sizeof(FrameJob), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+          hipEventRecord(g->ev[turn], e->stream) != hipSuccess)
+        return RATSDF_ERR_DEVICE;
+      if (hipGraphLaunch(g->exec, e->stream) != hipSuccess) {
+        e->abandon_pipeline();
+        return RATSDF_ERR_DEVICE;
+      }
+      e->parity = (e->parity + (unsigned)n) & 1u;
+      e->cand_ready = false;
+      e->pending = true;
+      return RATSDF_OK;
+    }
+  }
   for (int i = 0; i < n; ++i) {
     const ratsdf_engine::FrameIn cur = input(i);
     ratsdf_engine::FrameIn nxt{};

@@ -348,6 +348,11 @@ RgbImage decode_jpeg(const uint8_t* data, size_t size, const std::string& name) 
         hmax = std::max(hmax, k.h);
         vmax = std::max(vmax, k.v);
       }
+      // (hs = hmax / h below must be exact: with h = 3, hmax = 4 the upsampled row would be shorter than the
+      // image and the filters read past the plane -- stb_image 2.08 accepts such streams and over-reads too;
+      // no encoder writes them)
+      for (const auto& k : comp)
+        if (hmax % k.h != 0 || vmax % k.v != 0) fail("unsupported JPEG (sampling factors)");
       mcus_x = (width + 8 * hmax - 1) / (8 * hmax);
       mcus_y = (height + 8 * vmax - 1) / (8 * vmax);
       for (auto& c : comp) {

@@ -222,7 +222,11 @@ HostBlock HostBlockPool::acquire(size_t bytes) {
 void HostBlockPool::release(const HostBlock& b) {
   {
     std::lock_guard<std::mutex> lock(mtx_);
-    if (free_.size() < 128) {  // (640x480: 4.9 MB each)
+    // page-locked memory is not reclaimable: keep at most 256 MiB of it parked per TSDFSystem (52 blocks at
+    // 640x480, 17 at 1280x720 -- more than the two batches of kMaxBatch frames that are ever in flight)
+    size_t parked = 0;
+    for (const HostBlock& f : free_) parked += f.bytes;
+    if (parked + b.bytes <= ((size_t)256 << 20)) {
       free_.push_back(b);
       return;
     }

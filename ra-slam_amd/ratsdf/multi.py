@@ -145,6 +145,23 @@ class DirectoryDeltaExchange(DirectoryExchange):
         self.last_sent = (0, 0)
         self._last_counts = None
 
+    def _restart(self):
+        """Back to the state before the first exchange: the next one carries whole directories again (in
+        pool-sized buffers) and the replicas are rebuilt from it.  After a delta that did not fit, the
+        truncated entries are in nobody's replica and the sender's `_prev` has already moved past them: a
+        caller that catches the OverflowError and carries on gets consistent replicas from the next exchange
+        on instead of silently diverged ones.  Every rank takes this path together (they all see the same
+        counts), so the buffer sizes of the next collective agree."""
+        torch = self.torch
+        self._first = True
+        self._C = self.capacity
+        self.send = torch.zeros(2 + 3 * (self._C + 1), **self._i32)
+        self.recv2 = [torch.zeros(self.world * (2 + 3 * (self._C + 1)), **self._i32)]
+        self._slot = 0
+        self._todo = None
+        self._prev_key = torch.full_like(self._prev_key, 2 ** 62)
+        self._replica = [rep[:0] for rep in self._replica]
+
     def _pos_key(self, rows):
         """int64 key of the block position (x, y, z int16 in the first 6 bytes of an entry)."""
         i64 = self.torch.int64
@@ -209,6 +226,10 @@ class DirectoryDeltaExchange(DirectoryExchange):
                 if int(counts[r, 0]) + int(counts[r, 1]) > C]
         if over:   # every rank sees the same counts: every rank raises, nobody is left in a collective
             r, na, nd = over[0]
+            # the truncated entries are in nobody's replica and _make_delta has already moved on: the next
+            # exchange of a caller that catches the error resends the whole directory (every rank resets,
+            # because every rank is here)
+            self._restart()
             raise OverflowError(f"directory delta of rank {r}: {na} added + {nd} deleted entries, "
                                 f"delta_capacity is {C}")
         self.last_sent = (int(counts[self.rank, 0]), int(counts[self.rank, 1]))

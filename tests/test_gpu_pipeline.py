@@ -45,10 +45,15 @@ def check_totals(gpu, cpu):
     assert tg == tc, (tg, tc)
 
 
-@pytest.mark.parametrize("chunks", [(12,), (1, 2, 3, 6), (5, 7)])
-def test_batches_match_oracle(chunks, make_engine, make_oracle):
+@pytest.mark.parametrize("graph", ["1", "0"])
+@pytest.mark.parametrize("chunks", [(12,), (1, 2, 3, 6), (5, 7), (4, 4, 4)])
+def test_batches_match_oracle(chunks, graph, monkeypatch, make_engine, make_oracle):
+    """(graph = "1", the default: a batch of n >= 2 frames is ONE replay of a HIP graph captured for (image size,
+    n) -- (4, 4, 4) replays the same graph three times with different frames; "0": every frame launched by itself)"""
     vs, md = 0.02, 4.0
+    monkeypatch.setenv("RATSDF_GRAPH", graph)
     gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    monkeypatch.delenv("RATSDF_GRAPH")
     frames = synthetic.stream("room", sum(chunks), scale=0.25, noise=True, holes=True)
     dev = device_frames(frames)
     lo = 0
