@@ -512,7 +512,8 @@ def main():
     def exchange():
         if backend == "nccl":
             # engine stream -> (event) -> torch stream -> RCCL all-gather -> (event) -> engine stream
-            ex.fill_from_engine_device(eng)
+            # (first exchange: the whole directory; then the engine's own delta log: dirty entries + deleted positions)
+            ex.fill_from_engine(eng)
         else:
             ex.fill_from_numpy(eng.dump_directory()[1])
         ex.all_gather()

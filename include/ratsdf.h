@@ -291,6 +291,16 @@ int ratsdf_group_profile_read(ratsdf_group* g, double* integrate_ms, int64_t* la
 int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t capacity,
                                    void* d_count);
 
+/* The directory DELTA since the previous call ("RCCL ncclAllGather ... of the block directory delta"):
+ * entries added or changed first, then {position, offset 0, idx -1} per deleted position, into d_payload
+ * (`capacity` 12-byte entries); d_counts = int32[2] {added, deleted}, the TRUE numbers -- their sum exceeding
+ * `capacity`, or deleted == 0x7FFFFFFF (the engine's log of deleted positions overflowed), means the delta is
+ * unusable and the caller exports the whole directory instead.  A position deleted and inserted again since the
+ * previous call is in both lists: apply "drop, then add".  d_payload == NULL forgets the changes so far (call it
+ * after a whole-directory export).  Asynchronous on the engine's stream, touches no sticky error.  No reference
+ * counterpart; the oracle reports RATSDF_ERR_NOT_IMPLEMENTED. */
+int ratsdf_export_directory_delta_device(ratsdf_engine* e, void* d_payload, int32_t capacity, void* d_counts);
+
 /* ---- test / inspection hooks (mirror the reference's gtest kernels) ------------------------- */
 /* One allocation pass over an explicit list of block positions (3 x int16 each), request i having
  * raster rank i, followed by ResetLocks: the Allocate<<<>>> kernel + ResetLocks of

@@ -965,6 +965,7 @@ int ratsdf_oracle_stream(ratsdf_engine*, void** s) {
 
 int ratsdf_oracle_profile_enable(ratsdf_engine*, int) { return RATSDF_ERR_NOT_IMPLEMENTED; }
 int ratsdf_oracle_pipeline_counters(ratsdf_engine*, int64_t*, int) { return RATSDF_ERR_NOT_IMPLEMENTED; }
+int ratsdf_oracle_export_directory_delta_device(ratsdf_engine*, void*, int32_t, void*) { return RATSDF_ERR_NOT_IMPLEMENTED; }
 int ratsdf_oracle_profile_read(ratsdf_engine*, double*, int64_t*) {
   return RATSDF_ERR_NOT_IMPLEMENTED;
 }

@@ -192,6 +192,18 @@ struct Table {
   unsigned long long* occ;  // occupancy bitmap of the directory: bit e set <=> entries[e].idx >= 0
   uint32_t num_bucket, num_entry, bucket_mask, entry_mask;
   int32_t num_block;
+  // What changed since the last directory-delta export (ratsdf_export_directory_delta_device):
+  //   dirty    one bit per entry, in the words right behind the occupancy bitmap (occ[(num_entry >> 6) + (e >> 6)]:
+  //            no pointer of its own -- k_integrate has no scalar register to spare), set whenever a live block's
+  //            entry is written (commit, chain link edited, a chain element moved into its bucket's head by a
+  //            delete): the export lists those entries as they are THEN -- a position lives in one entry, so the
+  //            list has no duplicates whatever happened in between
+  //   del_log  positions deleted, appended when a frame's deletes are finalised (carve_release_role /
+  //            carve_finalize: one returning atomic per frame); a position deleted and inserted again is in both
+  //            lists, the receiver drops before it adds; duplicates are harmless
+  uint2* del_log;           // {x | y << 16, z}
+  uint32_t* del_count;      // entries appended (may exceed del_cap: counted, not stored -- the export says so)
+  uint32_t del_cap;
 };
 
 struct Pool {

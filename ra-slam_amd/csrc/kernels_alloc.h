@@ -90,6 +90,11 @@ __device__ inline bool entry_matches(const EntryWords& w, uint32_t k0, uint32_t 
 __device__ inline uint32_t key0(int x, int y) { return ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16); }
 __device__ inline uint32_t key1(int z) { return (uint32_t)z & 0xFFFFu; }
 
+// directory-delta bookkeeping (device_types.h: Table, "what changed since the last directory-delta export")
+__device__ inline void mark_dirty(const Table& t, uint32_t e) {
+  atomicOr(&t.occ[(t.num_entry >> 6) + (e >> 6)], 1ull << (e & 63));
+}
+
 // VoxelHashTable::GetBlock(pos, out), voxel_hash.cu:190-218.  Returns the entry index or kInf.
 __device__ inline uint32_t find_block(const Table& t, int x, int y, int z, EntryWords* out) {
   const uint32_t k0 = key0(x, y), k1 = key1(z);
@@ -640,6 +645,7 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
     const int16_t link = (int16_t)(next + wrap - last);
     __hip_atomic_store(&pl[1], (last_w1 & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
+    mark_dirty(tab, last);  // (the tail's entry has changed: its link)
   };
   // outcome of a request whose plan held: [1:0] 1 = fill the home slot, 2 = link the tail and fill `next`;
   // [2] clear the claim of the first bucket locked (home / tail), [3] of `next`'s; [63:32] request slot
@@ -1218,6 +1224,7 @@ __device__ inline bool commit_request(const Table& tab, const Pool& pool, const 
     }
     pe[2] = (uint32_t)idx;
     atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
+    mark_dirty(tab, e);
   }
   *out_idx = idx;
   *out_entry = e;

@@ -147,6 +147,7 @@ __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb,
       st_agent(pn + 1, nw.w1 & 0xFFFFu);
       st_agent(pn + 2, (uint32_t)-1);
       occ_clear(tab, nxt);  // the head keeps its bit unless it was its own successor
+      if (nxt != last) mark_dirty(tab, last);  // (the block that moved into the head: same position, new entry words)
     } else {                                                            // voxel_hash.cu:142-158
       for (uint32_t g = 0; g < tab.num_entry; ++g) {
         const EntryWords lw = load_entry(tab.entries, last);
@@ -160,6 +161,7 @@ __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb,
           uint32_t* pl = reinterpret_cast<uint32_t*>(tab.entries + last);
           uint32_t* pcur = reinterpret_cast<uint32_t*>(tab.entries + cur);
           st_agent(pl + 1, (lw.w1 & 0xFFFFu) | ((uint32_t)(uint16_t)link << 16));
+          mark_dirty(tab, last);  // (the predecessor's link has changed)
           freed = cw.idx;
           st_agent(pcur + 1, cw.w1 & 0xFFFFu);
           st_agent(pcur + 2, (uint32_t)-1);
@@ -246,6 +248,38 @@ __device__ inline GateResult carve_resolve_gate(const Table& tab, const CarveBuf
   return (GateResult)gate_state;
 }
 
+// The positions a finished frame deleted go to the directory-delta log (Table::del_log): every simple delete of
+// the frame's list and every head / chain delete that happened.  All threads of one workgroup; one returning
+// atomic for the lot.  `lds`: 2 words.
+__device__ inline void log_deleted_positions(const Table& tab, const CarveBufs& cb, uint32_t nd, uint32_t ns,
+                                             uint32_t* lds) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  if (tid == 0) lds[0] = 0;
+  __syncthreads();
+  uint32_t mine = 0;  // slow deletes of this thread that happened
+  for (uint32_t j = tid; j < ns; j += nt) mine += (ld_agent(reinterpret_cast<const uint32_t*>(&cb.slow[j]) + 1) >> 16) == 2u;
+  const uint32_t first = mine ? atomicAdd(&lds[0], mine) : 0u;
+  __syncthreads();
+  const uint32_t n_slow_done = lds[0];
+  if (tid == 0) lds[1] = nd + n_slow_done ? atomicAdd(tab.del_count, nd + n_slow_done) : 0u;
+  __syncthreads();
+  const uint32_t base = lds[1];
+  // (a simple delete leaves the block's position in its cleared entry -- carve_candidate rewrites the second and
+  // third word only -- and nothing can have filled that entry again: this runs before the next allocation pass
+  // commits anything)
+  for (uint32_t i = tid; i < nd; i += nt) {
+    const EntryWords ew = load_entry(tab.entries, cb.del[i].entry);
+    if (base + i < tab.del_cap) tab.del_log[base + i] = make_uint2(ew.w0, ew.w1 & 0xFFFFu);
+  }
+  uint32_t at = base + nd + first;
+  for (uint32_t j = tid; j < ns; j += nt) {
+    const SlowDelete sd = cb.slow[j];
+    if ((ld_agent(reinterpret_cast<const uint32_t*>(&cb.slow[j]) + 1) >> 16) != 2u) continue;
+    if (at < tab.del_cap) tab.del_log[at] = make_uint2(key0(sd.x, sd.y), key1(sd.z));
+    ++at;
+  }
+}
+
 // Pool releases of a finished frame with few deletes (the steady state), spread over kReleaseWGs
 // workgroups of the next k_front: ReleaseBlock in ascending entry order (voxel_mem.cu:56-60) means
 // delete w goes to heap[num_free + (number of deleted entries below its own)].  Every workgroup
@@ -256,7 +290,7 @@ __device__ inline GateResult carve_resolve_gate(const Table& tab, const CarveBuf
 constexpr uint32_t kReleaseWGs = 16;
 
 // `scratch`: 2 * kSmallCarve + 4 words of LDS, 16-byte aligned.
-__device__ inline void carve_release_role(const Pool& pool, const CarveBufs& cb, Ctl* ctl,
+__device__ inline void carve_release_role(const Table& tab, const Pool& pool, const CarveBufs& cb, Ctl* ctl,
                                           FrameCtl* Fp, uint32_t wg, uint32_t* scratch) {
   uint32_t* del_entry = scratch;
   int32_t* del_pool = reinterpret_cast<int32_t*>(scratch + kSmallCarve);
@@ -310,11 +344,21 @@ __device__ inline void carve_release_role(const Pool& pool, const CarveBufs& cb,
     // (write-through: the frame's serial role at the tail of the same launch pops these, front_tail_role)
     if (sub == 0 && item < n) st_agent(reinterpret_cast<uint32_t*>(&pool.heap[(uint32_t)nf + k]), (uint32_t)del_pool[item]);
   }
+  if (wg == 0) {  // uniform: the frame's deleted positions, for the directory delta
+    __syncthreads();
+    log_deleted_positions(tab, cb, nd, ns, scratch + 2 * kSmallCarve + 4);
+  }
 }
 
 // ReleaseBlock calls of a finished frame in ascending entry order + bookkeeping.  All threads of one
 // workgroup.  `scratch`: 2 * kSmallCarve + 80 words of LDS (16-byte aligned).  `nf` = free blocks before the releases.
 // Returns the number of blocks released (uniform).
+// kLog: the frame's deleted positions go to the directory-delta log from here (k_settle: no frame followed, so
+// no release role has logged them).  Inside a frame's launches (kLog false) the release role of k_front logs
+// them; only a frame with more deletes than that role takes leaves them unlogged, and then the log is marked
+// unusable (the next delta export reports an overflow and the caller takes a whole directory): the logging
+// code itself stays out of k_integrate, which has no register to spare.
+template <bool kLog = false>
 __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, const CarveBufs& cb,
                                           Ctl* ctl, FrameCtl* F, ratsdf_frame_stats* stats, int32_t nf,
                                           uint32_t* scratch) {
@@ -337,6 +381,8 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
   }
   if (tid == 0) lds[32] = 0;
   __syncthreads();
+  if (kLog) log_deleted_positions(tab, cb, nd, ns, lds + 40);
+  else if (nd + ns > kSmallCarve && tid == 0) atomicOr(tab.del_count, 0x80000000u);
   uint32_t n_del = 0;
   if (nd + ns <= kSmallCarve) {
     for (uint32_t i = tid; i < nd; i += nt) {
@@ -454,7 +500,7 @@ __global__ __launch_bounds__(1024) void k_settle(Table tab, Pool pool, CarveBufs
     __syncthreads();
   }
   const int32_t nf = ctl->num_free;
-  const uint32_t n_del = carve_finalize(tab, pool, cb, ctl, F, stats, nf, scratch);
+  const uint32_t n_del = carve_finalize<true>(tab, pool, cb, ctl, F, stats, nf, scratch);
   if (threadIdx.x == 0 && n_del) ctl->num_free = nf + (int32_t)n_del;
 }
 

@@ -292,6 +292,7 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
       pe[1] = w1;                                                       // offset 0
       pe[2] = (uint32_t)idx;
       atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
+      mark_dirty(tab, e);
       // Which of the 8 per-XCD lists: the image tile of the pixel that asked first (block_list_of projects the
       // block's centre -- ~100 vector instructions; placement only affects speed, any list is correct).
       // Approximate float arithmetic on purpose; the same on every run.
@@ -407,7 +408,7 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
   };
   if (blockIdx.x >= n_vis_wg + n_cons_wg) {
     if (!RATSDF_DBG(P, 12) && gate() != kGateExpired)  // diagnostic ablations 3 / 11 / 12: skip one role
-      carve_release_role(pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - n_cons_wg, role_lds);
+      carve_release_role(tab, pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - n_cons_wg, role_lds);
   } else if (blockIdx.x >= n_vis_wg) {
     if (!RATSDF_DBG(P, 11)) {
       const uint32_t c = blockIdx.x - n_vis_wg;

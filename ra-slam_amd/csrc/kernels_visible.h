@@ -254,6 +254,59 @@ __global__ void k_export_entries(const VisItem* sel, const uint32_t* n_sel, Entr
   }
 }
 
+// ---- directory delta ("RCCL all-gather of the block directory delta") ---------------------------
+// Entries written since the last export, as they are now: one lane per 64-entry word of the dirty bitmap (the
+// words behind the occupancy bitmap); the workgroup's live entries go to out[0 ..) behind one returning atomic
+// per workgroup; the word is cleared.  counts[0] = entries listed (the TRUE number even past `cap`: the caller
+// sees that the payload was too small).
+__global__ __launch_bounds__(kVisWG) void k_delta_added(Table tab, Entry* out, uint32_t cap, uint32_t* counts) {
+  __shared__ uint32_t wg_n, wg_base;
+  const uint32_t nwords = tab.num_entry >> 6;
+  const uint32_t w = blockIdx.x * kVisWG + threadIdx.x;
+  if (threadIdx.x == 0) wg_n = 0;
+  __syncthreads();
+  unsigned long long* dirty = tab.occ + nwords;
+  const unsigned long long m = w < nwords ? dirty[w] : 0ull;
+  if (m) dirty[w] = 0ull;
+  unsigned long long live = 0;  // dirty AND still holding a block
+  for (unsigned long long t = m; t; t &= t - 1) {
+    const int b = __ffsll((long long)t) - 1;
+    if (load_entry(tab.entries, w * 64 + (uint32_t)b).idx >= 0) live |= 1ull << b;
+  }
+  uint32_t pos = live ? atomicAdd(&wg_n, (uint32_t)__popcll(live)) : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) wg_base = wg_n ? atomicAdd(&counts[0], wg_n) : 0u;
+  __syncthreads();
+  pos += wg_base;
+  for (; live; live &= live - 1, ++pos) {
+    const EntryWords ew = load_entry(tab.entries, w * 64 + (uint32_t)(__ffsll((long long)live) - 1));
+    if (pos < cap) {
+      uint32_t* o = reinterpret_cast<uint32_t*>(out + pos);
+      o[0] = ew.w0;
+      o[1] = ew.w1;
+      o[2] = (uint32_t)ew.idx;
+    }
+  }
+}
+// Positions deleted since the last export, behind the added entries: out[counts[0] ..); counts[1] = their number
+// (0x7FFFFFFF when the log overflowed: the delta is unusable, the caller takes a whole directory).  Resets the log.
+__global__ __launch_bounds__(256) void k_delta_deleted(Table tab, Entry* out, uint32_t cap, uint32_t* counts) {
+  const uint32_t logged = *tab.del_count;
+  const uint32_t n = logged < tab.del_cap ? logged : tab.del_cap;
+  const uint32_t base = counts[0];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint2 d = tab.del_log[i];
+    if (base + i < cap) {
+      uint32_t* o = reinterpret_cast<uint32_t*>(out + base + i);
+      o[0] = d.x;
+      o[1] = d.y;  // offset 0
+      o[2] = (uint32_t)-1;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = logged > tab.del_cap ? 0x7FFFFFFFu : n;
+}
+__global__ void k_delta_reset(Table tab) { *tab.del_count = 0; }
+
 // raw voxel storage of listed pool blocks (test hook)
 __global__ void k_gather_voxels(Pool pool, const int32_t* pool_idx, int n, float* tsdf,
                                 uint32_t* rgbw, float* prob) {

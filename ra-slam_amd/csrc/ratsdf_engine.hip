@@ -341,7 +341,7 @@ FrameParams ratsdf_engine::base_params() const {
 
 int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
-  void* ptrs[] = {tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
+  void* ptrs[] = {tab.del_log, tab.del_count, tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
                   d_stats, d_eng, texA[0], texA[1], texB[0], texB[1], cand[0].list, cand[1].list, cand_count,
                   req, req_k, win_ranks, abitmap, asummary, aprefix,
                   slow, xlocks,
@@ -971,7 +971,13 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CREATE_CHK(hipMalloc(&t.entries, (size_t)t.num_entry * sizeof(Entry)));
   CREATE_CHK(hipMalloc(&t.claim, (size_t)t.num_bucket * 4));
-  CREATE_CHK(hipMalloc(&t.occ, (size_t)occ_words * 8));
+  // occupancy bitmap, and behind it the dirty bitmap of the directory delta (device_types.h: Table)
+  CREATE_CHK(hipMalloc(&t.occ, (size_t)occ_words * 8 * 2));
+  CREATE_CHK(hipMemsetAsync(t.occ + occ_words, 0, (size_t)occ_words * 8, e->stream));
+  t.del_cap = (uint32_t)t.num_block;
+  CREATE_CHK(hipMalloc(&t.del_log, (size_t)t.del_cap * sizeof(uint2)));
+  CREATE_CHK(hipMalloc(&t.del_count, 128));
+  CREATE_CHK(hipMemsetAsync(t.del_count, 0, 128, e->stream));
   CREATE_CHK(hipMalloc(&e->pool.rgbw, nvox * 4));
   CREATE_CHK(hipMalloc(&e->pool.tsdf, nvox * 4));
   CREATE_CHK(hipMalloc(&e->pool.segm, nvox * 4));
@@ -1882,6 +1888,35 @@ int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t cap
   if (st != RATSDF_OK) return st;
   hipLaunchKernelGGL(k_export_entries, dim3(256), dim3(256), 0, e->stream, e->vis, &e->ctl->n_sel,
                      (Entry*)d_blocks, (int32_t*)nullptr, (uint32_t)capacity, (int32_t*)d_count, e->ctl);
+  HIPCHK(hipGetLastError());
+  return RATSDF_OK;
+}
+
+// What the directory gained, changed and lost since the previous call (or since creation): the engine keeps a
+// dirty bit per entry and a log of deleted positions (device_types.h: Table::dirty / del_log), so the delta costs
+// two small kernels instead of a sort of the whole directory on the caller's side.  d_payload receives the
+// added / changed entries first, then one entry {position, offset 0, idx -1} per deleted position; d_counts
+// (int32[2]) the TRUE numbers of both -- more than `capacity` together means the payload was too small, and
+// 0x7FFFFFFF deleted positions that the log overflowed: either way the caller takes a whole directory
+// (ratsdf_export_directory_device) next.  A position deleted and inserted again is in both lists: drop, then add.
+// d_payload == NULL: forget the changes so far (after a whole-directory export).  Asynchronous on the engine's stream.
+int ratsdf_export_directory_delta_device(ratsdf_engine* e, void* d_payload, int32_t capacity, void* d_counts) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e || capacity < 0 || (d_payload && !d_counts)) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
+  const uint32_t occ_words = (e->tab.num_entry + 63) / 64;
+  if (!d_payload) {
+    HIPCHK(hipMemsetAsync(e->tab.occ + occ_words, 0, (size_t)occ_words * 8, e->stream));
+    HIPCHK(hipMemsetAsync(e->tab.del_count, 0, 4, e->stream));
+    return RATSDF_OK;
+  }
+  HIPCHK(hipMemsetAsync(d_counts, 0, 8, e->stream));
+  hipLaunchKernelGGL(k_delta_added, dim3(e->nwg), dim3(kVisWG), 0, e->stream, e->tab, (Entry*)d_payload,
+                     (uint32_t)capacity, (uint32_t*)d_counts);
+  hipLaunchKernelGGL(k_delta_deleted, dim3(64), dim3(256), 0, e->stream, e->tab, (Entry*)d_payload,
+                     (uint32_t)capacity, (uint32_t*)d_counts);
+  hipLaunchKernelGGL(k_delta_reset, dim3(1), dim3(1), 0, e->stream, e->tab);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }

@@ -71,7 +71,7 @@ SYMBOLS = [
     "profile_enable", "profile_read", "profile_read_frames", "totals", "pipeline_counters",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "raycast", "raycast_device", "gather_valid_mesh", "download_all_mesh",
-    "export_directory_device", "group_create", "group_destroy", "group_size",
+    "export_directory_device", "export_directory_delta_device", "group_create", "group_destroy", "group_size",
     "group_integrate_device_batch", "group_synchronize", "group_profile_enable", "group_profile_read",
     "test_allocate", "test_delete",
     "test_retrieve", "test_assign_rgbw", "dump_directory", "dump_voxels", "dump_heap",
@@ -132,6 +132,7 @@ class Library:
                                                  C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
         self.fn["download_all_mesh"].argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p]
         self.fn["export_directory_device"].argtypes = [vp, vp, C.c_int32, vp]
+        self.fn["export_directory_delta_device"].argtypes = [vp, vp, C.c_int32, vp]
         self.fn["group_create"].argtypes = [vp, C.c_int, C.POINTER(vp)]
         self.fn["group_destroy"].argtypes = [vp]
         self.fn["group_size"].argtypes = [vp, C.POINTER(C.c_int32)]
@@ -422,6 +423,11 @@ class Engine:
     def export_directory_device(self, d_blocks, capacity, d_count):
         _check(self.lib.fn["export_directory_device"](self._h, d_blocks, capacity, d_count),
                "export_directory_device")
+
+    def export_directory_delta_device(self, d_payload, capacity, d_counts):
+        """added / changed entries, then deleted positions, since the previous call; d_payload = 0: forget them"""
+        _check(self.lib.fn["export_directory_delta_device"](self._h, d_payload or None, capacity, d_counts or None),
+               "export_directory_delta_device")
 
     # -- test hooks ------------------------------------------------------------------------
     @staticmethod

@@ -171,6 +171,25 @@ class DirectoryDeltaExchange(DirectoryExchange):
         engine.export_directory_device(self.full.data_ptr(), self.capacity, self.full_count.data_ptr())
         self._engine_stream = self.torch.cuda.ExternalStream(engine.stream(), device=self.device)
 
+    def fill_delta_from_engine_device(self, engine):
+        """The engine's own record of what changed since the previous export (ratsdf_export_directory_delta_device:
+        a dirty bit per directory entry + a log of deleted positions) straight into the payload: two small kernels on
+        the engine's stream instead of a sort of the whole directory here (_make_delta).  Not for the first exchange
+        (`fill_from_engine` chooses)."""
+        body = self.send[2:]
+        engine.export_directory_delta_device(body.data_ptr(), self._C, self.send.data_ptr())
+        self._engine_stream = self.torch.cuda.ExternalStream(engine.stream(), device=self.device)
+        self._have_delta = True
+
+    def fill_from_engine(self, engine):
+        """What bench.py --gpus N calls once per step: the whole directory the first time (and after an overflow),
+        the engine's delta log from then on."""
+        if self._first:
+            self.fill_from_engine_device(engine)
+            engine.export_directory_delta_device(0, 0, 0)   # the whole directory is on its way: forget the changes so far
+        else:
+            self.fill_delta_from_engine_device(engine)
+
     def fill_from_numpy(self, blocks):
         n = len(blocks)
         if n > self.capacity:   # (cannot happen with the default capacity = the engine's pool)
@@ -256,7 +275,10 @@ class DirectoryDeltaExchange(DirectoryExchange):
             ev = torch.cuda.Event()
             ev.record(es)
             torch.cuda.current_stream(self.device).wait_event(ev)
-        self._make_delta()
+        if getattr(self, "_have_delta", False):   # the engine has written header and payload itself
+            self._have_delta = False
+        else:
+            self._make_delta()
         recv = self.recv2[self._slot % len(self.recv2)]
         self._slot += 1
         if self.world == 1:

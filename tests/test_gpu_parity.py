@@ -133,6 +133,46 @@ def test_directory_delta_exchange_on_the_device(make_engine):
     assert sent[0][0] == sent[0][1] and all(0 < d < 0.7 * n for d, n in sent[1:]), sent
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(bucket_bits=9, block_bits=14)])
+def test_directory_delta_from_the_engines_log(kw, make_engine):
+    """The delta the ENGINE keeps (a dirty bit per directory entry + a log of deleted positions,
+    ratsdf_export_directory_delta_device) instead of a diff of two sorted whole directories on the caller's side:
+    the replica built from those deltas is the engine's directory -- every field, chain links included -- at every
+    step, over batched frames (blocks allocated and carved within one interval, positions deleted and inserted
+    again) and, in the second case, on a 512-bucket directory where most insertions link chains and most deletes
+    unlink them."""
+    import torch
+    from ratsdf import multi
+    vs = 0.02
+    gpu = make_engine(vs, 6 * vs, **kw)
+    dx = multi.DirectoryDeltaExchange(engine=gpu, device=torch.device("cuda", 0), delta_capacity=8192)
+    frames = synthetic.stream("room", 16, scale=0.25, noise=True, holes=True)
+    frames = frames + frames[::-1][:8]
+    by_pos = lambda b: b[np.lexsort((b["z"], b["y"], b["x"]))]
+    sent = []
+    at = 0
+    for n in (2, 1, 5, 3, 4, 6, 3):
+        gpu.integrate_batch(frames[at:at + n], 4.0)
+        at += n
+        dx.fill_from_engine(gpu)
+        dx.all_gather()
+        _, blocks = gpu.dump_directory()
+        got = dx.result()[0]
+        assert len(got) == len(blocks), (at, len(got), len(blocks))
+        assert np.array_equal(by_pos(got), by_pos(blocks)), at
+        sent.append((sum(dx.last_sent), len(blocks)))
+    assert sent[0][0] == sent[0][1] and all(0 < d for d, _ in sent[1:]), sent
+    # the hooks that edit the directory outside a frame are seen too
+    pos = np.array([[40, 41, 42], [-7, 3, 9], [40, 41, 43]], dtype=np.int16)
+    gpu.test_allocate(pos)
+    gpu.test_delete(pos[:1])
+    dx.fill_from_engine(gpu)
+    dx.all_gather()
+    _, blocks = gpu.dump_directory()
+    assert np.array_equal(by_pos(dx.result()[0]), by_pos(blocks))
+    gpu.synchronize()
+
+
 def test_raycast_matches_oracle(make_engine, make_oracle):
     """TSDFGrid::RayCast / TSDFSystem::Render (voxel_tsdf.cu:278-374): rgba + normal images of a
     virtual view.  Voxel weights must reach 10 before a surface is rendered, so integrate enough
