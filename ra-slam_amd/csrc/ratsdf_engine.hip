@@ -2337,11 +2337,16 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
   EnginePtr engs = (EnginePtr)g->d_engs;
   const bool fused = e0->fused_serial && e0->vpl != 1;
   const uint32_t n_serial_wg = fused ? 8u : 0u;
-  const unsigned grid0 = e0->geometry(height, width, false, 0, 0).grid;
+  ratsdf_engine::Geom g1 = e0->geometry(height, width, true, e0->vpl == 1 ? 100 : g->split_a,
+                                        (fused || e0->vpl == 1) ? 0 : g->split_b);
+  ratsdf_engine::Geom g0 = e0->geometry(height, width, false, 0, 0);
+  // Several members at VGA-sized images: a member's slice of 1 536 update workgroups (two blocks each at 640x480 /
+  // 5 mm) instead of 4 096 -- a quarter of those are idle and still have to be dispatched, slice after slice
+  // (4 members, round 4: 46.3 k frames/s at 4 096, 47.1 k at 3 072, 48.0 k at 2 048, 48.9 k at 1 536 and 1 024;
+  // a single stream measures the same from 1 536 to 4 096)
+  if (!e0->grid_from_env && S >= 2 && g0.grid == 4096u) g0.grid = g1.grid = 1536u;
+  const unsigned grid0 = g0.grid;
   const uint32_t commit_rot = fused ? e0->commit_rotation(grid0, grid0 * (unsigned)S) : 0u;
-  const ratsdf_engine::Geom g1 = e0->geometry(height, width, true, e0->vpl == 1 ? 100 : g->split_a,
-                                              (fused || e0->vpl == 1) ? 0 : g->split_b);
-  const ratsdf_engine::Geom g0 = e0->geometry(height, width, false, 0, 0);
   {  // nobody looked ahead for the first frame: its candidate pass runs in line
     AheadGeom all = g0.a;
     all.first_tile = 0;
