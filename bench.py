@@ -118,8 +118,8 @@ def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", en
     return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src,
                 timed_launches=("every 4th frame of every 4th batch of the timed region is launched by itself with "
-                                "HIP events attached to the dispatch (k_integrate<2>); the other batches are HIP-graph "
-                                "replays of the same frames (k_integrate_g<2>, one member: the same body)"
+                                "HIP events attached to the dispatch (k_integrate<2, false>); the other batches are HIP-graph "
+                                "replays of the same frames (k_integrate_g<2, false>, one member: the same body)"
                                 if engines == 1 else "every 4th launch of the timed region carries HIP events"),
                 launch_also_hosts=("the frame's serial allocation-order role (workgroup 0; the commit of the "
                                    "frame's new blocks waits for it inside the launch)" +

@@ -297,9 +297,21 @@ int ratsdf_export_directory_device(ratsdf_engine* e, void* d_blocks, int32_t cap
  * `capacity`, or deleted == 0x7FFFFFFF (the engine's log of deleted positions overflowed), means the delta is
  * unusable and the caller exports the whole directory instead.  A position deleted and inserted again since the
  * previous call is in both lists: apply "drop, then add".  d_payload == NULL forgets the changes so far (call it
- * after a whole-directory export).  Asynchronous on the engine's stream, touches no sticky error.  No reference
+ * after a whole-directory export).  The engine starts keeping this record with the FIRST call (an engine nobody
+ * asks for deltas pays nothing for them): that call delivers no delta -- with a payload it reports deleted ==
+ * 0x7FFFFFFF.  Asynchronous on the engine's stream, touches no sticky error.  No reference
  * counterpart; the oracle reports RATSDF_ERR_NOT_IMPLEMENTED. */
 int ratsdf_export_directory_delta_device(ratsdf_engine* e, void* d_payload, int32_t capacity, void* d_counts);
+
+/* Blocks copied in from ANOTHER map (a neighbour rank's subvolume, SURVEY 8e: "so any rank can answer
+ * Query / ray-cast / mesh across subvolume seams"): inserts the n blocks (8^3 voxels each, x + 8y + 64z order)
+ * whatever the engine's shard filter says -- an existing block is overwritten -- so that consumers which read
+ * NEIGHBOUR blocks (marching cubes: voxel_tsdf.cu:582-620 reads the 2x2x2 block neighbourhood) find them.
+ * ratsdf_gather_valid_mesh of a sharded engine emits the cells of the blocks the engine OWNS only, so imported
+ * blocks are read, never meshed.  Meant for a scratch engine built for one export (ratsdf.multi.mesh_across_shards);
+ * frames integrated afterwards would update imported blocks like any other.  No reference counterpart. */
+int ratsdf_import_blocks(ratsdf_engine* e, int32_t n, const int16_t* block_pos, const float* tsdf,
+                         const ratsdf_rgbw* rgbw, const float* prob);
 
 /* ---- test / inspection hooks (mirror the reference's gtest kernels) ------------------------- */
 /* One allocation pass over an explicit list of block positions (3 x int16 each), request i having

@@ -717,9 +717,10 @@ struct ratsdf_engine {
     }
     static const int kAxis[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};  // corners 1, 4, 3
 
+    // (a sharded map meshes the blocks it owns; blocks imported from a neighbour's subvolume are only read)
     std::vector<Entry> blocks;
     for (uint32_t i = 0; i < num_entry; ++i)
-      if (table[i].idx >= 0) blocks.push_back(table[i]);
+      if (table[i].idx >= 0 && owned(table[i].pos)) blocks.push_back(table[i]);
     const size_t nb = blocks.size();
     const size_t VV = 729;  // BLOCK_VERT_VOLUME = 9^3
     std::vector<float> verts(nb * VV * 9), vprob(nb * VV * 3);
@@ -1150,6 +1151,27 @@ int ratsdf_oracle_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) 
     if (e->owned(p)) e->allocate(p);
   }
   e->reset_locks();
+  return e->sticky;
+}
+
+int ratsdf_oracle_import_blocks(ratsdf_engine* e, int32_t n, const int16_t* bp, const float* tsdf,
+                                const ratsdf_rgbw* rgbw, const float* prob) {
+  if (!e || n < 0 || (n > 0 && (!bp || !tsdf || !rgbw || !prob))) return RATSDF_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < n; ++i) {
+    const S3 p{bp[3 * i], bp[3 * i + 1], bp[3 * i + 2]};
+    Entry b;
+    e->get_block(p, &b);
+    for (int pass = 0; b.idx < 0 && pass < 4; ++pass) {  // (an insertion can lose its bucket's lock: next pass)
+      e->allocate(p);
+      e->reset_locks();
+      e->get_block(p, &b);
+    }
+    if (b.idx < 0) return e->sticky != RATSDF_OK ? e->sticky : RATSDF_ERR_CAPACITY;
+    const size_t base = (size_t)b.idx << 9;
+    memcpy(e->tsdf + base, tsdf + (size_t)i * 512, 512 * sizeof(float));
+    memcpy(e->rgbw + base, rgbw + (size_t)i * 512, 512 * sizeof(ratsdf_rgbw));
+    memcpy(e->segm + base, prob + (size_t)i * 512, 512 * sizeof(float));
+  }
   return e->sticky;
 }
 

@@ -204,6 +204,12 @@ struct Table {
   uint2* del_log;           // {x | y << 16, z}
   uint32_t* del_count;      // entries appended (may exceed del_cap: counted, not stored -- the export says so)
   uint32_t del_cap;
+  // Switches (uniform; same-box A/B, round 4: with both features compiled in unconditionally the frame took 27.2
+  // instead of 25.4 us): delta_on -- somebody consumes directory deltas (set by the first
+  // ratsdf_export_directory_delta_device call): dirty bits and the delete log are kept; tail_on -- the serial role
+  // may run at the tail of k_front (RATSDF_FRONT_TAIL=1): requests and heap pushes leave k_front's workgroups as
+  // write-through stores, the arrival counters are reset with the frame's other counters
+  uint32_t delta_on, tail_on;
 };
 
 struct Pool {

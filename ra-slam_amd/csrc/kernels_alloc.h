@@ -36,7 +36,7 @@ __device__ inline void set_error(Ctl* ctl, uint32_t code) {
   atomicCAS(&ctl->error, expect, value);
 }
 // one thread: the words of a FrameCtl that are in use
-__device__ inline void zero_frame_ctl(FrameCtl* F) {
+__device__ inline void zero_frame_ctl(FrameCtl* F, bool tail_on) {
   F->n_req = 0;
   F->n_slow = 0;
   F->n_win = 0;
@@ -50,14 +50,16 @@ __device__ inline void zero_frame_ctl(FrameCtl* F) {
   F->n_delcand = 0;
   F->n_slow_del = 0;
   F->slow_resolved = 0;
-  F->arrive_top = 0;
-  F->front_done = 0;
 #pragma unroll
   for (int l = 0; l < kNumLists; ++l) F->n_list[l * kListStride] = 0;
+  if (tail_on) {  // (uniform) the words only front_tail_role's frames use: 42 more lines
+    F->arrive_top = 0;
+    F->front_done = 0;
 #pragma unroll
-  for (uint32_t l = 0; l < kArriveSubs; ++l) F->arrive[l * kListStride] = 0;
+    for (uint32_t l = 0; l < kArriveSubs; ++l) F->arrive[l * kListStride] = 0;
 #pragma unroll
-  for (int l = 0; l < kNumLists; ++l) F->n_fresh[l] = 0;
+    for (int l = 0; l < kNumLists; ++l) F->n_fresh[l] = 0;
+  }
 }
 // visible blocks of a frame for the statistics: the blocks listed by the visible role + the frame's new blocks
 __device__ inline uint32_t frame_visible_blocks(const FrameCtl* F) {
@@ -92,7 +94,7 @@ __device__ inline uint32_t key1(int z) { return (uint32_t)z & 0xFFFFu; }
 
 // directory-delta bookkeeping (device_types.h: Table, "what changed since the last directory-delta export")
 __device__ inline void mark_dirty(const Table& t, uint32_t e) {
-  atomicOr(&t.occ[(t.num_entry >> 6) + (e >> 6)], 1ull << (e & 63));
+  if (t.delta_on) atomicOr(&t.occ[(t.num_entry >> 6) + (e >> 6)], 1ull << (e & 63));
 }
 
 // VoxelHashTable::GetBlock(pos, out), voxel_hash.cu:190-218.  Returns the entry index or kInf.
@@ -233,7 +235,8 @@ __device__ inline void alloc_request_absent_wave(bool want, const Table& t, int 
       if (in_lds) {
         B.item[slot] = r;
       } else if (slot < req_cap) {
-        st_agent_request(req + slot, r);
+        if (t.tail_on) st_agent_request(req + slot, r);
+        else req[slot] = r;
       } else {
         set_error(ctl, RATSDF_ERR_CAPACITY);
       }
@@ -250,7 +253,8 @@ __device__ inline void alloc_request_absent_wave(bool want, const Table& t, int 
 }
 
 // all threads of the workgroup: append the collected requests to the frame's list
-__device__ inline void req_buf_flush(ReqBuf& B, Request* req, uint32_t req_cap, Ctl* ctl, FrameCtl* F) {
+__device__ inline void req_buf_flush(ReqBuf& B, Request* req, uint32_t req_cap, Ctl* ctl, FrameCtl* F,
+                                     bool write_through) {
   __syncthreads();
   const uint32_t n = B.n < kReqBufCap ? B.n : kReqBufCap;
   if (n == 0) return;  // uniform
@@ -259,7 +263,8 @@ __device__ inline void req_buf_flush(ReqBuf& B, Request* req, uint32_t req_cap, 
   const uint32_t base = B.base;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     if (base + i < req_cap) {
-      st_agent_request(req + base + i, B.item[i]);
+      if (write_through) st_agent_request(req + base + i, B.item[i]);
+      else req[base + i] = B.item[i];
     } else {
       set_error(ctl, RATSDF_ERR_CAPACITY);
     }

@@ -370,7 +370,7 @@ __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P,
     alloc_request_absent_wave(want, tab, bx, by, bz, item.z, ea, eb, req, req_cap, slow, slow_cap, ctl,
                               F, B);
   }
-  req_buf_flush(B, req, req_cap, ctl, F);
+  req_buf_flush(B, req, req_cap, ctl, F, tab.tail_on != 0);
 }
 
 // stand-alone candidate pass (single frames, first frame of a batch)

@@ -254,6 +254,7 @@ __device__ inline GateResult carve_resolve_gate(const Table& tab, const CarveBuf
 __device__ inline void log_deleted_positions(const Table& tab, const CarveBufs& cb, uint32_t nd, uint32_t ns,
                                              uint32_t* lds) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  if (!tab.delta_on) return;  // uniform: nobody consumes deltas
   if (tid == 0) lds[0] = 0;
   __syncthreads();
   uint32_t mine = 0;  // slow deletes of this thread that happened
@@ -342,9 +343,12 @@ __device__ inline void carve_release_role(const Table& tab, const Pool& pool, co
     }
     k = dpp_sum16(k);  // over the 16 lanes that share the delete
     // (write-through: the frame's serial role at the tail of the same launch pops these, front_tail_role)
-    if (sub == 0 && item < n) st_agent(reinterpret_cast<uint32_t*>(&pool.heap[(uint32_t)nf + k]), (uint32_t)del_pool[item]);
+    if (sub == 0 && item < n) {
+      if (tab.tail_on) st_agent(reinterpret_cast<uint32_t*>(&pool.heap[(uint32_t)nf + k]), (uint32_t)del_pool[item]);
+      else pool.heap[(uint32_t)nf + k] = del_pool[item];
+    }
   }
-  if (wg == 0) {  // uniform: the frame's deleted positions, for the directory delta
+  if (wg == 0 && tab.delta_on) {  // uniform: the frame's deleted positions, for the directory delta
     __syncthreads();
     log_deleted_positions(tab, cb, nd, ns, scratch + 2 * kSmallCarve + 4);
   }
@@ -382,7 +386,7 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
   if (tid == 0) lds[32] = 0;
   __syncthreads();
   if (kLog) log_deleted_positions(tab, cb, nd, ns, lds + 40);
-  else if (nd + ns > kSmallCarve && tid == 0) atomicOr(tab.del_count, 0x80000000u);
+  else if (nd + ns > kSmallCarve && tid == 0 && tab.delta_on) atomicOr(tab.del_count, 0x80000000u);
   uint32_t n_del = 0;
   if (nd + ns <= kSmallCarve) {
     for (uint32_t i = tid; i < nd; i += nt) {
@@ -467,7 +471,7 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
       ctl->totals[4] += n_del;
     }
     // counters ready for the frame after next
-    zero_frame_ctl(F);
+    zero_frame_ctl(F, tab.tail_on != 0);
   }
   __syncthreads();
   return n_del;

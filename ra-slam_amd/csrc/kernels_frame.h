@@ -344,7 +344,7 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
         atomicAdd(&ctl->totals[3], (unsigned long long)p_win);
         atomicAdd(&ctl->totals[4], (unsigned long long)n_del);
       }
-      zero_frame_ctl(Fp);  // counters ready for the frame after next (every reader of this launch has reported)
+      zero_frame_ctl(Fp, true);  // counters ready for the frame after next (every reader of this launch has reported)
     }
     if ((int64_t)total > (int64_t)nf) set_error(ctl, RATSDF_ERR_POOL_EXHAUSTED);
     F->alloc_base = (uint32_t)nf;
@@ -371,7 +371,11 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
 // workgroups [.., +kReleaseWGs)          pool releases of the previous frame (carve_release_role)
 // workgroups beyond                      look-ahead candidate pass of the next frame (`ahead()`)
 // The directory workgroup that finishes last runs the frame's serial role (front_tail_role) when `tail`.
-template <typename Ahead>
+// kTail: the launch may run the frame's serial role at its tail (front_arrive / front_tail_role).  A template
+// parameter, not a run-time switch: with the tail's code in the kernel -- even unused -- its scalar-register
+// pressure spilled into the hosted candidate pass (864 instead of 140 v_readlane in the kernel; k_front 8.1 ->
+// 9.0 us at 640x480, 22.8 -> 24.4 us at 1280x720, same-box A/B against the round-3 build).
+template <bool kTail, typename Ahead>
 __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32_t n_vis_wg,
                                   const CandSet& cand, uint32_t cand_parts, Request* req,
                                   uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap, VisItem* vis,
@@ -393,7 +397,7 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
   // The launch's critical path runs in these workgroups -- chains of dependent round trips with a little
   // arithmetic in between -- while the look-ahead candidate workgroups it hosts keep the vector ALUs busy:
   // ask the instruction arbiter for priority over them.
-  if (tail & 2u) __builtin_amdgcn_s_setprio(3);
+  if (kTail && (tail & 2u)) __builtin_amdgcn_s_setprio(3);
 #ifdef RATSDF_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(&ctl->tstamps[0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -420,10 +424,13 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
   }
   // (a workgroup whose gate expired does not report: the directory may be half-edited, the tail must not
   // run on it -- the sticky error says the frame is incomplete)
-  if ((tail & 1u) && !expired && front_arrive(F, blockIdx.x, n_dir_wg, ctl))
-    front_tail_role(tab, P, cand, req, req_cap, vis, seg_cap, pool, cb, ctl, par, stats, role_lds);
+  if constexpr (kTail) {
+    if ((tail & 1u) && !expired && front_arrive(F, blockIdx.x, n_dir_wg, ctl))
+      front_tail_role(tab, P, cand, req, req_cap, vis, seg_cap, pool, cb, ctl, par, stats, role_lds);
+  }
 }
 
+template <bool kTail>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8))) void k_front(
     Table tab, FrameParams P, uint32_t n_vis_wg, CandSet cand, uint32_t cand_parts, Request* req,
     uint32_t req_cap,
@@ -431,11 +438,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     Ctl* ctl, uint32_t par, ratsdf_frame_stats* stats, uint32_t tail, CandJob ahead) {
   // one LDS buffer for whichever role the workgroup plays
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
-  front_body(tab, P, n_vis_wg, cand, cand_parts, req, req_cap, slow, slow_cap, vis, seg_cap, pool, cb,
-             ctl, par, stats, tail, [&]() { return ahead; }, role_lds);
+  front_body<kTail>(tab, P, n_vis_wg, cand, cand_parts, req, req_cap, slow, slow_cap, vis, seg_cap, pool, cb,
+                    ctl, par, stats, tail, [&]() { return ahead; }, role_lds);
 }
 
 // the same launch for several engines: engine blockIdx.y, operands from its record and its job
+template <bool kTail>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8))) void k_front_g(
     EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_vis_wg, uint32_t cand_parts, uint32_t tail, AheadGeom ag) {
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
   JobPtr J = cur + blockIdx.y;
   const uint32_t par = J->par;
   const RankBufs rb = ld_const(&E->rb);
-  front_body(ld_const(&E->tab), ld_const(&J->P), n_vis_wg, ld_const(&E->cand[par]), cand_parts, rb.req,
+  front_body<kTail>(ld_const(&E->tab), ld_const(&J->P), n_vis_wg, ld_const(&E->cand[par]), cand_parts, rb.req,
              rb.req_cap, E->slow, E->slow_cap, E->vis, E->seg_cap, ld_const(&E->pool),
              ld_const(&E->cb[par ^ 1u]), E->ctl, par, E->stats, tail,
              [&]() { return make_cand_job(E, nxt + blockIdx.y, ag); }, role_lds);
@@ -565,7 +573,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
         ctl->totals[3] = tot[3] + p_win;
         ctl->totals[4] = tot[4] + n_del;
       }
-      zero_frame_ctl(Fp);  // counters ready for the frame after next
+      zero_frame_ctl(Fp, tab.tail_on != 0);  // counters ready for the frame after next
     }
     uint32_t take = total;
     if ((int64_t)total > (int64_t)nf) {  // voxel_mem.cu:39 assert(idx >= 1)
@@ -634,10 +642,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_ca
 }
 
 // voxel update of several engines (kernels_integrate.h: integrate_body)
-template <int VPL>
+template <int VPL, bool kTail>
 __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate_g(
     EnginePtr engs, JobPtr cur, JobPtr nxt, uint32_t n_int_wg, uint32_t n_serial_wg, uint32_t n_ahead_wg,
     uint32_t commit_rot, AheadGeom ag) {
+  constexpr bool tail_on = kTail;
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[kIntegLdsWords];
   EnginePtr E = engs + blockIdx.y;
   JobPtr J = cur + blockIdx.y;

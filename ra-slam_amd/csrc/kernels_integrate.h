@@ -412,7 +412,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
         atomicAdd(&ctl->totals[3], (unsigned long long)p_win);
         atomicAdd(&ctl->totals[4], (unsigned long long)n_del);
       }
-      zero_frame_ctl(Fp);  // counters ready for the frame after next
+      zero_frame_ctl(Fp, tab.tail_on != 0);  // counters ready for the frame after next
     }
     uint32_t take = total;
     if ((int64_t)total > (int64_t)nf) {  // voxel_mem.cu:39 assert(idx >= 1)
@@ -439,7 +439,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
 __device__ __forceinline__ void serial_workgroup(EnginePtr E, uint32_t par, uint32_t nwords, uint32_t* lds,
                                                  bool withhold = false) {
   // (an ordinary frame: the role ran at the tail of k_front, kernels_frame.h: front_tail_role)
-  if (E->ctl->fr[par].front_done) return;  // uniform
+  if (E->tab.tail_on && E->ctl->fr[par].front_done) return;  // uniform
   // The frame's critical path runs in these four waves, each sharing its SIMD with seven waves of the voxel
   // update: ask the instruction arbiter for the highest wave priority.
   __builtin_amdgcn_s_setprio(3);
@@ -468,7 +468,7 @@ __device__ __forceinline__ void serial_helper(EnginePtr E, uint32_t par, uint32_
                                               bool withhold = false) {
   Ctl* ctl = E->ctl;
   FrameCtl* F = &ctl->fr[par];
-  if (F->front_done) return;  // uniform: no serial role in this launch (front_tail_role did the frame's)
+  if (E->tab.tail_on && F->front_done) return;  // uniform: no serial role in this launch (front_tail_role did the frame's)
   if (threadIdx.x == 0) {
     uint32_t v = 0;
     const unsigned long long t0 = (unsigned long long)wall_clock64();
@@ -919,10 +919,13 @@ struct IntegArgs {
 // Workgroups [0, n_int_wg) update voxel blocks; workgroups beyond host a share of the NEXT frame's
 // candidate pass (`ahead`, kernels_cand.h): the update is bound by memory latency and leaves the
 // vector ALUs mostly idle, the candidate pass is ALU work on other inputs.
-template <int VPL>
+// kTail: the engine's front-tail option (front_tail_role, kernels_frame.h) -- a template parameter so that the
+// default kernel carries none of that path (same-box A/B: +0.2 us at 640x480, +0.6 us at 1280x720 with it in).
+template <int VPL, bool kTail>
 __global__ __launch_bounds__(VPL == 1 ? 512 : RATSDF_INTEG_NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(VPL <= 2 ? 8 : (VPL == 4 ? 5 : 3)))) void k_integrate(
     IntegArgs A, FrameParams P, EnginePtr E, uint32_t n_int_wg, uint32_t n_serial_wg, uint32_t n_ahead_wg,
     uint32_t commit_rot, CandJob ahead) {
+  constexpr bool tail_on = kTail;
   __shared__ __attribute__((aligned(16))) uint32_t role_lds[kIntegLdsWords];
   // Grid: [n_serial_wg: 0, or 8 of which the first is the frame's serial role][n_ahead_wg look-ahead
   // workgroups of the next frame's candidate pass][n_int_wg update workgroups].  The first two groups

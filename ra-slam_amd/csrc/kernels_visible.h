@@ -16,7 +16,7 @@
 
 namespace ratsdf {
 
-enum SelectMode { kSelVisible = 0, kSelValid = 1, kSelBounds = 2 };
+enum SelectMode { kSelVisible = 0, kSelValid = 1, kSelBounds = 2, kSelOwned = 3 };
 
 struct GridBounds {  // BoundingCube<short>, voxel_tsdf.cuh:19-34
   int16_t xmin, xmax, ymin, ymax, zmin, zmax;
@@ -48,6 +48,8 @@ __device__ inline void select_flags_role(const Table& tab, const FrameParams& P,
       bool s;
       if (Mode == kSelVisible) {
         s = block_visible<false>(bx, by, bz, P);                            // voxel_tsdf.cu:98-109
+      } else if (Mode == kSelOwned) {
+        s = shard_owned(bx, P);  // (blocks imported from a neighbour's subvolume are read, not meshed)
       } else {
         const int gx = (int16_t)(bx << 3), gy = (int16_t)(by << 3), gz = (int16_t)(bz << 3);
         s = gx >= gb.xmin && gy >= gb.ymin && gz >= gb.zmin && gx + 8 - 1 <= gb.xmax &&
@@ -251,6 +253,30 @@ __global__ void k_export_entries(const VisItem* sel, const uint32_t* n_sel, Entr
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (out_count) *out_count = (int32_t)total;
     if (total > cap && ctl) set_error(ctl, RATSDF_ERR_CAPACITY);
+  }
+}
+
+// ratsdf_import_blocks: the voxels of block i of the list into the pool block its directory entry names; one wave
+// per block; blocks the directory does not hold are counted in *missing.
+__global__ __launch_bounds__(256) void k_import_voxels(Table tab, Pool pool, const int16_t* pos, int n,
+                                                       const float* tsdf, const uint32_t* rgbw, const float* prob,
+                                                       uint32_t* missing) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t b = wave; b < (uint32_t)n; b += nwaves) {
+    EntryWords w;
+    const uint32_t e = find_block(tab, pos[3 * b], pos[3 * b + 1], pos[3 * b + 2], &w);
+    if (e == kInf || w.idx < 0 || w.idx == kPlaceholderIdx) {
+      if (lane == 0) atomicAdd(missing, 1u);
+      continue;
+    }
+    const size_t dst = ((size_t)w.idx << 9) + lane * 8, src = ((size_t)b << 9) + lane * 8;
+    for (int i = 0; i < 8; ++i) {
+      pool.tsdf[dst + i] = tsdf[src + i];
+      pool.rgbw[dst + i] = rgbw[src + i];
+      pool.segm[dst + i] = prob[src + i];
+    }
   }
 }
 

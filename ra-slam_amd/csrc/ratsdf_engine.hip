@@ -550,6 +550,9 @@ int ratsdf_engine::select(int mode, const GridBounds& gb, uint32_t* count_slot) 
   if (mode == kSelValid)
     hipLaunchKernelGGL(k_select_flags<kSelValid>, dim3(nwg), dim3(kVisWG), 0, stream, tab, P, gb,
                        masks, wg_count);
+  else if (mode == kSelOwned)
+    hipLaunchKernelGGL(k_select_flags<kSelOwned>, dim3(nwg), dim3(kVisWG), 0, stream, tab, P, gb,
+                       masks, wg_count);
   else
     hipLaunchKernelGGL(k_select_flags<kSelBounds>, dim3(nwg), dim3(kVisWG), 0, stream, tab, P, gb,
                        masks, wg_count);
@@ -684,9 +687,14 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
   const bool fused = fused_serial && vpl != 1;
-  hipLaunchKernelGGL(k_front, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
-                     (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis + kFreshCap, seg_cap, pool, carve_bufs(par ^ 1u),
-                     ctl, (uint32_t)par, d_stats, (uint32_t)((fused && front_tail) ? 1u : 0u) | front_prio, ahead_a);
+  if (tab.tail_on)
+    hipLaunchKernelGGL(k_front<true>, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
+                       (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis + kFreshCap, seg_cap, pool,
+                       carve_bufs(par ^ 1u), ctl, (uint32_t)par, d_stats, 1u | front_prio, ahead_a);
+  else
+    hipLaunchKernelGGL(k_front<false>, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
+                       (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis + kFreshCap, seg_cap, pool,
+                       carve_bufs(par ^ 1u), ctl, (uint32_t)par, d_stats, 0u, ahead_a);
   if (!fused) {
     st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
     if (st != RATSDF_OK) return st;
@@ -724,15 +732,18 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   ia.F = &ctl->fr[par];
   ia.upd_wg = upd_wg[par];
   ia.par = par;
-#define RATSDF_LAUNCH_INTEGRATE(V, NT)                                                              \
-  hipExtLaunchKernelGGL(k_integrate<V>, dim3(integrate_grid + n_serial_wg + extra_c), dim3(NT), 0, \
-                        stream, ev0, ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid,    \
+#define RATSDF_LAUNCH_INTEGRATE(V, T, NT)                                                              \
+  hipExtLaunchKernelGGL((k_integrate<V, T>), dim3(integrate_grid + n_serial_wg + extra_c), dim3(NT), 0, \
+                        stream, ev0, ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid,         \
                         n_serial_wg, (uint32_t)extra_c, commit_rot, ahead_c)
+  // (the voxels-per-lane variants 1 / 4 / 8 are tuning options: without the front-tail path)
   switch (vpl) {
-    case 1: RATSDF_LAUNCH_INTEGRATE(1, 512); break;
-    case 8: RATSDF_LAUNCH_INTEGRATE(8, RATSDF_INTEG_NT); break;
-    case 4: RATSDF_LAUNCH_INTEGRATE(4, RATSDF_INTEG_NT); break;
-    default: RATSDF_LAUNCH_INTEGRATE(2, RATSDF_INTEG_NT);
+    case 1: RATSDF_LAUNCH_INTEGRATE(1, false, 512); break;
+    case 8: RATSDF_LAUNCH_INTEGRATE(8, false, RATSDF_INTEG_NT); break;
+    case 4: RATSDF_LAUNCH_INTEGRATE(4, false, RATSDF_INTEG_NT); break;
+    default:
+      if (tab.tail_on) RATSDF_LAUNCH_INTEGRATE(2, true, RATSDF_INTEG_NT);
+      else RATSDF_LAUNCH_INTEGRATE(2, false, RATSDF_INTEG_NT);
   }
 #undef RATSDF_LAUNCH_INTEGRATE
 
@@ -837,7 +848,7 @@ int ratsdf_engine::batch_graph(int n, int H, int W, BatchGraph** out) {
   const Geom g0 = geometry(H, W, false, 0, 0);
   const uint32_t n_serial_wg = 8u;
   const uint32_t commit_rot = commit_rotation(g0.grid, g0.grid);
-  const uint32_t tail = (front_tail ? 1u : 0u) | front_prio;
+  const uint32_t tail = (tab.tail_on ? 1u : 0u) | front_prio;
   EnginePtr engs = (EnginePtr)d_eng;
   if (hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) != hipSuccess) return fail("hipStreamBeginCapture");
   {
@@ -851,22 +862,24 @@ int ratsdf_engine::batch_graph(int n, int H, int W, BatchGraph** out) {
     const Geom& gg = has_next ? g1 : g0;
     JobPtr cur = (JobPtr)(g.d_jobs + f);
     JobPtr nxt = (JobPtr)(g.d_jobs + (has_next ? f + 1 : f));
-    hipLaunchKernelGGL(k_front_g, dim3(gg.n_front_wg, 1), dim3(256), 0, stream, engs, cur, nxt,
-                       (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, tail, gg.a);
+    if (tab.tail_on)
+      hipLaunchKernelGGL(k_front_g<true>, dim3(gg.n_front_wg, 1), dim3(256), 0, stream, engs, cur, nxt,
+                         (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, tail, gg.a);
+    else
+      hipLaunchKernelGGL(k_front_g<false>, dim3(gg.n_front_wg, 1), dim3(256), 0, stream, engs, cur, nxt,
+                         (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, 0u, gg.a);
     const unsigned extra_c = ((gg.c.n_tiles + 3) / 4 + 7u) & ~7u;
+#define RATSDF_GRAPH_INTEGRATE(V, T)                                                                                \
+  hipLaunchKernelGGL((k_integrate_g<V, T>), dim3(gg.grid + n_serial_wg + extra_c, 1), dim3(RATSDF_INTEG_NT), 0, stream, \
+                     engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg, (uint32_t)extra_c, commit_rot, gg.c)
     switch (vpl) {
-      case 8:
-        hipLaunchKernelGGL(k_integrate_g<8>, dim3(gg.grid + n_serial_wg + extra_c, 1), dim3(RATSDF_INTEG_NT), 0, stream,
-                           engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg, (uint32_t)extra_c, commit_rot, gg.c);
-        break;
-      case 4:
-        hipLaunchKernelGGL(k_integrate_g<4>, dim3(gg.grid + n_serial_wg + extra_c, 1), dim3(RATSDF_INTEG_NT), 0, stream,
-                           engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg, (uint32_t)extra_c, commit_rot, gg.c);
-        break;
+      case 8: RATSDF_GRAPH_INTEGRATE(8, false); break;
+      case 4: RATSDF_GRAPH_INTEGRATE(4, false); break;
       default:
-        hipLaunchKernelGGL(k_integrate_g<2>, dim3(gg.grid + n_serial_wg + extra_c, 1), dim3(RATSDF_INTEG_NT), 0, stream,
-                           engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg, (uint32_t)extra_c, commit_rot, gg.c);
+        if (tab.tail_on) RATSDF_GRAPH_INTEGRATE(2, true);
+        else RATSDF_GRAPH_INTEGRATE(2, false);
     }
+#undef RATSDF_GRAPH_INTEGRATE
   }
   const hipError_t launch_err = hipGetLastError();
   if (hipStreamEndCapture(stream, &g.graph) != hipSuccess || launch_err != hipSuccess || !g.graph)
@@ -948,6 +961,8 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
     }
   }
   Table& t = e->tab;
+  t.tail_on = (e->front_tail && e->fused_serial && e->vpl == 2) ? 1u : 0u;
+  t.delta_on = 0;
   t.num_block = 1 << bb;
   t.num_bucket = 1u << kb;
   t.num_entry = t.num_bucket << 1;
@@ -1777,7 +1792,8 @@ int ratsdf_gather_valid_mesh(ratsdf_engine* e, float** vertices, size_t* n_verti
   if (!e || !vertices || !n_vertices || !indices || !n_triangles || !vertex_prob)
     return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
-  int st = e->select(kSelValid, GridBounds{}, &e->ctl->n_sel);  // check_valid_kernel + GatherBlock
+  // check_valid_kernel + GatherBlock; a sharded map meshes the blocks it owns (imported neighbours are read only)
+  int st = e->select(e->shard_count > 1 ? kSelOwned : kSelValid, GridBounds{}, &e->ctl->n_sel);
   if (st != RATSDF_OK) return st;
   uint32_t nb = 0;
   HIPCHK(hipMemcpyAsync(&nb, &e->ctl->n_sel, 4, hipMemcpyDeviceToHost, e->stream));
@@ -1906,6 +1922,23 @@ int ratsdf_export_directory_delta_device(ratsdf_engine* e, void* d_payload, int3
   if (!e || capacity < 0 || (d_payload && !d_counts)) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   const uint32_t occ_words = (e->tab.num_entry + 63) / 64;
+  if (!e->tab.delta_on) {
+    // The first call starts the bookkeeping (an engine nobody asks for deltas keeps none: a dirty-bit atomic per
+    // commit and the delete log cost the frame 0.9 us).  Nothing has been recorded so far, so this call cannot
+    // deliver a delta: a payload call reports the overflow value and the caller takes a whole directory.
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->tab.delta_on = 1;
+    const int st1 = e->upload_record();
+    if (st1 != RATSDF_OK) return st1;
+    HIPCHK(hipMemsetAsync(e->tab.occ + occ_words, 0, (size_t)occ_words * 8, e->stream));
+    HIPCHK(hipMemsetAsync(e->tab.del_count, 0, 4, e->stream));
+    if (d_payload) {
+      const int32_t unusable[2] = {0, 0x7FFFFFFF};
+      HIPCHK(hipMemcpyAsync(d_counts, unusable, 8, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return RATSDF_OK;
+  }
   if (!d_payload) {
     HIPCHK(hipMemsetAsync(e->tab.occ + occ_words, 0, (size_t)occ_words * 8, e->stream));
     HIPCHK(hipMemsetAsync(e->tab.del_count, 0, 4, e->stream));
@@ -1954,6 +1987,60 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   const int st2 = e->sticky();
   (void)hipFree(d);
   return st != RATSDF_OK ? st : st2;
+}
+
+int ratsdf_import_blocks(ratsdf_engine* e, int32_t n, const int16_t* bp, const float* tsdf, const ratsdf_rgbw* rgbw,
+                         const float* prob) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e || n < 0 || (n > 0 && (!bp || !tsdf || !rgbw || !prob))) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
+  if (n == 0) return e->sticky();
+  int st = e->ensure_image(0, (size_t)n);
+  if (st != RATSDF_OK) return st;
+  int16_t* d_pos = nullptr;
+  uint8_t* d_vox = nullptr;
+  uint32_t* d_missing = nullptr;
+  const size_t per = (size_t)n * 512 * 4;
+  st = upload_s3(e, bp, n, &d_pos);
+  if (st != RATSDF_OK) return st;
+  auto cleanup = [&](int status) {
+    (void)hipStreamSynchronize(e->stream);
+    if (d_pos) (void)hipFree(d_pos);
+    if (d_vox) (void)hipFree(d_vox);
+    if (d_missing) (void)hipFree(d_missing);
+    return status;
+  };
+  if (hipMalloc(&d_vox, per * 3) != hipSuccess || hipMalloc(&d_missing, 4) != hipSuccess) return cleanup(RATSDF_ERR_DEVICE);
+  if (hipMemcpyAsync(d_vox, tsdf, per, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+      hipMemcpyAsync(d_vox + per, rgbw, per, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+      hipMemcpyAsync(d_vox + 2 * per, prob, per, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+    return cleanup(RATSDF_ERR_DEVICE);
+  FrameParams P = e->base_params();
+  P.shard_count = 1;  // whatever the engine's shard filter says
+  uint32_t missing = (uint32_t)n;
+  // an insertion can lose its bucket to another one of the same pass (one per bucket and pass,
+  // voxel_hash.cu:67-78): allocate, copy, and go again for whatever the directory still lacks
+  for (int pass = 0; pass < 8 && missing != 0; ++pass) {
+    const uint32_t par = e->parity;
+    hipLaunchKernelGGL(k_alloc_list, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->tab, P, d_pos, n, e->req,
+                       e->req_cap, e->slow, kSlowCap, e->ctl, par);
+    st = e->alloc_rank((uint32_t)n, par);
+    if (st != RATSDF_OK) return cleanup(st);
+    hipLaunchKernelGGL(k_commit_only, dim3(256), dim3(256), 0, e->stream, e->tab, e->pool, e->req, e->req_cap,
+                       e->req_k, e->win_ranks, e->ctl, par);
+    hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, e->stream, e->tab, e->pool, e->carve_bufs(par), e->ctl, par,
+                       (ratsdf_frame_stats*)nullptr);
+    if (hipMemsetAsync(d_missing, 0, 4, e->stream) != hipSuccess) return cleanup(RATSDF_ERR_DEVICE);
+    hipLaunchKernelGGL(k_import_voxels, dim3((n + 3) / 4), dim3(256), 0, e->stream, e->tab, e->pool, d_pos, n,
+                       (const float*)d_vox, (const uint32_t*)(d_vox + per), (const float*)(d_vox + 2 * per), d_missing);
+    if (hipMemcpyAsync(&missing, d_missing, 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+      return cleanup(RATSDF_ERR_DEVICE);
+  }
+  st = e->sticky();
+  if (st == RATSDF_OK && missing != 0) st = RATSDF_ERR_CAPACITY;
+  return cleanup(st);
 }
 
 int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {
@@ -2393,8 +2480,12 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
     const ratsdf_engine::Geom& gg = has_next ? g1 : g0;
     JobPtr cur = (JobPtr)(g->d_jobs + (size_t)f * S);
     JobPtr nxt = (JobPtr)(g->d_jobs + (size_t)(has_next ? f + 1 : f) * S);
-    hipLaunchKernelGGL(k_front_g, dim3(gg.n_front_wg, S), dim3(256), 0, g->stream, engs, cur, nxt,
-                       (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, (uint32_t)((fused && e0->front_tail) ? 1u : 0u) | e0->front_prio, gg.a);
+    if (e0->tab.tail_on)
+      hipLaunchKernelGGL(k_front_g<true>, dim3(gg.n_front_wg, S), dim3(256), 0, g->stream, engs, cur, nxt,
+                         (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, 1u | e0->front_prio, gg.a);
+    else
+      hipLaunchKernelGGL(k_front_g<false>, dim3(gg.n_front_wg, S), dim3(256), 0, g->stream, engs, cur, nxt,
+                         (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, 0u, gg.a);
     if (!fused) {
       const unsigned extra_b = gg.b.n_tiles ? (gg.b.n_tiles + gg.b.tiles_per_wg - 1) / gg.b.tiles_per_wg : 0;
       hipLaunchKernelGGL(k_alloc_rank_g, dim3(1 + extra_b, S), dim3(1024), kSerialLdsBytes, g->stream,
@@ -2407,15 +2498,17 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
       ++g->prof_used;
     }
     const unsigned extra_c = ((gg.c.n_tiles + 3) / 4 + 7u) & ~7u;
-#define RATSDF_LAUNCH_INTEGRATE_G(V, NT)                                                            \
-  hipExtLaunchKernelGGL(k_integrate_g<V>, dim3(gg.grid + n_serial_wg + extra_c, S), dim3(NT), 0,    \
-                        g->stream, ev0, ev1, 0, engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg,     \
+#define RATSDF_LAUNCH_INTEGRATE_G(V, T, NT)                                                            \
+  hipExtLaunchKernelGGL((k_integrate_g<V, T>), dim3(gg.grid + n_serial_wg + extra_c, S), dim3(NT), 0,  \
+                        g->stream, ev0, ev1, 0, engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg,        \
                         (uint32_t)extra_c, commit_rot, gg.c)
     switch (e0->vpl) {
-      case 1: RATSDF_LAUNCH_INTEGRATE_G(1, 512); break;
-      case 8: RATSDF_LAUNCH_INTEGRATE_G(8, RATSDF_INTEG_NT); break;
-      case 4: RATSDF_LAUNCH_INTEGRATE_G(4, RATSDF_INTEG_NT); break;
-      default: RATSDF_LAUNCH_INTEGRATE_G(2, RATSDF_INTEG_NT);
+      case 1: RATSDF_LAUNCH_INTEGRATE_G(1, false, 512); break;
+      case 8: RATSDF_LAUNCH_INTEGRATE_G(8, false, RATSDF_INTEG_NT); break;
+      case 4: RATSDF_LAUNCH_INTEGRATE_G(4, false, RATSDF_INTEG_NT); break;
+      default:
+        if (e0->tab.tail_on) RATSDF_LAUNCH_INTEGRATE_G(2, true, RATSDF_INTEG_NT);
+        else RATSDF_LAUNCH_INTEGRATE_G(2, false, RATSDF_INTEG_NT);
     }
 #undef RATSDF_LAUNCH_INTEGRATE_G
     if (hipGetLastError() != hipSuccess) {  // a launch of this frame was refused

@@ -71,7 +71,7 @@ SYMBOLS = [
     "profile_enable", "profile_read", "profile_read_frames", "totals", "pipeline_counters",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "raycast", "raycast_device", "gather_valid_mesh", "download_all_mesh",
-    "export_directory_device", "export_directory_delta_device", "group_create", "group_destroy", "group_size",
+    "export_directory_device", "export_directory_delta_device", "import_blocks", "group_create", "group_destroy", "group_size",
     "group_integrate_device_batch", "group_synchronize", "group_profile_enable", "group_profile_read",
     "test_allocate", "test_delete",
     "test_retrieve", "test_assign_rgbw", "dump_directory", "dump_voxels", "dump_heap",
@@ -91,8 +91,16 @@ class Library:
         self.prefix = prefix
         self.dll = C.CDLL(self.path)
         self.fn = {}
+        import os
         for s in SYMBOLS:
-            self.fn[s] = getattr(self.dll, prefix + s)  # AttributeError = missing export
+            try:
+                self.fn[s] = getattr(self.dll, prefix + s)  # AttributeError = missing export
+            except AttributeError:
+                # (same-box A/B against engine builds of earlier commits, tools/build_variant.sh: entry points
+                # added since are simply absent there; never set for the product library)
+                if os.environ.get("RATSDF_LIB_VARIANT") != "1":
+                    raise
+                self.fn[s] = C.CFUNCTYPE(C.c_int)(lambda *a: 6)
         for s in SYMBOLS:
             self.fn[s].restype = C.c_int
         self.fn["status_string"].restype = C.c_char_p
@@ -133,6 +141,7 @@ class Library:
         self.fn["download_all_mesh"].argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p]
         self.fn["export_directory_device"].argtypes = [vp, vp, C.c_int32, vp]
         self.fn["export_directory_delta_device"].argtypes = [vp, vp, C.c_int32, vp]
+        self.fn["import_blocks"].argtypes = [vp, C.c_int32, vp, vp, vp, vp]
         self.fn["group_create"].argtypes = [vp, C.c_int, C.POINTER(vp)]
         self.fn["group_destroy"].argtypes = [vp]
         self.fn["group_size"].argtypes = [vp, C.POINTER(C.c_int32)]
@@ -428,6 +437,16 @@ class Engine:
         """added / changed entries, then deleted positions, since the previous call; d_payload = 0: forget them"""
         _check(self.lib.fn["export_directory_delta_device"](self._h, d_payload or None, capacity, d_counts or None),
                "export_directory_delta_device")
+
+    def import_blocks(self, block_pos, tsdf, rgbw, prob):
+        """blocks copied in from another map (a neighbour rank's subvolume): positions [n, 3] int16 and the three
+        voxel arrays [n, 512] in dump_voxels()'s layout; inserted whatever the shard filter says"""
+        a, n = self._s3(block_pos)
+        t = np.ascontiguousarray(tsdf, dtype=np.float32).reshape(n, BLOCK_VOLUME)
+        c = np.ascontiguousarray(rgbw, dtype=RGBW_DTYPE).reshape(n, BLOCK_VOLUME)
+        p = np.ascontiguousarray(prob, dtype=np.float32).reshape(n, BLOCK_VOLUME)
+        _check(self.lib.fn["import_blocks"](self._h, n, a.ctypes.data, t.ctypes.data, c.ctypes.data, p.ctypes.data),
+               "import_blocks")
 
     # -- test hooks ------------------------------------------------------------------------
     @staticmethod

@@ -400,3 +400,120 @@ def check_sharded_directories(per_rank, slab_bits=2):
                 raise AssertionError(f"block {p} present on two ranks")
             seen.add(p)
     return len(seen)
+
+
+# ---- consumers that read NEIGHBOUR blocks, across subvolume seams ------------------------------------------------
+def _pos_set(blocks):
+    return set(zip(blocks["x"].tolist(), blocks["y"].tolist(), blocks["z"].tolist()))
+
+
+def halo_plan(per_rank):
+    """Which blocks every rank needs from every other rank to mesh its own subvolume.
+
+    Marching cubes on block B reads B + {0, 1}^3 (GatherValidMesh, voxel_tsdf.cu:582-620: the 2x2x2 block
+    neighbourhood behind the 16^3 tile).  Ownership is by x-slab, so a neighbour that belongs to someone else has
+    x + 1: rank r needs every block (x + 1, y + dy, z + dz), dy, dz in {0, 1}, of its own blocks (x, y, z) that
+    exists in another rank's directory.  Computed from the replicated directories alone, hence the same on every
+    rank: nobody has to ask.  Returns plan[q][r] = sorted list of positions rank q sends to rank r."""
+    world = len(per_rank)
+    sets = [_pos_set(b) for b in per_rank]
+    plan = [[[] for _ in range(world)] for _ in range(world)]
+    for r in range(world):
+        want = set()
+        for (x, y, z) in sets[r]:
+            for dy in (0, 1):
+                for dz in (0, 1):
+                    want.add((x + 1, y + dy, z + dz))
+        want -= sets[r]
+        for q in range(world):
+            if q != r:
+                plan[q][r] = sorted(want & sets[q])
+    return plan
+
+
+def export_blocks(engine, positions):
+    """(positions [n, 3] int16, tsdf, rgbw, prob [n, 512]) of the listed blocks of this engine's map"""
+    from ._abi import RGBW_DTYPE
+    _, blocks = engine.dump_directory()
+    idx_of = {(int(x), int(y), int(z)): int(i) for x, y, z, i in zip(blocks["x"], blocks["y"], blocks["z"], blocks["idx"])}
+    pos = np.array(positions, dtype=np.int16).reshape(-1, 3)
+    if len(pos) == 0:
+        return (pos, np.zeros((0, 512), np.float32), np.zeros((0, 512), RGBW_DTYPE), np.zeros((0, 512), np.float32))
+    t, c, p = engine.dump_voxels(np.array([idx_of[tuple(int(v) for v in q)] for q in pos], dtype=np.int32))
+    return pos, t, c, p
+
+
+def mesh_with_halo(engine, scratch, halo):
+    """The mesh of the blocks `engine` owns, with the cells on its subvolume's +x seam closed: `scratch` (a fresh
+    engine with the same voxel size and shard parameters) receives the engine's own blocks and the neighbours'
+    blocks `halo` (an export_blocks() tuple) through ratsdf_import_blocks and is meshed -- a sharded engine meshes
+    only what it owns, so every cell of the whole map is emitted by exactly one rank (the owner of the block that
+    holds the cell's minimum corner), and the map itself is not touched."""
+    _, blocks = engine.dump_directory()
+    own = export_blocks(engine, np.stack([blocks["x"], blocks["y"], blocks["z"]], axis=1))
+    for part in (own, halo):
+        for lo in range(0, len(part[0]), 4096):
+            scratch.import_blocks(part[0][lo:lo + 4096], part[1][lo:lo + 4096], part[2][lo:lo + 4096],
+                                  part[3][lo:lo + 4096])
+    return scratch.gather_valid_mesh()
+
+
+def mesh_across_shards(engine, make_scratch, per_rank):
+    """TSDFSystem::DownloadAllMesh (tsdf_module.cc:66-86) of a map that is spread over ranks by block ownership:
+    halo exchange (one all-gather of the seam blocks' voxel data, 6 KiB per block), per-rank meshing with the
+    seam closed, one all-gather of the meshes.  `per_rank` = the replicated directories
+    (DirectoryExchange.result()); `make_scratch()` builds an empty engine like `engine`.  Returns (vertices [n, 3],
+    triangles [m, 3], vertex probability [n]) of the whole map on every rank; as a multiset of triangles it is the
+    mesh of the same map held by one engine."""
+    import torch
+    import torch.distributed as dist
+    from ._abi import RGBW_DTYPE
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    plan = halo_plan(per_rank)
+    # what I send to anybody, once; everybody knows everybody's list, so the buffers have agreed sizes
+    out_lists = [sorted(set(p for r in range(world) for p in plan[q][r])) for q in range(world)]
+    nmax = max(1, max(len(l) for l in out_lists))
+    pos, t, c, p = export_blocks(engine, out_lists[rank])
+    send = torch.zeros((nmax, 3 * 512), dtype=torch.int32)
+    if len(pos):
+        send[:len(pos), 0:512] = torch.from_numpy(t.view(np.int32))
+        send[:len(pos), 512:1024] = torch.from_numpy(np.ascontiguousarray(c).view(np.int32).reshape(-1, 512))
+        send[:len(pos), 1024:1536] = torch.from_numpy(p.view(np.int32))
+    if world > 1:
+        recv = [torch.zeros_like(send) for _ in range(world)]
+        dist.all_gather(recv, send)
+    else:
+        recv = [send]
+    hp, ht, hc, hprob = [], [], [], []
+    for q in range(world):
+        if q == rank or not plan[q][rank]:
+            continue
+        row_of = {pp: i for i, pp in enumerate(out_lists[q])}
+        rows = np.array([row_of[pp] for pp in plan[q][rank]], dtype=np.int64)
+        data = recv[q].numpy()[rows]
+        hp.append(np.array(plan[q][rank], dtype=np.int16))
+        ht.append(data[:, 0:512].copy().view(np.float32))
+        hc.append(data[:, 512:1024].copy().view(RGBW_DTYPE).reshape(-1, 512))
+        hprob.append(data[:, 1024:1536].copy().view(np.float32))
+    if hp:
+        halo = (np.concatenate(hp), np.concatenate(ht), np.concatenate(hc), np.concatenate(hprob))
+    else:
+        halo = (np.zeros((0, 3), np.int16), np.zeros((0, 512), np.float32), np.zeros((0, 512), RGBW_DTYPE),
+                np.zeros((0, 512), np.float32))
+    scratch = make_scratch()
+    try:
+        v, tri, vp = mesh_with_halo(engine, scratch, halo)
+    finally:
+        scratch.close()
+    if world == 1:
+        return v, tri, vp
+    parts = [None] * world
+    dist.all_gather_object(parts, (v, tri, vp))
+    off, vs_, ts_, ps_ = 0, [], [], []
+    for (vv, tt, pp) in parts:
+        vs_.append(vv)
+        ts_.append(tt + off)
+        ps_.append(pp)
+        off += len(vv)
+    return np.concatenate(vs_), np.concatenate(ts_), np.concatenate(ps_)

@@ -32,7 +32,9 @@ def test_kernels_do_not_spill_and_keep_their_occupancy():
     assert len(k) > 20
     for name, res in k.items():
         assert res.get("ScratchSize", 0) == 0, f"{name} uses scratch memory: {res}"
+    # k_integrate<2, false> (the default) and <2, true> (with the front-tail path, RATSDF_FRONT_TAIL=1)
     integrate2 = [v for n, v in k.items() if "k_integrateILi2E" in n]
-    assert len(integrate2) == 1 and integrate2[0]["VGPRs"] <= 64 and integrate2[0]["Occupancy"] == 8
-    front = [v for n, v in k.items() if "7k_front" in n]
-    assert len(front) == 1 and front[0]["Occupancy"] == 8 and front[0]["LDS"] <= 20 * 1024
+    assert len(integrate2) == 2 and all(v["VGPRs"] <= 64 and v["Occupancy"] == 8 for v in integrate2)
+    # k_front<false> (the default) and k_front<true> (serial role at the launch's tail, RATSDF_FRONT_TAIL=1)
+    front = [v for n, v in k.items() if "7k_frontILb" in n]
+    assert len(front) == 2 and all(f["Occupancy"] == 8 and f["LDS"] <= 20 * 1024 for f in front)

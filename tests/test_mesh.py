@@ -81,3 +81,63 @@ def test_engine_mesh_matches_oracle(scene, make_engine, make_oracle):
     assert np.max(np.abs(gp - cp), initial=0) <= 1e-4
     v0, t0, p0 = make_engine(vs, 6 * vs).gather_valid_mesh()
     assert len(v0) == 0 and len(t0) == 0
+
+
+def _tri_rows(v, t, p):
+    a = np.concatenate([v[t].reshape(-1, 9), p[t].reshape(-1, 3)], axis=1)
+    return a[np.lexsort(a.T[::-1])]
+
+
+@pytest.mark.gpu
+def test_mesh_across_shard_seams_on_the_hip_engine(make_engine, make_oracle):
+    """Two HIP engines hold the two subvolumes of one stream (block ownership by x-slab); each meshes a scratch
+    copy of its own blocks plus the neighbour's seam blocks (ratsdf_import_blocks; a sharded engine meshes only
+    what it owns): together, triangle for triangle, the mesh of the same stream held by ONE engine -- HIP and
+    oracle.  (The two-rank form of the same thing over gloo: tests/test_multi_gloo.py.)"""
+    from ratsdf import multi
+    vs = 0.02
+    kw = [dict(shard_rank=r, shard_count=2, shard_slab_bits=1) for r in range(2)]
+    one, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=4)
+    sh = [make_engine(vs, 6 * vs, **k) for k in kw]
+    frames = [synthetic.frame("room", 0, scale=0.25) for _ in range(12)] + synthetic.stream("room", 4, scale=0.25)
+    for f in frames:
+        for e in [one, cpu] + sh:
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+    dirs = [e.dump_directory()[1] for e in sh]
+    assert multi.check_sharded_directories(dirs, slab_bits=1) == one.num_active_blocks()
+    plan = multi.halo_plan(dirs)
+    assert len(plan[0][1]) > 0 and len(plan[1][0]) > 0
+    parts = []
+    for r in range(2):
+        scratch = make_engine(vs, 6 * vs, **kw[r])
+        halo = multi.export_blocks(sh[1 - r], plan[1 - r][r])
+        parts.append(_tri_rows(*multi.mesh_with_halo(sh[r], scratch, halo)))
+        assert sh[r].num_active_blocks() == len(dirs[r])          # the map itself is untouched
+    got = np.concatenate(parts)
+    got = got[np.lexsort(got.T[::-1])]
+    ref = _tri_rows(*one.gather_valid_mesh())
+    assert got.shape == ref.shape and np.array_equal(got, ref), (got.shape, ref.shape)
+    ref_cpu = _tri_rows(*cpu.gather_valid_mesh())
+    assert ref.shape == ref_cpu.shape and np.abs(ref - ref_cpu).max() <= 1e-4
+    assert sum(len(e.gather_valid_mesh()[1]) for e in sh) < len(ref)   # the seam cells exist
+
+
+@pytest.mark.gpu
+def test_import_blocks_round_trip(make_engine, make_oracle):
+    """ratsdf_import_blocks: blocks exported from one map arrive in another with every voxel intact, whatever the
+    receiving engine's shard filter says, new and already-present blocks alike; HIP engine and oracle agree."""
+    from ratsdf import multi
+    vs = 0.02
+    src = make_engine(vs, 6 * vs)
+    for f in synthetic.stream("room", 3, scale=0.25):
+        src.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+    _, b = src.dump_directory()
+    pos = np.stack([b["x"], b["y"], b["z"]], axis=1)
+    data = multi.export_blocks(src, pos)
+    for dst in (make_engine(vs, 6 * vs, shard_rank=1, shard_count=4, shard_slab_bits=1),
+                make_oracle(vs, 6 * vs, shard_rank=1, shard_count=4, shard_slab_bits=1)):
+        dst.import_blocks(*data)
+        dst.import_blocks(data[0][:5], data[1][:5], data[2][:5], data[3][:5])   # present already: overwritten
+        assert dst.num_active_blocks() == len(pos)
+        back = multi.export_blocks(dst, pos)
+        assert np.array_equal(back[1], data[1]) and np.array_equal(back[2], data[2]) and np.array_equal(back[3], data[3])

@@ -256,3 +256,78 @@ def test_two_ranks_gloo_directories_beyond_64k_entries(oracle_lib):
             pytest.fail("rank hung")
         assert p.exitcode == 0
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _tri_rows(v, t, p):
+    """a mesh as a sorted array of rows {9 vertex coordinates, 3 vertex probabilities} per triangle: equal rows =
+    equal meshes whatever the order and numbering of vertices"""
+    a = np.concatenate([v[t].reshape(-1, 9), p[t].reshape(-1, 3)], axis=1)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def _mesh_worker(rank, world, port, ret):
+    sys.path.insert(0, str(ROOT / "ra-slam_amd"))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from oracle_binding import load_oracle
+    from ratsdf import multi, synthetic
+    from ratsdf._abi import Engine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = load_oracle()
+        vs = 0.02
+        kw = dict(shard_rank=rank, shard_count=world, shard_slab_bits=1)
+        eng = Engine(lib, vs, 6 * vs, **kw)
+        single = Engine(lib, vs, 6 * vs)
+        # (marching cubes reads voxels of weight > 10 only: the first view a dozen times, then a short sweep)
+        frames = [synthetic.frame("room", 0, scale=0.25) for _ in range(12)] + synthetic.stream("room", 4, scale=0.25)
+        for f in frames:
+            for e in (eng, single):
+                e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+        ex = multi.DirectoryExchange(capacity=4096)
+        ex.fill_from_numpy(eng.dump_directory()[1])
+        ex.all_gather()
+        per_rank = ex.result()
+        assert multi.check_sharded_directories(per_rank, slab_bits=1) == single.num_active_blocks()
+        plan = multi.halo_plan(per_rank)
+        assert all(len(plan[q][r]) > 0 for q in range(world) for r in range(world) if q != r), "no seam in this scene"
+        v, t, p = multi.mesh_across_shards(eng, lambda: Engine(lib, vs, 6 * vs, **kw), per_rank)
+        ref = _tri_rows(*single.gather_valid_mesh())
+        got = _tri_rows(v, t, p)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (got.shape, ref.shape)
+        # the seam cells exist: without the halo the shards' own meshes add up to fewer triangles
+        own = eng.gather_valid_mesh()
+        parts = [None] * world
+        dist.all_gather_object(parts, len(own[1]))
+        assert sum(parts) < len(ref), (parts, len(ref))
+        # and the map itself was not touched by the export
+        assert eng.num_active_blocks() == len(per_rank[rank])
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mesh_across_shard_seams_gloo(oracle_lib):
+    """TSDFSystem::DownloadAllMesh of a map spread over two ranks by block ownership (multi.mesh_across_shards: halo
+    exchange of the seam blocks' voxel data, per-rank meshing of a scratch copy with the seam closed, gather): as a
+    set of triangles it is the mesh of the same map held by ONE engine -- every seam cell emitted exactly once.
+    Marching cubes reads the 2x2x2 block neighbourhood (voxel_tsdf.cu:582-620), so without the halo the cells on
+    the subvolume faces are missing."""
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_mesh_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("rank hung")
+        assert p.exitcode == 0
+    assert dict(ret) == {0: "ok", 1: "ok"}

@@ -14,7 +14,7 @@ def extract(prefix):
     return lines[s:e + 1]
 
 
-for name, sym in (("k_integrate<2>", "_ZN6ratsdf11k_integrateILi2EEEv"), ("k_integrate_g<2>", "_ZN6ratsdf13k_integrate_gILi2EEEv")):
+for name, sym in (("k_integrate<2>", "_ZN6ratsdf11k_integrateILi2ELb0EEEv"), ("k_integrate_g<2>", "_ZN6ratsdf13k_integrate_gILi2ELb0EEEv")):
     f = extract(sym)
     rpi = next(i for i, l in enumerate(f) if "v_cvt_rpi_i32_f32_e64" in l)
     bar = next(i for i in range(rpi, len(f)) if "s_barrier" in f[i])
