@@ -632,6 +632,7 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
     __hip_atomic_store(&p[0], k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&p[1], k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // offset 0
     __hip_atomic_store(&p[2], (uint32_t)kPlaceholderIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mark_dirty(tab, e);  // (the commit fills in the pool index; the export lists the entry as it is then)
     if (slot < req_cap) {
       const Request r{(int16_t)(k0 & 0xFFFFu), (int16_t)(k0 >> 16), (int16_t)(k1 & 0xFFFFu),
                       (uint16_t)(kReqWinner | kReqPlaced), rank, e};
@@ -1106,7 +1107,10 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
       if (!(r.flags & kReqPlaced)) {
         const uint32_t bucket = block_hash(r.x, r.y, r.z, tab.bucket_mask);
         win = tab.claim[bucket] == r.rank;
-        if (win) req[i].flags = kReqWinner;
+        if (win) {
+          req[i].flags = kReqWinner;
+          mark_dirty(tab, r.entry);  // (directory delta: the entry the commit will fill)
+        }
       }
       if (win) {
         const uint32_t slot = atomicAdd(&lds[32], 1u);
@@ -1144,7 +1148,10 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
         bool win = (r[u].flags & kReqWinner) != 0;
         if (!(r[u].flags & kReqPlaced)) {
           win = c[u] == r[u].rank;
-          if (win) req[i].flags = kReqWinner;
+          if (win) {
+            req[i].flags = kReqWinner;
+            mark_dirty(tab, r[u].entry);
+          }
         }
         if (win) bitmap_set(bitmap, summary, r[u].rank);
       }
@@ -1201,6 +1208,10 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
 // heap[alloc_base - 1 - k] (AquireBlock, voxel_mem.cu:37-41) and gets its directory entry written
 // (voxel_hash.cu:72-74,101-103); every request releases its bucket's claim (ResetLocks).
 // Returns true for a winner that received a block; *out_k / *out_idx / *out_entry describe it.
+// kMark: the entry's dirty bit for the directory delta is set here (stand-alone commit).  Inside k_integrate the
+// frame's serial role marks every winner's entry instead (claim_pass / write_placed): the update loop has no
+// register to spare for one more rarely-taken atomic.
+template <bool kMark = false>
 __device__ inline bool commit_request(const Table& tab, const Pool& pool, const Request& r,
                                       uint32_t k, uint32_t alloc_base, uint32_t n_win, bool writer,
                                       int32_t* out_idx, uint32_t* out_entry) {
@@ -1229,7 +1240,7 @@ __device__ inline bool commit_request(const Table& tab, const Pool& pool, const 
     }
     pe[2] = (uint32_t)idx;
     atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
-    mark_dirty(tab, e);
+    if (kMark) mark_dirty(tab, e);
   }
   *out_idx = idx;
   *out_entry = e;
@@ -1263,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_commit_only(Table tab, Pool pool, const
         k = req_k[i];
       }
     }
-    if (!commit_request(tab, pool, r, k, base, n_win, lane == 0, &idx, &e)) continue;
+    if (!commit_request<true>(tab, pool, r, k, base, n_win, lane == 0, &idx, &e)) continue;
     const size_t v = ((size_t)idx << 9) + lane * 8;
     float4* pt = reinterpret_cast<float4*>(pool.tsdf + v);
     float4* ps = reinterpret_cast<float4*>(pool.segm + v);

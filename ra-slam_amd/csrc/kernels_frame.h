@@ -544,6 +544,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
     const uint32_t i = tid + k * NT;
     if (i < n && c[k] == r[k].rank) {
       rb.req[i].flags = kReqWinner;
+      mark_dirty(tab, r[k].entry);  // (directory delta: the entry the commit will fill)
       const uint32_t slot = atomicAdd(&lds[33], 1u);
       rb.win_ranks[slot] = r[k].rank;
     }

@@ -260,8 +260,14 @@ __device__ __forceinline__ void claim_pass(const Table& tab, const RankBufs& rb,
       if (i >= n) continue;
       const bool placed = ((r[k].w1 >> 16) & kReqPlaced) != 0;
       if (placed || c[k] == r[k].rank) {
-        if (!placed)  // word 1 = z | flags << 16: the winner flag as one agent-scope word store
+        if (!placed) {  // word 1 = z | flags << 16: the winner flag as one agent-scope word store
           st_agent(reinterpret_cast<uint32_t*>(rb.req + i) + 1, (r[k].w1 & 0xFFFFu) | ((uint32_t)kReqWinner << 16));
+          // (directory delta: the entry this winner's commit will fill -- its home bucket's first or second one)
+          if (tab.delta_on)
+            mark_dirty(tab, (block_hash((int16_t)(r[k].w0 & 0xFFFFu), (int16_t)(r[k].w0 >> 16),
+                                        (int16_t)(r[k].w1 & 0xFFFFu), tab.bucket_mask) << 1) +
+                                (((r[k].w1 >> 16) & kReqSlot1) ? 1u : 0u));
+        }
         at[k] = atomicAdd(&lds[cursor ? 4 : 1], 1u);
       }
     }
