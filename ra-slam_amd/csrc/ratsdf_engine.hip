@@ -633,10 +633,11 @@ ratsdf_engine::Geom ratsdf_engine::geometry(int H, int W, bool has_next, int spl
   if (cand_parts_env) parts = cand_parts_env;
   g.parts = parts;
   g.n_front_wg = g.n_vis_wg + kCandSegs * parts + kReleaseWGs + (g.a.n_tiles + 3) / 4;
-  // more workgroups for images with several times more visible blocks than 640x480: one voxel block
-  // per workgroup beats a loop over blocks (measured at 1280x720 / 2 mm, 13 k - 22 k visible blocks:
-  // 8192 -> 16384 workgroups -3 % kernel time, 24576 no better; profiles/r02_grid_sweep.txt)
-  g.grid = grid_from_env ? integrate_grid : (npix >= 600000 ? 16384u : 4096u);
+  // more workgroups for images with several times more visible blocks than 640x480 (1280x720 / 2 mm: 13 k - 22 k
+  // visible blocks).  Round 2 measured 16 384 as best (profiles/r02_grid_sweep.txt); with round 4's kernels 8 192
+  // is: 60.3 vs 62.4 us per frame on the 20-frame ping-pong (6 144: 61.9, 12 288: 61.5), 11 316 vs 10 838
+  // frames/s on the 416 MB map -- a workgroup takes 1.5 - 2.6 blocks, fewer workgroups to dispatch
+  g.grid = grid_from_env ? integrate_grid : (npix >= 600000 ? 8192u : 4096u);
   return g;
 }
 
