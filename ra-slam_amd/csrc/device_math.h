@@ -63,6 +63,20 @@ __device__ inline int f2i(float f) {
   return r;
 }
 
+// |(int)roundf(x)| in one instruction: v_cvt_rpi_i32_f32 of |x| = floor(|x| + 0.5) evaluated exactly = roundf(|x|)
+// for every float (tools/probes/round_probe.hip), saturating at INT_MAX, NaN -> 0.
+__device__ inline uint32_t rpi_abs(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32_e64 %0, |%1|" : "=v"(r) : "v"(x));
+  return (uint32_t)r;
+}
+// (int)roundf(x) for |x| < 2^31 (roundf is symmetric about zero: the magnitude above, then the sign): four
+// instructions instead of the eight of roundf + conversion.  NaN -> 0 like the conversion of a NaN.
+__device__ inline int round_to_int(float x) {
+  const int a = (int)rpi_abs(x);
+  return x < 0.f ? -a : a;
+}
+
 // IEEE-exact division with a shared divisor.  hipcc expands `a / b` (correctly rounded, no fast-math)
 // into: r0 = rcp(b); e = fma(-b, r0, 1); r1 = fma(e, r0, r0); q0 = a * r1; e2 = fma(-b, q0, a);
 // q1 = fma(e2, r1, q0); e3 = fma(-b, q1, a); q = fma(e3, r1, q1), wrapped in v_div_scale /

@@ -127,7 +127,10 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
     // probability update (kernels_integrate.h); -inf / +inf / NaN for ht = 0 / lt = 0 / both
     float ln = 0.f;
     if (P.has_sem) ln = __logf(hv) - __logf(lv);
-    const float wn = (1 - d / P.md) * 4;                                // :226
+    // :226.  d / max_depth with the frame's shared reciprocal: the correctly rounded quotient for every depth the
+    // update can use (finite, at most max_depth; a texel's w_new is read only when its voxel updates)
+    const Recip rmd = make_recip(P.md);
+    const float wn = (1 - (recip_safe(P.md) ? div_shared(d, rmd) : d / P.md)) * 4;
     J.texA[pix] = make_float4(d, r, ln, wn);
     J.texB[pix] = c;
   }
@@ -157,7 +160,8 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   // :159 -- dividing by 1, 2, 4, ... is an exact scaling, so multiply by the exact reciprocal then
   V3 st;
   if (steps <= 2 || (steps & (steps - 1)) == 0) {
-    const float inv = 1.f / den;  // exact for powers of two
+    // den = 2^k: its reciprocal is the same mantissa with the exponent mirrored (one integer subtraction, exact)
+    const float inv = __uint_as_float(0x7F000000u - __float_as_uint(den));
     st = V3{rg.x * inv, rg.y * inv, rg.z * inv};
   } else {
     st = V3{rg.x / den, rg.y / den, rg.z / den};
@@ -168,11 +172,23 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   }
   V3 p = sg;
   uint32_t prev0 = kInf, prev1 = kInf;  // this lane's previous sample
+  // every sample of every ray of the wave within +-2^30 voxels (always, for a map whose coordinates fit the
+  // reference's shorts): the short form of (int)roundf below; else the long one
+  const bool small = __all(!valid || (fabsf(sg.x) + fabsf(rg.x) < 1e9f && fabsf(sg.y) + fabsf(rg.y) < 1e9f &&
+                                      fabsf(sg.z) + fabsf(rg.z) < 1e9f));  // uniform
   for (int i = 0; i < P.S; ++i) {       // uniform trip count: the shuffles below need every lane
     const bool act = valid && i <= steps;
     if (!__any(act)) break;             // (uniform) no ray of the wave reaches this sample
-    const int gx = (int16_t)f2i(roundf(p.x)), gy = (int16_t)f2i(roundf(p.y)),
-              gz = (int16_t)f2i(roundf(p.z));                           // :163-164
+    int gx, gy, gz;                                                      // :163-164
+    if (small) {
+      gx = (int16_t)round_to_int(p.x);
+      gy = (int16_t)round_to_int(p.y);
+      gz = (int16_t)round_to_int(p.z);
+    } else {
+      gx = (int16_t)f2i(roundf(p.x));
+      gy = (int16_t)f2i(roundf(p.y));
+      gz = (int16_t)f2i(roundf(p.z));
+    }
     const int bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
     const uint32_t k0 = act ? key0(bx, by) : kInf;
     const uint32_t k1 = act ? key1(bz) : kInf;
@@ -186,7 +202,9 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
     if (act && !dup && shard_owned(bx, P) && !RATSDF_DBG(P, 2)) {
       const uint32_t rank = (uint32_t)pix * (uint32_t)P.S + (uint32_t)i;
       const unsigned long long key = (unsigned long long)k0 | ((unsigned long long)k1 << 32);
-      if (!cand_lds_insert(L, key, block_hash(bx, by, bz, 0xFFFFFFFFu), rank))
+      // (slot of the workgroup's set: any spreading of neighbouring blocks will do -- two 24-bit multiply-adds
+      // instead of the directory hash's three full 32-bit multiplications, which issue at a quarter of the rate)
+      if (!cand_lds_insert(L, key, (uint32_t)(bx + by * 17 + bz * 41), rank))
         cand_append(J.set, (J.first_tile + wg) & (kCandSegs - 1), k0, k1, rank, ctl);
     }
     if (act) {

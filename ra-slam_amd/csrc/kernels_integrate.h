@@ -499,12 +499,6 @@ __device__ __forceinline__ void serial_helper(EnginePtr E, uint32_t par, uint32_
     (void)__hip_atomic_fetch_add(&F->help_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// |(int)roundf(x)| in one instruction (see integrate_block)
-__device__ inline uint32_t rpi_abs(float x) {
-  int r;
-  asm("v_cvt_rpi_i32_f32_e64 %0, |%1|" : "=v"(r) : "v"(x));
-  return (uint32_t)r;
-}
 
 // round-half-away-from-zero of a NON-NEGATIVE float (roundf for x >= 0, NaN stays NaN); the generic
 // roundf additionally restores the sign (v_bfi)

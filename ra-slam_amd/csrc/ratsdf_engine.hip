@@ -1144,6 +1144,10 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
       return RATSDF_OK;
     }
   }
+  // (mode 1 samples frames 2, 6, 10, ... of the batch, never its first: the start stamp of a dispatch that finds
+  // the queue idle is taken early -- events showed 100+ us for such a frame where rocprofv3's trace of the same
+  // launch shows an ordinary one, tools/event_probe.py)
+  if (e->profiling && e->prof_mode != 2 && n > 2) e->prof_frame = 2;
   for (int i = 0; i < n; ++i) {
     const ratsdf_engine::FrameIn cur = input(i);
     ratsdf_engine::FrameIn nxt{};
