@@ -155,12 +155,15 @@ __device__ inline int block_list_of(int bx, int by, int bz, const FrameParams& P
   return (tx + 3 * ty) & 7;
 }
 
+// owner of a block = floormod(bx >> slab_bits, shard_count).  bx is a short: shifted by shard_bias (a
+// multiple of shard_count >= 32768) the slab number is non-negative, and its remainder comes from one multiply-high
+// with shard_magic = floor(2^32 / shard_count) + 1 (exact while (slab + bias) * shard_count < 2^32) -- the `%` of a
+// run-time divisor was 17 vector instructions per ray sample, evaluated whether the map is sharded or not.
 __device__ inline bool shard_owned(int bx, const FrameParams& P) {
   if (P.shard_count <= 1) return true;
-  const int s = bx >> P.shard_slab_bits;
-  int m = s % P.shard_count;
-  if (m < 0) m += P.shard_count;
-  return m == P.shard_rank;
+  const uint32_t u = (uint32_t)((bx >> P.shard_slab_bits) + P.shard_bias);
+  const uint32_t m = u - __umulhi(u, P.shard_magic) * (uint32_t)P.shard_count;
+  return m == (uint32_t)P.shard_rank;
 }
 
 }  // namespace ratsdf

@@ -181,6 +181,8 @@ struct FrameParams {
   int S;        // rank stride: max ray samples per pixel
   int has_sem;
   int shard_rank, shard_count, shard_slab_bits;
+  int shard_bias;          // multiple of shard_count, >= 32768 (device_math.h: shard_owned)
+  uint32_t shard_magic;    // floor(2^32 / shard_count) + 1
   int debug;    // diagnostic switches (0 in production)
 };
 

@@ -55,7 +55,9 @@ struct CandJob {
   uint32_t first_tile, n_tiles;  // this share: tiles [first_tile, first_tile + n_tiles)
   uint32_t tiles_per_wg;         // waves of a workgroup that take a tile; the others only join barriers
   uint32_t tiles_x;              // super-tiles per image row = ceil(W / 16)
+  uint32_t tiles_x_magic;        // floor(2^32 / tiles_x) + 1: n / tiles_x = mulhi(n, magic) for n * tiles_x < 2^32
 };
+inline uint32_t cand_tiles_magic(uint32_t tiles_x) { return tiles_x > 1 ? 0xFFFFFFFFu / tiles_x + 1u : 0u; }
 
 // Workgroup-level aggregation: the pixels of one workgroup ask for the same few dozen blocks over
 // and over.  A request that finds the LDS set full goes to the global list directly.
@@ -96,13 +98,23 @@ __device__ inline bool cand_lds_insert(CandLds& L, unsigned long long key, uint3
 // tile per wave.  `wg` counts workgroups inside the job.
 __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg, Ctl* ctl) {
   const FrameParams& P = J.P;
-  const uint32_t wave = threadIdx.x >> 6;
+  // (the tile's place in the image is the same for the whole wave: scalar arithmetic, and the division by the
+  // row length as a multiplication -- as vector code with a run-time divisor it was 33 instructions per lane)
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
+  // Which super-tile a workgroup takes: horizontal neighbours (2k, 2k + 1) go to workgroups 8 apart -- the same
+  // XCD (round-robin placement), dispatched back to back.  A 16-pixel row of a float image is HALF a 128-byte
+  // line; with neighbours on different XCDs every line of depth / ht / lt was fetched from memory twice (once per
+  // L2) and a wave's inputs took 4.3 us to arrive at 1280x720 (2.0 us at 640x480), the longest phase of the pass.
+  // (shares start at multiples of 16 super-tiles -- ratsdf_engine::geometry -- so relative = absolute parity)
+  if (J.tiles_per_wg == 4 && (wg | 15u) < (J.n_tiles + 3) / 4) wg = (wg & ~15u) | ((wg & 7u) << 1) | ((wg >> 3) & 1u);
   const uint32_t rel = wg * J.tiles_per_wg + wave;       // tile within the share
   const uint32_t tile = J.first_tile + rel;
   const uint32_t sup = tile >> 2, sub = tile & 3u;
-  const int px = (int)(sup % J.tiles_x) * 16 + (lane & 15);
-  const int py = (int)(sup / J.tiles_x) * 16 + (int)sub * 4 + (lane >> 4);
+  const uint32_t srow = J.tiles_x > 1 ? __umulhi(sup, J.tiles_x_magic) : sup;
+  const uint32_t scol = sup - srow * J.tiles_x;
+  const int px = (int)scol * 16 + (lane & 15);
+  const int py = (int)srow * 16 + (int)sub * 4 + (lane >> 4);
   const bool inb = wave < J.tiles_per_wg && rel < J.n_tiles && px < P.W && py < P.H;
   const int pix = inb ? py * P.W + px : 0;
   // every input of the pixel is requested here, in ONE round of loads (depth, ht, lt, the three colour
@@ -110,6 +122,10 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   // colour) in a workgroup whose whole life is ~6 us
   float d = 0.f, hv = 1.f, lv = 1.f;
   uint32_t c = 0;
+#ifdef RATSDF_STAMPS
+  unsigned long long pt[5];
+  pt[0] = clock64();
+#endif
   if (inb) {
     d = J.depth[pix];
     if (P.has_sem) {
@@ -136,6 +152,9 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   }
   const bool valid = inb && !(d == 0 || d > P.md);                      // :141
   if (RATSDF_DBG(P, 1)) return;  // uniform
+#ifdef RATSDF_STAMPS
+  pt[1] = clock64();  // (the inputs have arrived: the texel values above needed them)
+#endif
 
   const V3 pcd{pc.x * d, pc.y * d, pc.z * d};
   const V3 pw = se3_apply(P.Ti, pcd);                                   // :146
@@ -146,7 +165,9 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   const V3 dw = quat_rotate(P.Ti.q, dc);                                // :150
   const V3 sw{pw.x - dw.x * P.trunc, pw.y - dw.y * P.trunc, pw.z - dw.z * P.trunc};  // :151
   V3 dg, sg;
-  if (vs_ok && fabsf(sw.x) < 1e18f && fabsf(sw.y) < 1e18f && fabsf(sw.z) < 1e18f) {
+  // (one decision for the wave: as a per-lane choice the compiler evaluated BOTH forms for every lane -- six full
+  // IEEE divisions, 66 instructions, beside the six short ones.  The long form is right for every lane.)
+  if (vs_ok && __all(fabsf(sw.x) < 1e18f && fabsf(sw.y) < 1e18f && fabsf(sw.z) < 1e18f)) {
     dg = V3{div_shared(dw.x, rvs), div_shared(dw.y, rvs), div_shared(dw.z, rvs)};     // :153
     sg = V3{div_shared(sw.x, rvs), div_shared(sw.y, rvs), div_shared(sw.z, rvs)};     // :154
   } else {
@@ -176,6 +197,10 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   // reference's shorts): the short form of (int)roundf below; else the long one
   const bool small = __all(!valid || (fabsf(sg.x) + fabsf(rg.x) < 1e9f && fabsf(sg.y) + fabsf(rg.y) < 1e9f &&
                                       fabsf(sg.z) + fabsf(rg.z) < 1e9f));  // uniform
+#ifdef RATSDF_STAMPS
+  pt[2] = clock64();
+  pt[4] = 0;
+#endif
   for (int i = 0; i < P.S; ++i) {       // uniform trip count: the shuffles below need every lane
     const bool act = valid && i <= steps;
     if (!__any(act)) break;             // (uniform) no ray of the wave reaches this sample
@@ -214,7 +239,20 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
     p.x += st.x;
     p.y += st.y;
     p.z += st.z;
+#ifdef RATSDF_STAMPS
+    pt[4] += 1;
+#endif
   }
+#ifdef RATSDF_STAMPS
+  pt[3] = clock64();
+  if (threadIdx.x == 0 && (wg & 15) == 0) {  // [cand stamps] of ratsdf_debug_tail_stamps
+    atomicAdd(&ctl->tstamps[11], pt[1] - pt[0]);
+    atomicAdd(&ctl->tstamps[12], pt[2] - pt[1]);
+    atomicAdd(&ctl->tstamps[13], pt[3] - pt[2]);
+    atomicAdd(&ctl->tstamps[14], pt[4]);
+    atomicAdd(&ctl->tstamps[15], 1ull);
+  }
+#endif
 }
 
 // `L`: LDS of the workgroup (the caller owns it so that a kernel with several roles can share one buffer)
@@ -265,11 +303,15 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
   // compact the occupied slots
   constexpr uint32_t kMaxPerThread = kCandLdsSlots / 64;  // blockDim.x >= 64
   uint32_t pos[kMaxPerThread];
+  // (a 256-thread workgroup covers the set in two rounds: the other six are skipped by a scalar branch -- as
+  // predicated straight-line code they were 72 vector instructions per wave that did nothing)
 #pragma unroll
   for (uint32_t k = 0; k < kMaxPerThread; ++k) {
-    const uint32_t i = threadIdx.x + k * blockDim.x;
     pos[k] = kInf;
-    if (i < kCandLdsSlots && L.keys[i] != kCandEmpty) pos[k] = atomicAdd(&L.n, 1u);
+    if (k * blockDim.x < kCandLdsSlots) {  // uniform
+      const uint32_t i = threadIdx.x + k * blockDim.x;
+      if (i < kCandLdsSlots && L.keys[i] != kCandEmpty) pos[k] = atomicAdd(&L.n, 1u);
+    }
   }
   if (threadIdx.x == 0) L.base = reserved_at;
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

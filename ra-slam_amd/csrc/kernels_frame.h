@@ -38,7 +38,7 @@ typedef const FrameJob __attribute__((address_space(4))) * JobPtr;
 
 // which tiles of the look-ahead candidate pass a launch hosts (same for every engine of the launch)
 struct AheadGeom {
-  uint32_t first_tile, n_tiles, tiles_per_wg, tiles_x;
+  uint32_t first_tile, n_tiles, tiles_per_wg, tiles_x, tiles_x_magic;
 };
 
 // the candidate pass of frame `J` of engine `E`, restricted to `g`
@@ -57,6 +57,7 @@ __device__ inline CandJob make_cand_job(EnginePtr E, JobPtr J, const AheadGeom& 
   j.n_tiles = g.n_tiles;
   j.tiles_per_wg = g.tiles_per_wg;
   j.tiles_x = g.tiles_x;
+  j.tiles_x_magic = g.tiles_x_magic;
   return j;
 }
 

@@ -335,6 +335,8 @@ FrameParams ratsdf_engine::base_params() const {
   P.shard_rank = shard_rank;
   P.shard_count = shard_count;
   P.shard_slab_bits = shard_slab_bits;
+  P.shard_bias = (32768 + shard_count - 1) / shard_count * shard_count;
+  P.shard_magic = shard_count > 1 ? 0xFFFFFFFFu / (uint32_t)shard_count + 1u : 0u;
   P.debug = debug;
   return P;
 }
@@ -590,6 +592,7 @@ CandJob ratsdf_engine::cand_job(const FrameIn& in, const FrameParams& P, unsigne
   j.texB = texB[par];
   j.set = cand[par];
   j.tiles_x = (uint32_t)((P.W + 15) / 16);
+  j.tiles_x_magic = cand_tiles_magic(j.tiles_x);
   j.first_tile = 0;
   j.n_tiles = j.tiles_x * (uint32_t)((P.H + 15) / 16) * 4u;
   j.tiles_per_wg = 4;
@@ -607,11 +610,13 @@ ratsdf_engine::Geom ratsdf_engine::geometry(int H, int W, bool has_next, int spl
   const uint32_t tiles = tiles_x * (uint32_t)((H + 15) / 16) * 4u;
   g.n_cand_wg = (tiles + 3) / 4;
   g.a.tiles_x = g.b.tiles_x = g.c.tiles_x = tiles_x;
+  g.a.tiles_x_magic = g.b.tiles_x_magic = g.c.tiles_x_magic = cand_tiles_magic(tiles_x);
   g.a.tiles_per_wg = g.b.tiles_per_wg = g.c.tiles_per_wg = 4;
   if (has_next) {
     // k_front and k_integrate take whole 16x16 super-tiles (4 tiles per 256-thread workgroup)
-    const uint32_t tiles_a = (uint32_t)((uint64_t)(tiles / 4) * (unsigned)split_a / 100) * 4;
-    uint32_t tiles_b = (uint32_t)((uint64_t)(tiles / 4) * (unsigned)split_b / 100) * 4;
+    // (shares begin at multiples of 16 super-tiles: cand_pixel_work pairs neighbouring super-tiles per XCD)
+    const uint32_t tiles_a = (uint32_t)((uint64_t)(tiles / 4) * (unsigned)split_a / 100) / 16 * 64;
+    uint32_t tiles_b = (uint32_t)((uint64_t)(tiles / 4) * (unsigned)split_b / 100) / 16 * 64;
     if (split_a + split_b >= 100 || tiles_a + tiles_b > tiles) tiles_b = tiles - tiles_a;
     g.a.n_tiles = tiles_a;
     g.b.first_tile = tiles_a;
@@ -1557,6 +1562,17 @@ extern "C" int ratsdf_debug_tail_stamps(ratsdf_engine* e) {
           "winners listed %.2f | commits issued %.2f | end %.2f ; requests %.1f winners %.1f per frame\n",
           t[8], t[1] / n / 100, t[2] / n / 100, t[3] / n / 100, t[4] / n / 100, t[5] / n / 100, t[6] / n / 100,
           t[7] / n / 100, t[9] / n, t[10] / n);
+  if (t[15]) {
+    const double m = (double)t[15];
+    unsigned long long c[32];
+    HIPCHK(hipMemcpyAsync(c, e->ctl->stamps, sizeof(c), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const double k = c[17] ? (double)c[17] : 1.0;
+    fprintf(stderr, "[cand stamps] %llu candidate workgroups sampled (wave 0), shader cycles: inputs arrive %.0f | ray set-up %.0f | "
+            "sample loop %.0f (%.2f iterations) ; workgroup: set init + barrier %.0f | pixel work %.0f | barrier wait %.0f | "
+            "compaction + stores %.0f\n",
+            t[15], t[11] / m, t[12] / m, t[13] / m, t[14] / m, c[14] / k, c[15] / k, c[16] / k, c[18] / k);
+  }
   return RATSDF_OK;
 }
 
