@@ -96,7 +96,7 @@ __device__ inline bool cand_lds_insert(CandLds& L, unsigned long long key, uint3
 
 // block_allocate_kernel up to (not including) the directory lookup, one lane per pixel, one 16x4
 // tile per wave.  `wg` counts workgroups inside the job.
-__device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg, Ctl* ctl) {
+__device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg, Ctl* ctl, uint32_t reserved_at) {
   const FrameParams& P = J.P;
   // (the tile's place in the image is the same for the whole wave: scalar arithmetic, and the division by the
   // row length as a multiplication -- as vector code with a run-time divisor it was 33 instructions per lane)
@@ -121,20 +121,30 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
   // bytes): read where they are used they made three dependent memory round trips (depth -> ht / lt ->
   // colour) in a workgroup whose whole life is ~6 us
   float d = 0.f, hv = 1.f, lv = 1.f;
-  uint32_t c = 0;
+  uint32_t c0 = 0, c1 = 0, c2 = 0;
 #ifdef RATSDF_STAMPS
   unsigned long long pt[5];
   pt[0] = clock64();
 #endif
   if (inb) {
+    // (the colour bytes FIRST: the compiler moves the logarithms of ht / lt up into the has_sem branch, right behind
+    // their loads; with the colour loads after that branch the "one round" was two -- depth / ht / lt, a wait,
+    // the logarithms, then the colour loads and a second wait)
+    c0 = J.rgb[3 * pix];
+    c1 = J.rgb[3 * pix + 1];
+    c2 = J.rgb[3 * pix + 2];
     d = J.depth[pix];
     if (P.has_sem) {
       hv = J.ht[pix];
       lv = J.lt[pix];
     }
-    c = (uint32_t)J.rgb[3 * pix] | ((uint32_t)J.rgb[3 * pix + 1] << 8) | ((uint32_t)J.rgb[3 * pix + 2] << 16);
   }
+  const uint32_t c = c0 | (c1 << 8) | (c2 << 16);
 
+  // (the workgroup's list reservation -- a returning atomic issued before the loads above -- is put where the
+  // other waves find it HERE: the wait for it is the wait for the inputs; read at the end of the workgroup it
+  // would be a `s_waitcnt vmcnt(0)` behind the texel stores, i.e. a wait for their acknowledgement)
+  if (threadIdx.x == 0) L.base = reserved_at;
   const V3 pimg{(float)px, (float)py, 1.f};
   const V3 pc = intr_mul(P.Ki, pimg);                                   // :137
   const float r = sqrtf(pc.x * pc.x + (pc.y * pc.y + pc.z * pc.z));     // :140 (Eigen norm order)
@@ -257,7 +267,11 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
 
 // `L`: LDS of the workgroup (the caller owns it so that a kernel with several roles can share one buffer)
 __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl, CandLds& L) {
-  for (uint32_t i = threadIdx.x; i < kCandLdsSlots; i += blockDim.x) {
+  // (the workgroup size, read ONCE: the compiler fetches blockDim.x from the dispatch packet with a vector load
+  // wherever it is used and cannot hoist that across stores -- in the output loop below every round then began
+  // with `s_waitcnt vmcnt(0)`, i.e. waited for the previous round's list stores to be acknowledged)
+  const uint32_t nthreads = (uint32_t)__builtin_amdgcn_readfirstlane((int)blockDim.x);
+  for (uint32_t i = threadIdx.x; i < kCandLdsSlots; i += nthreads) {
     L.keys[i] = kCandEmpty;
     L.ranks[i] = kInf;
   }
@@ -266,11 +280,17 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
   // between two barriers at the end of every workgroup); unused entries are written as empties.
   const uint32_t seg = (J.first_tile + wg) & (kCandSegs - 1);
   const uint32_t reserve = kCandReserve * ((J.tiles_per_wg + 3) / 4);
-  uint32_t reserved_at = 0;  // thread 0 keeps the answer in a register until it is needed: storing it
-                             // to LDS here, or a __syncthreads(), would wait for the atomic
+  // Thread 0 keeps the answer in a register until the workgroup's inputs have arrived (cand_pixel_work).  The
+  // counter's address goes through a vector register the compiler cannot see through: with an address it knows
+  // to be the same for the whole wave its atomic optimiser rewrites atomicAdd() into "one lane adds for the wave,
+  // the others read its result with v_readfirstlane", which put `s_waitcnt vmcnt(0)` right behind the atomic -- a
+  // full round trip to L2 at the top of every workgroup, before its first input load.
+  uint32_t reserved_at = 0;
   if (threadIdx.x == 0) {
     L.n = 0;
-    reserved_at = atomicAdd(&J.set.count[seg * kCandCountStride], reserve);
+    uint32_t opaque_zero;
+    asm("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+    reserved_at = atomicAdd(&J.set.count[seg * kCandCountStride + opaque_zero], reserve);
   }
 #ifdef RATSDF_STAMPS
   unsigned long long cs[4];
@@ -284,7 +304,7 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
 #ifdef RATSDF_STAMPS
   cs[1] = clock64();
 #endif
-  if ((threadIdx.x >> 6) < J.tiles_per_wg) cand_pixel_work(J, L, wg, ctl);  // whole waves in or out
+  if ((threadIdx.x >> 6) < J.tiles_per_wg) cand_pixel_work(J, L, wg, ctl, reserved_at);  // whole waves in or out
 #ifdef RATSDF_STAMPS
   cs[2] = clock64();
 #endif
@@ -308,12 +328,11 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
 #pragma unroll
   for (uint32_t k = 0; k < kMaxPerThread; ++k) {
     pos[k] = kInf;
-    if (k * blockDim.x < kCandLdsSlots) {  // uniform
-      const uint32_t i = threadIdx.x + k * blockDim.x;
+    if (k * nthreads < kCandLdsSlots) {  // uniform
+      const uint32_t i = threadIdx.x + k * nthreads;
       if (i < kCandLdsSlots && L.keys[i] != kCandEmpty) pos[k] = atomicAdd(&L.n, 1u);
     }
   }
-  if (threadIdx.x == 0) L.base = reserved_at;
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   const uint32_t n = L.n;
   const uint32_t base = L.base;
@@ -331,14 +350,14 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
   uint4* out = J.set.list + (size_t)seg * J.set.seg_cap;
 #pragma unroll
   for (uint32_t k = 0; k < kMaxPerThread; ++k) {
-    const uint32_t i = threadIdx.x + k * blockDim.x;
+    const uint32_t i = threadIdx.x + k * nthreads;
     if (pos[k] != kInf) {
       const unsigned long long key = L.keys[i];
       const uint32_t at = pos[k] < reserve ? base + pos[k] : base2 + (pos[k] - reserve);
       out[at] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), L.ranks[i], 0u);
     }
   }
-  for (uint32_t i = n + threadIdx.x; i < reserve; i += blockDim.x)
+  for (uint32_t i = n + threadIdx.x; i < reserve; i += nthreads)
     out[base + i] = make_uint4(kInf, kInf, kInf, 0u);  // empty
 #ifdef RATSDF_STAMPS
   if (threadIdx.x == 0 && (wg & 15) == 0) atomicAdd(&ctl->stamps[18], (unsigned long long)clock64() - cs[3]);
