@@ -171,6 +171,16 @@ struct Intr {
 };
 
 // everything a frame's kernels need, passed by value
+// Threads of the workgroup.  Every launch of this engine runs whole workgroups, so this is the implicit argument
+// hidden_group_size_x (code object v5: a 16-bit word 12 bytes into the implicit arguments), fetched with a SCALAR
+// load.  `blockDim.x` compiles to "block index < block count ? group size : remainder", and in the large kernels
+// the compiler does not fold that: a scalar load, a select of the address, then `global_load_ushort` + wait --
+// a vector-memory round trip in front of the first real load of every role that strides by the workgroup size.
+__device__ __forceinline__ uint32_t block_threads() {
+  const uint16_t* ia = (const uint16_t*)__builtin_amdgcn_implicitarg_ptr();
+  return ia[6];
+}
+
 struct FrameParams {
   Se3 T;        // cam_T_world
   Se3 Ti;       // world_T_cam (host-computed, voxel_tsdf.cu:459)

@@ -261,7 +261,7 @@ __device__ inline void req_buf_flush(ReqBuf& B, Request* req, uint32_t req_cap, 
   if (threadIdx.x == 0) B.base = atomicAdd(&F->n_req, n);
   __syncthreads();
   const uint32_t base = B.base;
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+  for (uint32_t i = threadIdx.x; i < n; i += block_threads()) {
     if (base + i < req_cap) {
       if (write_through) st_agent_request(req + base + i, B.item[i]);
       else req[base + i] = B.item[i];
@@ -276,7 +276,7 @@ __device__ inline void req_buf_flush(ReqBuf& B, Request* req, uint32_t req_cap, 
 __global__ void k_alloc_list(Table tab, FrameParams P, const int16_t* pos, int n, Request* req,
                              uint32_t req_cap, SlowRequest* slow, uint32_t slow_cap, Ctl* ctl,
                              uint32_t par) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * block_threads() + threadIdx.x;
   if (i >= n) return;
   const int x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
   if (!shard_owned(x, P)) return;
@@ -407,7 +407,7 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
                                              uint32_t* lds_locks = nullptr, uint32_t lds_lock_slots = 0) {
   using KeyPtr = typename PtrOf<kLds, unsigned long long>::type;
   using WordPtr = typename PtrOf<kLds, uint32_t>::type;
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t tid = threadIdx.x, nt = block_threads();
   uint32_t n = F->n_slow;
   if (n > slow_cap) n = slow_cap;
   if (n > (uint32_t)kSlowSortCap) {
@@ -529,7 +529,7 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
       uint32_t mine = 0;
       for (uint32_t i = tid; i < n; i += nt) mine += !((uint32_t)skeys[i] & kDup);
       uint32_t distinct = 0;
-      for (uint32_t r = 0; r < 4; ++r) distinct += (uint32_t)__syncthreads_count(mine > r);  // (n <= 4 * blockDim.x)
+      for (uint32_t r = 0; r < 4; ++r) distinct += (uint32_t)__syncthreads_count(mine > r);  // (n <= 4 * block_threads())
       if (4u * distinct > locks.mask + 1u) return false;  // uniform
     }
   }
@@ -923,9 +923,9 @@ __device__ inline bool resolve_slow_requests(const Table& tab, Request* req, uin
 
 // Exclusive scan of one value per thread across the workgroup: wave-level scan with cross-lane
 // shuffles, then the (<= 16) wave totals through LDS.  Returns the exclusive prefix; *total receives
-// the workgroup sum.  lds: at least blockDim.x / 64 words.  Two barriers.
+// the workgroup sum.  lds: at least block_threads() / 64 words.  Two barriers.
 __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (block_threads() + 63) >> 6;
   uint32_t x = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -988,14 +988,14 @@ __device__ inline uint32_t chunk_popcount(const uint32_t* bitmap, const uint32_t
 // Zero every group of `bitmap` whose summary bit is set, then the summary itself (whole workgroup).
 __device__ inline void bitmap_clean(uint32_t* bitmap, uint32_t* summary, uint32_t nwords) {
   const uint32_t ngroups = (nwords + kGroupWords - 1) / kGroupWords;
-  for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
+  for (uint32_t g = threadIdx.x; g < ngroups; g += block_threads()) {
     if (!((summary[g >> 5] >> (g & 31)) & 1u)) continue;
     uint4* p = reinterpret_cast<uint4*>(bitmap + g * kGroupWords);
 #pragma unroll
     for (int i = 0; i < 8; ++i) p[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < (ngroups + 31) / 32; i += blockDim.x) summary[i] = 0;
+  for (uint32_t i = threadIdx.x; i < (ngroups + 31) / 32; i += block_threads()) summary[i] = 0;
 }
 
 // Per-word exclusive prefix, written only for groups that contain set bits (the only ones anyone
@@ -1045,7 +1045,7 @@ __device__ inline uint32_t bitmap_rank(const uint32_t* bitmap, const uint32_t* p
 // All threads of the workgroup; two barriers.
 template <typename Emit>
 __device__ inline void lds_rank_all(uint32_t* keys, uint32_t n, Emit emit) {
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t tid = threadIdx.x, nt = block_threads();
   const uint32_t n16 = (n + 15u) & ~15u;
   __syncthreads();
   if (tid < n16 - n) keys[n + tid] = kInf;
@@ -1085,7 +1085,7 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
                                        int32_t nf, unsigned long long* skeys, bool resolved = false) {
   uint32_t* lds = reinterpret_cast<uint32_t*>(skeys);  // [0,32): scan scratch, [32]: counter
   uint32_t* lds_rank = lds + 64;                       // kSmallRank words
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t tid = threadIdx.x, nt = block_threads();
   RATSDF_STAMP(ctl->stamps, 8);
   const uint32_t n_slow = F->n_slow;
   if (n_slow != 0 && !resolved) {  // uniform
@@ -1257,8 +1257,8 @@ __global__ __launch_bounds__(256) void k_commit_only(Table tab, Pool pool, const
   uint32_t n = F->n_req;
   if (n > req_cap) n = req_cap;
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (blockIdx.x * block_threads() + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * block_threads()) >> 6;
   const uint32_t base = F->alloc_base, n_win = F->n_win, n_winlist = F->n_winlist;
   for (uint32_t i = wave; i < n; i += nwaves) {
     const Request r = req[i];

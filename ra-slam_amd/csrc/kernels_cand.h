@@ -267,10 +267,8 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
 
 // `L`: LDS of the workgroup (the caller owns it so that a kernel with several roles can share one buffer)
 __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl, CandLds& L) {
-  // (the workgroup size, read ONCE: the compiler fetches blockDim.x from the dispatch packet with a vector load
-  // wherever it is used and cannot hoist that across stores -- in the output loop below every round then began
-  // with `s_waitcnt vmcnt(0)`, i.e. waited for the previous round's list stores to be acknowledged)
-  const uint32_t nthreads = (uint32_t)__builtin_amdgcn_readfirstlane((int)blockDim.x);
+  // (the workgroup size in a scalar register: device_types.h, block_threads())
+  const uint32_t nthreads = block_threads();
   for (uint32_t i = threadIdx.x; i < kCandLdsSlots; i += nthreads) {
     L.keys[i] = kCandEmpty;
     L.ranks[i] = kInf;
@@ -321,7 +319,7 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
   }
 #endif
   // compact the occupied slots
-  constexpr uint32_t kMaxPerThread = kCandLdsSlots / 64;  // blockDim.x >= 64
+  constexpr uint32_t kMaxPerThread = kCandLdsSlots / 64;  // block_threads() >= 64
   uint32_t pos[kMaxPerThread];
   // (a 256-thread workgroup covers the set in two rounds: the other six are skipped by a scalar branch -- as
   // predicated straight-line code they were 72 vector instructions per wave that did nothing)
@@ -420,17 +418,17 @@ __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P,
   // `parts` workgroups share a list (part = 0 .. parts-1): the lists of a large or finely resolved
   // image hold thousands of candidates each.  The counters are reset by the serial role afterwards.
   const uint4* list = cs.list + (size_t)seg * cs.seg_cap;
-  const uint32_t stride = parts * blockDim.x;
+  const uint32_t stride = parts * block_threads();
   // the count and the first batch of items are fetched together (list memory is always readable)
-  const uint32_t i0 = part * blockDim.x + threadIdx.x;
+  const uint32_t i0 = part * block_threads() + threadIdx.x;
   uint4 item = list[i0 < cs.seg_cap ? i0 : 0];
   uint32_t n = cs.count[seg * kCandCountStride];
   if (gate() == kGateExpired) return;  // uniform: the directory may be half-edited (sticky error set)
   if (n > cs.seg_cap) n = cs.seg_cap;
-  for (uint32_t base = part * blockDim.x; base < n; base += stride) {  // uniform
+  for (uint32_t base = part * block_threads(); base < n; base += stride) {  // uniform
     const uint32_t i = base + threadIdx.x;
     bool have = i < n;
-    if (base != part * blockDim.x && have) item = list[i];
+    if (base != part * block_threads() && have) item = list[i];
     have = have && item.y != kInf;  // reserved but unused entry
     int bx = 0, by = 0, bz = 0;
     EntryWords ea{0, 0, -1}, eb{0, 0, -1};

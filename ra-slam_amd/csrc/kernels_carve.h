@@ -106,7 +106,7 @@ __device__ inline void carve_candidate(const Table& tab, const CarveBufs& cb, Ct
 // is an agent-scope (write-through) store: the hand-off then needs no cache maintenance at all
 // (carve_resolve_gate).  Its own loads are plain: what it reads was written by earlier launches.
 __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb, Ctl* ctl, FrameCtl* F) {
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t tid = threadIdx.x, nt = block_threads();
   SlowDelete* slow = cb.slow;
   uint32_t ns = F->n_slow_del;
   if (ns > cb.slow_cap) ns = cb.slow_cap;
@@ -253,7 +253,7 @@ __device__ inline GateResult carve_resolve_gate(const Table& tab, const CarveBuf
 // atomic for the lot.  `lds`: 2 words.
 __device__ inline void log_deleted_positions(const Table& tab, const CarveBufs& cb, uint32_t nd, uint32_t ns,
                                              uint32_t* lds) {
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t tid = threadIdx.x, nt = block_threads();
   if (!tab.delta_on) return;  // uniform: nobody consumes deltas
   if (tid == 0) lds[0] = 0;
   __syncthreads();
@@ -296,7 +296,7 @@ __device__ inline void carve_release_role(const Table& tab, const Pool& pool, co
   uint32_t* del_entry = scratch;
   int32_t* del_pool = reinterpret_cast<int32_t*>(scratch + kSmallCarve);
   uint32_t& n_extra = scratch[2 * kSmallCarve];
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t tid = threadIdx.x, nt = block_threads();
   // one round of loads: counters, free count and (speculatively) the head of the delete list
   const uint32_t pend = Fp->pending;
   uint32_t nd = Fp->n_delcand, ns = Fp->n_slow_del;
@@ -367,7 +367,7 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
                                           Ctl* ctl, FrameCtl* F, ratsdf_frame_stats* stats, int32_t nf,
                                           uint32_t* scratch) {
   if (F->pending == 0) return 0;  // uniform
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t tid = threadIdx.x, nt = block_threads();
   uint32_t* lds = scratch;                    // [0,32): scan scratch, [32]: counter, [33]: result
   uint32_t* del_entry = scratch + 64;
   int32_t* del_pool = reinterpret_cast<int32_t*>(scratch + 64 + kSmallCarve + 16);
@@ -481,7 +481,7 @@ __device__ inline uint32_t carve_finalize(const Table& tab, const Pool& pool, co
 // exists becomes a carve candidate; k_settle then deletes them in entry order
 __global__ void k_delete_list(Table tab, const int16_t* pos, int n, CarveBufs cb, Ctl* ctl,
                               uint32_t par) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * block_threads() + threadIdx.x;
   FrameCtl* F = &ctl->fr[par];
   if (i == 0) F->pending = 1;
   if (i >= n) return;

@@ -193,8 +193,8 @@ __global__ __launch_bounds__(1024) void k_mask_positions(const uint32_t* mask, s
 
 __global__ void k_compact_vertices(const float* verts, const float* vprob, const uint32_t* vmask,
                                    const uint32_t* vpos, size_t n, float* out_v, float* out_p) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * block_threads() + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * block_threads()) {
     if (!vmask[i]) continue;
     const uint32_t o = vpos[i];
     out_v[(size_t)o * 3 + 0] = verts[i * 3 + 0];
@@ -206,8 +206,8 @@ __global__ void k_compact_vertices(const float* verts, const float* vprob, const
 
 __global__ void k_compact_triangles(const int32_t* tids, const uint32_t* tmask, const uint32_t* tpos,
                                     const uint32_t* vpos, size_t n, int32_t* out_i) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * block_threads() + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * block_threads()) {
     if (!tmask[i]) continue;
     const uint32_t o = tpos[i];
     for (int j = 0; j < 3; ++j) out_i[(size_t)o * 3 + j] = (int32_t)vpos[(size_t)tids[i * 3 + j]];

@@ -93,7 +93,7 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
   __shared__ uint32_t n_items, more, cnt[kNumLists], base[kNumLists], cnt2[kNumLists];
   const uint32_t nwords = tab.num_entry >> 6;
   const uint32_t w = wg * kVisWG + threadIdx.x;
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t tid = threadIdx.x, nt = block_threads();
   unsigned long long occ = w < nwords ? tab.occ[w] : 0ull;
   const uint32_t g = gate();
   if (g == kGateExpired) return;  // uniform: the directory may be half-edited (sticky error set)
@@ -214,8 +214,8 @@ template <bool Semantic>
 __global__ __launch_bounds__(256) void k_download(Pool pool, const VisItem* sel, const uint32_t* n_sel,
                                                   float vs, float* out) {
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (blockIdx.x * block_threads() + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * block_threads()) >> 6;
   const uint32_t n = *n_sel;
   constexpr int R = Semantic ? 5 : 4;
   for (uint32_t b = wave; b < n; b += nwaves) {
@@ -245,7 +245,7 @@ __global__ void k_export_entries(const VisItem* sel, const uint32_t* n_sel, Entr
                                  Ctl* ctl) {
   const uint32_t total = *n_sel;
   const uint32_t n = total > cap ? cap : total;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (uint32_t i = blockIdx.x * block_threads() + threadIdx.x; i < n; i += gridDim.x * block_threads()) {
     const VisItem it = sel[i];
     if (out_blocks) out_blocks[i] = Entry{it.x, it.y, it.z, it.offset, it.idx};
     if (out_entry_index) out_entry_index[i] = (int32_t)it.entry;
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256) void k_import_voxels(Table tab, Pool pool, con
                                                        const float* tsdf, const uint32_t* rgbw, const float* prob,
                                                        uint32_t* missing) {
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (blockIdx.x * block_threads() + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * block_threads()) >> 6;
   for (uint32_t b = wave; b < (uint32_t)n; b += nwaves) {
     EntryWords w;
     const uint32_t e = find_block(tab, pos[3 * b], pos[3 * b + 1], pos[3 * b + 2], &w);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_delta_deleted(Table tab, Entry* out, ui
   const uint32_t logged = *tab.del_count;
   const uint32_t n = logged < tab.del_cap ? logged : tab.del_cap;
   const uint32_t base = counts[0];
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (uint32_t i = blockIdx.x * block_threads() + threadIdx.x; i < n; i += gridDim.x * block_threads()) {
     const uint2 d = tab.del_log[i];
     if (base + i < cap) {
       uint32_t* o = reinterpret_cast<uint32_t*>(out + base + i);
@@ -337,8 +337,8 @@ __global__ void k_delta_reset(Table tab) { *tab.del_count = 0; }
 __global__ void k_gather_voxels(Pool pool, const int32_t* pool_idx, int n, float* tsdf,
                                 uint32_t* rgbw, float* prob) {
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (blockIdx.x * block_threads() + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * block_threads()) >> 6;
   for (uint32_t b = wave; b < (uint32_t)n; b += nwaves) {
     const size_t src = ((size_t)pool_idx[b] << 9) + lane * 8;
     const size_t dst = ((size_t)b << 9) + lane * 8;
@@ -353,7 +353,7 @@ __global__ void k_gather_voxels(Pool pool, const int32_t* pool_idx, int n, float
 // Retrieve<Voxel>(point, cache) with a fresh cache, voxel_hash.cuh:104-143 (test hook)
 __global__ void k_retrieve(Table tab, Pool pool, const int16_t* pts, int n, uint32_t* rgbw,
                            float* tsdf, float* prob, Entry* blocks) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * block_threads() + threadIdx.x;
   if (i >= n) return;
   const int px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
   const int bx = px >> 3, by = py >> 3, bz = pz >> 3;
@@ -377,7 +377,7 @@ __global__ void k_retrieve(Table tab, Pool pool, const int16_t* pts, int n, uint
 // *RetrieveMutable<VoxelRGBW>(point) = value, voxel_hash_test.cu:47-54 (test hook)
 __global__ void k_assign_rgbw(Table tab, Pool pool, const int16_t* pts, const uint32_t* vals,
                               int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * block_threads() + threadIdx.x;
   if (i >= n) return;
   const int px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
   EntryWords w;
