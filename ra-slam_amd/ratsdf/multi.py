@@ -517,3 +517,136 @@ def mesh_across_shards(engine, make_scratch, per_rank):
         ps_.append(pp)
         off += len(vv)
     return np.concatenate(vs_), np.concatenate(ts_), np.concatenate(ps_)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Ray casting across shards (TSDFGrid::RayCast, voxel_tsdf.cu:278-374, 885-902).
+#
+# A ray marches through the map with a step that depends on what it reads on the way (fine steps once tsdf < 0.5),
+# so a rank that renders from its own blocks alone -- other ranks' blocks absent, i.e. "far from any surface" --
+# samples different positions than one engine holding the whole map would, and compositing per-rank images by depth
+# is not exact.  What IS exact: partition the IMAGE.  Rank r renders rows [r0, r1) and needs every block a ray of
+# those rows can read; the replicated directories say which blocks those are and who owns them, so nobody has to ask:
+# one all-gather carries the blocks' voxel data, each rank imports what it needs into a scratch engine
+# (ratsdf_import_blocks), renders there, and one all-gather assembles the strips.  Retrieve() is a lookup by position
+# and an absent block reads as the default voxel in both engines, so the strip equals the same rows of the image one
+# engine would render -- bit for bit.
+# ---------------------------------------------------------------------------------------------------------------
+def strip_rows(height, world):
+    """image rows [lo, hi) of every rank: equal strips, the last one takes the remainder"""
+    per = (height + world - 1) // world
+    return [(min(r * per, height), min((r + 1) * per, height)) for r in range(world)]
+
+
+def _quat_matrix(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=np.float64)
+
+
+def frustum_blocks(blocks, intrinsics, width, rows, pose, max_depth, voxel_size, margin_voxels=6.0):
+    """Mask over directory records: may a ray through image rows [rows[0], rows[1]) read a voxel of the block?
+
+    Conservative (a superset): the block's bounding sphere, grown by `margin_voxels` (the march reads voxels rounded
+    from ray positions, the zero crossing's trilinear taps and gradient taps one voxel further out), against the
+    four side planes of the strip's frustum (one pixel of slack), the camera plane, and the ray length
+    (max_depth + one coarse step, taken as 1 m)."""
+    from ._abi import _as_intr, _as_pose
+    k, p = _as_intr(intrinsics), _as_pose(pose)
+    if len(blocks) == 0:
+        return np.zeros(0, dtype=bool)
+    c = (np.stack([blocks["x"], blocks["y"], blocks["z"]], axis=1).astype(np.float64) * 8 + 3.5) * voxel_size
+    R = _quat_matrix((p.qx, p.qy, p.qz, p.qw))
+    pc = c @ R.T + np.array([p.tx, p.ty, p.tz], dtype=np.float64)          # cam_T_world applied to the centres
+    rad = (np.sqrt(3.0) * 4.0 + margin_voxels) * voxel_size
+    x, y, z = pc[:, 0], pc[:, 1], pc[:, 2]
+    umin, umax, vmin, vmax = -1.0, float(width), float(rows[0]) - 1.0, float(rows[1])
+
+    def side(a, b, cc):  # signed distance to the plane a x + b y + cc z = 0 through the camera centre
+        return (a * x + b * y + cc * z) / np.sqrt(a * a + b * b + cc * cc)
+    keep = z > -rad
+    keep &= side(k.fx, 0.0, k.cx - umin) > -rad
+    keep &= side(-k.fx, 0.0, umax - k.cx) > -rad
+    keep &= side(0.0, k.fy, k.cy - vmin) > -rad
+    keep &= side(0.0, -k.fy, vmax - k.cy) > -rad
+    keep &= np.sqrt(x * x + y * y + z * z) < float(max_depth) + 1.0 + rad
+    return keep
+
+
+def raycast_plan(per_rank, intrinsics, height, width, pose, max_depth, voxel_size):
+    """plan[q][r] = sorted positions of rank q's blocks that rank r needs to render its strip (q == r included).
+    From the replicated directories alone: the same on every rank."""
+    world = len(per_rank)
+    strips = strip_rows(height, world)
+    plan = [[[] for _ in range(world)] for _ in range(world)]
+    for q in range(world):
+        b = per_rank[q]
+        for r in range(world):
+            if strips[r][0] >= strips[r][1] or len(b) == 0:
+                continue
+            m = frustum_blocks(b, intrinsics, width, strips[r], pose, max_depth, voxel_size)
+            plan[q][r] = sorted(zip(b["x"][m].tolist(), b["y"][m].tolist(), b["z"][m].tolist()))
+    return plan
+
+
+def _import_chunks(scratch, part):
+    for lo in range(0, len(part[0]), 4096):
+        scratch.import_blocks(part[0][lo:lo + 4096], part[1][lo:lo + 4096], part[2][lo:lo + 4096],
+                              part[3][lo:lo + 4096])
+
+
+def raycast_strip(scratch, parts, intrinsics, height, width, pose, max_depth, rows):
+    """rows [rows[0], rows[1]) of TSDFGrid::RayCast rendered on `scratch` (an empty engine of the map's voxel size)
+    after importing `parts` (export_blocks() tuples): (rgba, normal) strips."""
+    for part in parts:
+        _import_chunks(scratch, part)
+    rgba, normal = scratch.raycast(intrinsics, height, width, pose, max_depth)
+    return rgba[rows[0]:rows[1]].copy(), normal[rows[0]:rows[1]].copy()
+
+
+def raycast_across_shards(engine, make_scratch, per_rank, intrinsics, height, width, pose, max_depth, voxel_size):
+    """TSDFGrid::RayCast of a map spread over ranks by block ownership (comment above): returns the whole
+    (rgba, normal) images, H x W x 4 uint8, on every rank -- equal to one engine's rendering of the same map.
+    `per_rank` = the replicated directories; `make_scratch()` builds an empty, UNsharded engine."""
+    import torch
+    import torch.distributed as dist
+    from ._abi import RGBW_DTYPE
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    plan = raycast_plan(per_rank, intrinsics, height, width, pose, max_depth, voxel_size)
+    strips = strip_rows(height, world)
+    # what I send to the others, once; everybody knows everybody's list, so the buffers have agreed sizes
+    out_lists = [sorted(set(p for r in range(world) if r != q for p in plan[q][r])) for q in range(world)]
+    nmax = max(1, max(len(l) for l in out_lists))
+    pos, t, c, p = export_blocks(engine, out_lists[rank])
+    send = torch.zeros((nmax, 3 * 512), dtype=torch.int32)
+    if len(pos):
+        send[:len(pos), 0:512] = torch.from_numpy(t.view(np.int32))
+        send[:len(pos), 512:1024] = torch.from_numpy(np.ascontiguousarray(c).view(np.int32).reshape(-1, 512))
+        send[:len(pos), 1024:1536] = torch.from_numpy(p.view(np.int32))
+    if world > 1:
+        recv = [torch.zeros_like(send) for _ in range(world)]
+        dist.all_gather(recv, send)
+    else:
+        recv = [send]
+    parts = [export_blocks(engine, plan[rank][rank])]
+    for q in range(world):
+        if q == rank or not plan[q][rank]:
+            continue
+        row_of = {pp: i for i, pp in enumerate(out_lists[q])}
+        rows = np.array([row_of[pp] for pp in plan[q][rank]], dtype=np.int64)
+        data = recv[q].numpy()[rows]
+        parts.append((np.array(plan[q][rank], dtype=np.int16), data[:, 0:512].copy().view(np.float32),
+                      data[:, 512:1024].copy().view(RGBW_DTYPE).reshape(-1, 512),
+                      data[:, 1024:1536].copy().view(np.float32)))
+    scratch = make_scratch()
+    try:
+        mine = raycast_strip(scratch, parts, intrinsics, height, width, pose, max_depth, strips[rank])
+    finally:
+        scratch.close()
+    if world == 1:
+        return mine
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return np.concatenate([g[0] for g in got], axis=0), np.concatenate([g[1] for g in got], axis=0)

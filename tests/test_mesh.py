@@ -141,3 +141,55 @@ def test_import_blocks_round_trip(make_engine, make_oracle):
         assert dst.num_active_blocks() == len(pos)
         back = multi.export_blocks(dst, pos)
         assert np.array_equal(back[1], data[1]) and np.array_equal(back[2], data[2]) and np.array_equal(back[3], data[3])
+
+
+@pytest.mark.gpu
+def test_raycast_across_shards_on_the_hip_engine(make_engine, make_oracle):
+    """Two HIP engines hold the two subvolumes of one stream; the image is partitioned into strips and every strip is
+    rendered on a scratch HIP engine that holds only the blocks the plan names for it (multi.raycast_plan /
+    raycast_strip; the two-rank form over gloo: tests/test_multi_gloo.py): assembled, bit for bit the rendering of
+    the WHOLE sharded map by one engine (every shard's blocks imported into one scratch engine).
+    Not compared with the rendering of the same stream integrated by one unsharded engine: the maps differ in a
+    few blocks by construction -- in one engine two absent blocks of different owners that hash to the same bucket
+    collide (voxel_hash.cu:46-108: the later request finds the bucket locked and its block is inserted a frame
+    later, missing an update), in the shards they never meet.  That is a property of BASELINE config 4 under the
+    reference's allocation rule, in the oracle as well; each shard equals the oracle with the same ownership
+    filter (test_gpu_parity.py)."""
+    from ratsdf import multi
+    vs = 0.01
+    kw = [dict(shard_rank=r, shard_count=2, shard_slab_bits=1) for r in range(2)]
+    one = make_engine(vs, 6 * vs)
+    sh = [make_engine(vs, 6 * vs, **k) for k in kw]
+    frames = [synthetic.frame("room", 0, scale=0.25) for _ in range(12)] + synthetic.stream("room", 6, scale=0.25)
+    for f in frames:
+        for e in [one] + sh:
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+    dirs = [e.dump_directory()[1] for e in sh]
+    assert multi.check_sharded_directories(dirs, slab_bits=1) == one.num_active_blocks()
+    view = frames[-1]
+    H, W = view["depth"].shape
+    K, T = view["intrinsics"], view["pose"]
+    whole = make_engine(vs, 6 * vs)
+    for e, d in zip(sh, dirs):
+        multi._import_chunks(whole, multi.export_blocks(e, np.stack([d["x"], d["y"], d["z"]], axis=1)))
+    assert whole.num_active_blocks() == one.num_active_blocks()
+    ref_rgba, ref_normal = whole.raycast(K, H, W, T, 4.0)
+    assert (ref_rgba[..., 3] == 255).mean() > 0.5
+    # (the unsharded stream's rendering is close, not equal: see above)
+    one_rgba, _ = one.raycast(K, H, W, T, 4.0)
+    assert (np.abs(one_rgba.astype(int) - ref_rgba.astype(int)).max(axis=2) > 2).mean() < 0.05
+    plan = multi.raycast_plan(dirs, K, H, W, T, 4.0, vs)
+    strips = multi.strip_rows(H, 2)
+    rgba, normal = [], []
+    for r in range(2):
+        assert all(len(plan[q][r]) > 0 for q in range(2))          # the strip reads blocks of both subvolumes
+        assert sum(len(plan[q][r]) for q in range(2)) < one.num_active_blocks()
+        scratch = make_engine(vs, 6 * vs)
+        a, b = multi.raycast_strip(scratch, [multi.export_blocks(sh[q], plan[q][r]) for q in range(2)], K, H, W, T,
+                                   4.0, strips[r])
+        rgba.append(a)
+        normal.append(b)
+        assert sh[r].num_active_blocks() == len(dirs[r])           # the maps themselves are untouched
+    assert np.array_equal(np.concatenate(rgba), ref_rgba) and np.array_equal(np.concatenate(normal), ref_normal)
+    own, _ = sh[0].raycast(K, H, W, T, 4.0)
+    assert not np.array_equal(own, ref_rgba)                       # own blocks alone render something else
