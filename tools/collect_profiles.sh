@@ -22,5 +22,6 @@ bash tools/traffic_group.sh 4 > gpurun_out/traffic_grp.log 2>&1 &&
 cp $O/traffic_latest.json $O/traffic_hd2mm.json $O/traffic_bigmap.json $O/traffic_group4.json profiles/ &&
 timeout -k 10 800 python bench.py > gpurun_out/bench_default.log 2>&1 && tail -1 gpurun_out/bench_default.log > $O/${TAG}_bench_line.json &&
 timeout -k 10 500 python bench.py --config hd2mm --host-frames 0 --streams 0 > gpurun_out/bench_hd2mm.log 2>&1 && tail -1 gpurun_out/bench_hd2mm.log > $O/${TAG}_bench_line_hd2mm.json &&
-timeout -k 10 500 python bench.py --config bigmap > gpurun_out/bench_bigmap.log 2>&1 && tail -1 gpurun_out/bench_bigmap.log > $O/${TAG}_bench_line_bigmap.json
+timeout -k 10 500 python bench.py --config bigmap > gpurun_out/bench_bigmap.log 2>&1 && tail -1 gpurun_out/bench_bigmap.log > $O/${TAG}_bench_line_bigmap.json &&
+timeout -k 10 500 python bench.py --config flythrough --host-frames 0 --streams 0 > gpurun_out/bench_fly.log 2>&1 && tail -1 gpurun_out/bench_fly.log > $O/${TAG}_bench_line_flythrough_hd2mm.json
 echo "collect rc=$?"
