@@ -70,6 +70,13 @@ __global__ void k_init_table(Entry* entries, uint32_t* claim, unsigned long long
   if (i < num_bucket) claim[i] = kInf;
   if (i < (num_entry + 63) / 64) occ[i] = 0ull;
 }
+// block_threads() (device_types.h) reads the workgroup size from a fixed place in the implicit kernel arguments:
+// checked once per engine against blockDim.x, with an odd size, so that a toolchain that lays them out
+// differently fails ratsdf_create instead of computing garbage.
+__global__ void k_check_block_threads(uint32_t* out) {
+  if (threadIdx.x == 0) out[0] = block_threads() == blockDim.x ? blockDim.x : 0u;
+}
+
 __global__ void k_init_heap(int32_t* heap, int32_t n) {   // heap_init_kernel, voxel_mem.cu:6-11
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) heap[i] = i;
@@ -1051,8 +1058,17 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMemcpyAsync(&e->ctl->num_free, &nf, 4, hipMemcpyHostToDevice, e->stream));
   CREATE_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_alloc_rank),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+  hipLaunchKernelGGL(k_check_block_threads, dim3(3), dim3(192), 0, e->stream, &e->ctl->n_sel);
+  uint32_t bt = 0;
+  CREATE_CHK(hipMemcpyAsync(&bt, &e->ctl->n_sel, 4, hipMemcpyDeviceToHost, e->stream));
   CREATE_CHK(hipStreamSynchronize(e->stream));
   CREATE_CHK(hipGetLastError());
+  if (bt != 192u) {
+    fprintf(stderr, "[ratsdf] create failed: the workgroup size is not where block_threads() reads it (code object ABI?)\n");
+    e->free_all();
+    delete e;
+    return RATSDF_ERR_DEVICE;
+  }
   if (e->upload_record() != RATSDF_OK) {
     e->free_all();
     delete e;
