@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""GPU box: frames that leave the serial role's ordinary path -- more than 32 768 allocation requests (the first
+frame of a 1280x720 view at 1.2 mm voxels) and more than 2 048 deletes (the frame after the camera has turned away
+from a carved region) -- timed with the product build: wall time per frame (one frame per call, synchronised),
+which form of the serial role it took (ratsdf_pipeline_counters), parity of the map with the oracle at the end."""
+import os, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "ra-slam_amd")); sys.path.insert(0, str(ROOT / "tests"))
+import numpy as np
+import torch, ratsdf
+from ratsdf import synthetic
+from ratsdf._abi import Engine
+from oracle_binding import load_oracle
+from parity import assert_maps_equal
+dev = torch.device("cuda", 0)
+vs = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0012
+idx = (0, 1, 2, 40, 41, 0, 1)
+frames = [synthetic.frame("room", i, cam="l515_720p", noise=True, holes=True) for i in idx]
+H, W = frames[0]["depth"].shape
+dd = [[torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")] for f in frames]
+eng = ratsdf.TSDFGrid(vs, 6 * vs, pool_bits=20, bucket_bits=20)
+cpu = Engine(load_oracle(), vs, 6 * vs, threads=16, pool_bits=20, bucket_bits=20)
+prev = eng.pipeline_counters()
+for f, d, i in zip(frames, dd, idx):
+    eng.synchronize()
+    t0 = time.perf_counter()
+    eng.integrate_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), H, W, 4.0,
+                         f["intrinsics"], f["pose"])
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    now = eng.pipeline_counters()
+    took = {k: now[k] - prev[k] for k in now if now[k] != prev[k]}
+    prev = now
+    print(f"frame {i:3d}: wall {dt * 1e6:9.1f} us  path {took}  {eng.last_frame_stats()}", flush=True)
+    cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+assert_maps_equal(cpu, eng)
+print("parity with the oracle after these frames: ok (directory bit-exact)")
