@@ -19,8 +19,8 @@ idx = (0, 1, 2, 40, 41, 0, 1)
 frames = [synthetic.frame("room", i, cam="l515_720p", noise=True, holes=True) for i in idx]
 H, W = frames[0]["depth"].shape
 dd = [[torch.from_numpy(f[k]).to(dev) for k in ("rgb", "depth", "ht", "lt")] for f in frames]
-eng = ratsdf.TSDFGrid(vs, 6 * vs, pool_bits=20, bucket_bits=20)
-cpu = Engine(load_oracle(), vs, 6 * vs, threads=16, pool_bits=20, bucket_bits=20)
+eng = ratsdf.TSDFGrid(vs, 6 * vs, block_bits=20)
+cpu = Engine(load_oracle(), vs, 6 * vs, threads=16, block_bits=20)
 prev = eng.pipeline_counters()
 for f, d, i in zip(frames, dd, idx):
     eng.synchronize()
