@@ -160,7 +160,7 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
     J.texA[pix] = make_float4(d, r, ln, wn);
     J.texB[pix] = c;
   }
-  const bool valid = inb && !(d == 0 || d > P.md);                      // :141
+  bool valid = inb && !(d == 0 || d > P.md);                            // :141
   if (RATSDF_DBG(P, 1)) return;  // uniform
 #ifdef RATSDF_STAMPS
   pt[1] = clock64();  // (the inputs have arrived: the texel values above needed them)
@@ -168,6 +168,24 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
 
   const V3 pcd{pc.x * d, pc.y * d, pc.z * d};
   const V3 pw = se3_apply(P.Ti, pcd);                                   // :146
+  // A map split over ranks by block ownership: every sample of this pixel's ray lies within the
+  // truncation distance of the surface point, so its blocks' x lies in a short interval; when no slab of that
+  // interval belongs to this rank, every request of the pixel would be dropped by shard_owned() further down --
+  // the pixel is done, and so is the wave when that holds for all of its pixels (the ray set-up and the sample
+  // loop are ~2/3 of the pass's instructions and all of its LDS traffic).  Conservative: 2.5 voxels of slack for
+  // the roundings; coordinates outside the shorts' range (which wrap) never skip.
+  if (P.shard_count > 1) {  // uniform
+    const float lo = (pw.x - P.trunc) / P.vs - 2.5f, hi = (pw.x + P.trunc) / P.vs + 2.5f;
+    if (lo > -32000.f && hi < 32000.f) {
+      const int s_lo = ((int)floorf(lo) >> 3) >> P.shard_slab_bits, s_hi = ((int)floorf(hi) >> 3) >> P.shard_slab_bits;
+      const uint32_t u = (uint32_t)(s_lo + P.shard_bias);
+      const uint32_t m_lo = u - __umulhi(u, P.shard_magic) * (uint32_t)P.shard_count;  // floormod(s_lo, count)
+      uint32_t k0 = (uint32_t)P.shard_rank + (uint32_t)P.shard_count - m_lo;           // slabs up to the next own one
+      if (k0 >= (uint32_t)P.shard_count) k0 -= (uint32_t)P.shard_count;
+      if (k0 > (uint32_t)(s_hi - s_lo)) valid = false;
+    }
+    if (!__any(valid)) return;  // uniform
+  }
   // shared-divisor divisions (device_math.h): r in [1, ~3], voxel size a frame constant
   const Recip rr = make_recip(r), rvs = make_recip(P.vs);
   const bool vs_ok = recip_safe(P.vs);  // uniform
