@@ -65,6 +65,11 @@ def parse():
                     help="N > 1: every rank integrates the SAME stream and owns the blocks "
                          "owner(block) == rank (spatial subvolumes, strong scaling) instead of "
                          "one independent stream per rank")
+    ap.add_argument("--bcast-chunk", type=int, default=15,
+                    help="--shard: frames per broadcast chunk (one collective and one HIP-graph replay each); the "
+                         "largest divisor of --frames-per-step not above this is used")
+    ap.add_argument("--bcast-ring", type=int, default=3,
+                    help="--shard: chunk buffers per rank; the broadcasts run (ring - 1) chunks ahead of the integration")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of k_integrate")
     ap.add_argument("--host-frames", type=int, default=60,
                     help="frames timed through the host-image entry point, PCIe included (0 = skip)")
@@ -376,6 +381,160 @@ def bench_tsdf_system(frames, md, vs, nframes=3000):
     return out
 
 
+def bench_sharded_stream(a, rank, world, dev, dev_index, backend, torch, dist, ratsdf):
+    """BASELINE configs[3]: ONE camera stream, N spatial subvolumes (block ownership), one rank per GPU.
+    Rank 0 owns the stream (packed wire chunks resident in its HBM); every chunk reaches the other ranks by one
+    broadcast on a side stream, (ring - 1) chunks ahead of the integration (ratsdf.framecast.FrameCaster) -- the
+    broadcasts ARE inside the timed region.  Every rank integrates what it received into its own subvolume; the
+    block-directory deltas are all-gathered once per step.  `value` = frames of the one stream per second
+    ("scaling": "strong")."""
+    from ratsdf import framecast, multi, synthetic
+    vs, md, B = a.voxel, a.max_depth, a.frames_per_step
+    W, H, _ = synthetic.camera(a.cam)
+    C = max(c for c in range(1, min(a.bcast_chunk, B) + 1) if B % c == 0)
+    n_chunks = B // C
+    slab_bits = 2
+    eng = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index, shard_rank=rank, shard_count=world, shard_slab_bits=slab_bits)
+    ext = torch.cuda.ExternalStream(eng.stream(), device=dev)
+    packed = None
+    if rank == 0:   # the camera's rank: the only one that ever sees the stream
+        frames = make_stream(a.scene, a.cam, (B + 1) // 2, phase=0)[:B]
+        packed = [torch.from_numpy(framecast.pack_chunk(frames[c * C:(c + 1) * C], md, H, W, C, first_frame_no=c * C)).to(dev)
+                  for c in range(n_chunks)]
+        del frames
+    torch.cuda.synchronize()
+    fc = framecast.FrameCaster(H, W, C, ring=a.bcast_ring, src=0, device=dev)
+
+    # ---- parity on the first chunk, from the bytes this rank RECEIVED: transport (byte sums from the camera's
+    # rank), then HIP shard == the CPU oracle's shard fed with the same received images
+    parity = None
+    if a.cpu_frames > 0:
+        from oracle_binding import load_oracle
+        from parity import assert_maps_equal
+        from ratsdf._abi import Engine
+        fc.post(packed[0] if rank == 0 else None)
+        chk = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index, shard_rank=rank, shard_count=world, shard_slab_bits=slab_bits)
+        cext = torch.cuda.ExternalStream(chk.stream(), device=dev)
+        ch = fc.take(cext, verify=True)
+        framecast.integrate_chunk(chk, ch)
+        chk.synchronize()
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = max(1, min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16"))) // world)
+        cpu = Engine(load_oracle(), vs, 6 * vs, threads=cores, shard_rank=rank, shard_count=world, shard_slab_bits=slab_bits)
+        npix = H * W
+        for i in range(ch.n):
+            img = fc.chunk_tensor(ch)[i * fc.stride:(i + 1) * fc.stride].cpu().numpy()
+            cpu.integrate(img[npix * 12:npix * 15].reshape(H, W, 3), img[:npix * 4].view(np.float32).reshape(H, W),
+                          img[npix * 4:npix * 8].view(np.float32).reshape(H, W),
+                          img[npix * 8:npix * 12].view(np.float32).reshape(H, W), ch.max_depth, ch.intrinsics[i], ch.poses[i])
+        worst = assert_maps_equal(chk, cpu)
+        fc.done(ch, cext)
+        parity = dict(frames=ch.n, max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"], directory="bit-exact",
+                      transport="per-frame byte sums of the received chunk == the camera rank's", oracle_threads=cores)
+        chk.close()
+        cpu.close()
+
+    ex = multi.DirectoryDeltaExchange(engine=eng, device=dev) if backend == "nccl" else multi.DirectoryDeltaExchange(engine=eng)
+
+    def exchange():
+        if backend == "nccl":
+            ex.fill_from_engine(eng)
+        else:
+            ex.fill_from_numpy(eng.dump_directory()[1])
+        try:
+            ex.all_gather()
+        except OverflowError:   # (every rank raises together; the exchange has restarted with whole directories)
+            pass
+
+    def run(nsteps):
+        total, posted = nsteps * n_chunks, 0
+        for k in range(total):
+            while posted < total and fc.can_post():
+                fc.post(packed[posted % n_chunks] if rank == 0 else None)
+                posted += 1
+            ch = fc.take(ext)
+            framecast.integrate_chunk(eng, ch)
+            fc.done(ch, ext)
+            if (k + 1) % n_chunks == 0:
+                exchange()
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    run(a.warmup)
+    fence()
+    eng.totals(reset=True)
+    if not a.no_profile:
+        eng.profile_enable(True)
+    sent0 = fc.bytes_sent
+    rep_dt = []
+    for _ in range(max(a.reps, 1)):
+        t0 = time.perf_counter()
+        run(a.steps)
+        fence()
+        d = time.perf_counter() - t0
+        t = torch.tensor([d], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rep_dt.append(float(t.item()))
+    dt = sorted(rep_dt)[len(rep_dt) // 2]
+    k_ms, k_n = (0.0, 0)
+    if not a.no_profile:
+        k_ms, k_n = eng.profile_read()
+        eng.profile_enable(False)
+    tot = eng.totals()
+    stats = eng.last_frame_stats()
+    shares = [None] * world
+    dist.all_gather_object(shares, dict(visible_blocks=round(tot["visible_blocks"] / max(tot["frames"], 1), 1),
+                                        updated_voxels=round(tot["updated_voxels"] / max(tot["frames"], 1), 1),
+                                        active_blocks=stats["active_blocks"]))
+    per_rank = ex.result()
+    out = None
+    if rank == 0:
+        union = multi.check_sharded_directories(per_rank, slab_bits=slab_bits)   # every block on its owner, on no other rank
+        nframes = a.steps * B
+        fps = nframes / dt
+        V = tot["visible_blocks"] / max(tot["frames"], 1)
+        U = tot["updated_voxels"] / max(tot["frames"], 1)
+        b_alg = 15.0 * W * H + 12.0 * V + 24.0 * U     # this rank's launch: the whole image, its share of the blocks
+        roof = roofline_block(b_alg, k_ms, k_n, a.config, whole_frame_gbps=b_alg * fps / 1e9)
+        bytes_timed = (fc.bytes_sent - sent0) / max(len(rep_dt), 1)
+        out = {
+            "metric": ("depth+semantic frames/sec integrated @640x480, 5mm voxels" if a.config == "vga5mm"
+                       else f"depth+semantic frames/sec integrated @{W}x{H}, {vs * 1e3:g}mm voxels"),
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "reps": len(rep_dt),
+            "value_min_max": [round(nframes / max(rep_dt), 1), round(nframes / min(rep_dt), 1)],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"ONE synthetic '{a.scene}' RGB-D+ht/lt stream, {a.cam} intrinsics {W}x{H}, voxel "
+                            f"{vs * 1e3:g} mm, truncation {6 * vs * 1e3:g} mm, max depth {md:g} m, 1 deg/frame ping-pong "
+                            f"sweep, 1 mm depth noise, 1% holes; {world} spatial subvolumes, one per GPU",
+                "frames_per_step": B, "streams": 1,
+                "sharding": f"block ownership: floormod(block.x >> {slab_bits}, N)",
+                "directory_allgather_every_frames": B,
+            },
+            "frame_broadcast": {
+                "camera_rank": 0, "chunk_frames": C, "ring": fc.ring, "frames_ahead": fc.frames_ahead,
+                "bytes_per_frame": fc.stride + framecast.HEADER_BYTES, "in_timed_region": True,
+                "broadcast_gbps": round(bytes_timed / dt / 1e9, 2), "backend": backend,
+                "note": "one dist.broadcast per chunk on a side stream into a ring of device buffers, event-ordered "
+                        "against the engine's stream both ways; rate = payload delivered to every rank / wall time "
+                        "of the timed region (the broadcasts overlap the integration)"},
+            "directory_blocks_all_ranks": int(sum(len(x) for x in per_rank)),
+            "directory_union_blocks": int(union),
+            "directory_delta_entries_last_step_rank0": list(ex.last_sent),
+            "shards": shares,
+            "frame": {"avg_visible_blocks": round(V, 1), "avg_updated_voxels": round(U, 1), "alg_bytes": round(b_alg),
+                      "active_blocks": stats["active_blocks"], "note": "rank 0's subvolume"},
+            "roofline": roof, "cpu_baseline": None, "parity": parity,
+        }
+    eng.close()
+    return out
+
+
 def self_launch(a):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks as CHILD processes through
     torch.distributed.run (one rank per GPU over RCCL, rendezvous on 127.0.0.1), forward what they print and
@@ -387,7 +546,10 @@ def self_launch(a):
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes of one node)
+    # This pool's host driver supports dmabuf IPC only: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's intra-node
+    # set-up fails in hipIpcGetMemHandle ("invalid argument").  The image exports it already (so does the GPU
+    # box); setdefault only covers a caller that scrubbed the environment, and never overrides a value.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
     r = subprocess.run(cmd, env=env)
@@ -448,10 +610,16 @@ def main():
             a.cpu_frames = 8             # parity on the first frames only (the CPU runs ~30 frames/s)
         a.host_frames = 0
         a.streams = 0
+    if a.shard and world > 1:   # BASELINE configs[3]: one stream, N subvolumes, frames broadcast from rank 0
+        out = bench_sharded_stream(a, rank, world, dev, dev_index, backend, torch, dist, ratsdf)
+        if rank == 0:
+            print(json.dumps(out))
+        dist.destroy_process_group()
+        return
     vs = a.voxel
     B = a.frames_per_step
     half = (B + 1) // 2
-    frames = make_stream(a.scene, a.cam, half, phase=0 if a.shard else 45 * rank)
+    frames = make_stream(a.scene, a.cam, half, phase=45 * rank)
     frames = frames[:B] if len(frames) >= B else frames
     H, W = frames[0]["depth"].shape
     # resident inputs
@@ -520,7 +688,10 @@ def main():
             ex.fill_from_engine(eng)
         else:
             ex.fill_from_numpy(eng.dump_directory()[1])
-        ex.all_gather()
+        try:
+            ex.all_gather()
+        except OverflowError:   # a delta larger than the payload: every rank raises together and the exchange has
+            pass                # restarted (whole directories next time): nothing to do here
 
     batch = eng.make_batch([t.data_ptr() for t in d_rgb], [t.data_ptr() for t in d_depth],
                            [t.data_ptr() for t in d_ht], [t.data_ptr() for t in d_lt], H, W,
@@ -634,19 +805,20 @@ def main():
                               "page-locked ring (4.6 MB/frame, 4 threads), H2D on a copy stream, frame enqueued; "
                               "one synchronisation at the end of the timed region; batched = "
                               "ratsdf_integrate_batch, 8 frames per call from pageable memory")
-        # page-locked copies of the stream's frames
-        # (one block per frame, its images side by side as depth | ht | lt | rgb: the order of the engine's
-        # staging slot, so a frame goes up as ONE copy -- include/ratsdf.h, ratsdf_integrate_batch)
-        pin, blocks = [], []
+        # page-locked copies of the stream's frames: ONE arena, a block of 16 bytes per pixel per frame, the
+        # frame's images side by side in it as depth | ht | lt | rgb -- the order and stride of the engine's staging
+        # ring, so a frame goes up as one copy and neighbouring frames up to four per copy (include/ratsdf.h,
+        # ratsdf_integrate_batch; ratsdf::TSDFSystem's queue lays its frames out the same way)
+        pin = []
         npx = frames[0]["depth"].size
-        for f in frames:
-            blk = hp.host_alloc((npx * 15,), np.uint8)
-            blocks.append(blk)
+        arena = hp.host_alloc((len(frames) * npx * 16,), np.uint8)
+        for i, f in enumerate(frames):
+            blk = arena[i * npx * 16:(i + 1) * npx * 16]
             g = dict(f)
             g["depth"] = blk[:npx * 4].view(np.float32).reshape(f["depth"].shape)
             g["ht"] = blk[npx * 4:npx * 8].view(np.float32).reshape(f["ht"].shape)
             g["lt"] = blk[npx * 8:npx * 12].view(np.float32).reshape(f["lt"].shape)
-            g["rgb"] = blk[npx * 12:].reshape(f["rgb"].shape)
+            g["rgb"] = blk[npx * 12:npx * 15].reshape(f["rgb"].shape)
             for k in ("rgb", "depth", "ht", "lt"):
                 g[k][...] = f[k]
             pin.append(g)
@@ -663,12 +835,11 @@ def main():
         tp = time.perf_counter() - tp
         pinned_path = dict(frames_per_s=round(npin / tp, 1), frames=npin,
                            h2d_gbps=round(npin * bytes_per_frame / tp / 1e9, 1), link_gbps_spec=63.0,
-                           note=f"ratsdf_integrate_batch(pinned=1), {len(chunks[0])} frames per call from "
-                                "ratsdf_host_alloc blocks (one per frame, depth | ht | lt | rgb: one copy per "
-                                "frame): uploads on the engine's two copy streams up to 7 frames ahead of the "
-                                "integration, one sync per call")
-        for blk in blocks:
-            hp.host_free(blk)
+                           note=f"ratsdf_integrate_batch(pinned=1), {len(chunks[0])} frames per call from one "
+                                "ratsdf_host_alloc arena (a 16 B/pixel block per frame, depth | ht | lt | rgb): up to "
+                                "4 neighbouring frames per copy, on the engine's two copy streams, up to 15 frames "
+                                "ahead of the integration, one sync per call")
+        hp.host_free(arena)
         hp.close()
 
     # ---- S streams on this GPU through one launch triple per frame step ------------------------

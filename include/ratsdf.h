@@ -167,7 +167,9 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
  * blocks until all n frames are integrated (like n calls of ratsdf_integrate).  `pinned` != 0 says
  * that every image buffer comes from ratsdf_host_alloc (uploaded without a staging copy); a frame
  * whose four images lie side by side in one such block in the order depth | ht | lt | rgb goes up as
- * one copy instead of four (~10 us of copy-engine overhead each). */
+ * one copy instead of four (~10 us of copy-engine overhead each), and consecutive frames whose blocks
+ * lie side by side at a stride of 16 bytes per pixel (ratsdf::TSDFSystem's queue hands them out so) go
+ * up up to four at a time. */
 int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
                            const float* const* depth, const float* const* ht,
                            const float* const* lt, int height, int width, float max_depth,

@@ -85,7 +85,8 @@ __global__ void k_init_heap(int32_t* heap, int32_t n) {   // heap_init_kernel, v
 constexpr uint32_t kSlowCap = kSlowSortCap;
 constexpr int kDefaultVPL = 2;  // voxels per lane in k_integrate (RATSDF_VPL=2|4|8 overrides: tuning)
 constexpr uint32_t kSlowDelCap = 1u << 16;
-constexpr int kStageSlots = 8;
+constexpr int kStageSlots = 16;  // frames of the host-image entry points in flight (uploads run ahead)
+constexpr int kUploadRun = 4;    // frames that go up with one copy when they lie side by side in page-locked memory
 
 }  // namespace
 
@@ -100,8 +101,16 @@ class HostCopyPool {
     const void* src;
     size_t bytes;
   };
+  // (thread creation can fail -- RLIMIT_NPROC, a cgroup's pids limit -- and nothing may be thrown through the C
+  // ABI: the pool carries on with the helpers that did start; with none, copy() is a plain memcpy loop)
   explicit HostCopyPool(unsigned helpers) {
-    for (unsigned i = 0; i < helpers; ++i) threads_.emplace_back([this] { run(); });
+    for (unsigned i = 0; i < helpers; ++i) {
+      try {
+        threads_.emplace_back([this] { run(); });
+      } catch (...) {
+        break;
+      }
+    }
   }
   ~HostCopyPool() {
     {
@@ -254,8 +263,8 @@ struct ratsdf_engine {
   size_t stage_pix = 0;
   uint8_t* h_stage = nullptr;  // pinned
   uint8_t* d_stage = nullptr;
-  hipEvent_t stage_ev[8] = {};  // upload of the slot's last user has been executed
-  hipEvent_t use_ev[9] = {};    // the frame that read the slot has been executed (+1: call fence)
+  hipEvent_t stage_ev[kStageSlots] = {};  // upload of the slot's last user has been executed
+  hipEvent_t use_ev[kStageSlots + 1] = {};  // the frame that read the slot has been executed (+1: call fence)
   hipStream_t copy_stream = nullptr;   // uploads of ratsdf_integrate_batch: even frames
   hipStream_t copy_stream2 = nullptr;  // ... odd frames (two copy engines: one sustains ~31 GB/s)
   // ratsdf_integrate (one frame of host images per call) uses the same slots as a ring and does not wait for
@@ -284,7 +293,10 @@ struct ratsdf_engine {
   uint64_t graph_clock = 0;
   void free_graph(BatchGraph& g);
   int batch_graph(int n, int H, int W, BatchGraph** out);
-  int record_version = 0;                // bumped by upload_record (graphs read the record through d_eng)
+  struct GraphShape {
+    int H, W, n;
+  };
+  std::vector<GraphShape> graph_failed;  // shapes whose capture failed once: launched frame by frame from then on
 
   // profiling of the dominant kernel
   bool profiling = false;
@@ -832,7 +844,12 @@ int ratsdf_engine::batch_graph(int n, int H, int W, BatchGraph** out) {
       *out = &g;
       return RATSDF_OK;
     }
-  if (graphs.size() >= 6) {  // least recently used out
+  for (const auto& f : graph_failed)
+    if (f.H == H && f.W == W && f.n == n) return RATSDF_ERR_DEVICE;  // (reported when it happened)
+  // A graph per batch LENGTH: a caller that drains a queue (ratsdf::TSDFSystem hands over 1 .. 32 frames) meets
+  // every length sooner or later, so the cache holds all of them for a couple of image sizes before anything is
+  // evicted (a graph is ~0.2 KiB of job table per frame plus the executable graph).
+  if (graphs.size() >= 72) {  // least recently used out
     size_t victim = 0;
     for (size_t i = 1; i < graphs.size(); ++i)
       if (graphs[i].last_use < graphs[victim].last_use) victim = i;
@@ -848,6 +865,7 @@ int ratsdf_engine::batch_graph(int n, int H, int W, BatchGraph** out) {
     fprintf(stderr, "[ratsdf] batch graph %dx%d x %d: %s failed; batches of this shape are launched frame by frame\n",
             W, H, n, what);
     free_graph(g);
+    graph_failed.push_back(GraphShape{H, W, n});
     return RATSDF_ERR_DEVICE;
   };
   if (hipMalloc(&g.d_jobs, (size_t)n * sizeof(FrameJob)) != hipSuccess) return fail("hipMalloc");
@@ -1200,7 +1218,10 @@ int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, c
   // nothing here waits for the GPU unless the ring is full -- the slot's previous upload (8 calls ago) must
   // have left its host memory before it is overwritten.  (Until round 4 every call ended with a stream
   // synchronisation: 2 700 frames/s at 640x480, a third of it the single-threaded staging copy.)
-  const size_t slot_bytes = npix * 16;
+  // (the slot stride is the ring's, not this call's: a smaller image after a larger one must land in the SAME slot
+  // memory the slot's events guard -- with a per-call stride its bytes would fall inside other slots that frames of
+  // earlier calls, which are not waited for, may still be reading)
+  const size_t slot_bytes = e->stage_pix * 16;
   const int slot = (int)(e->single_no++ % kStageSlots);
   uint8_t* h = e->h_stage + (size_t)slot * slot_bytes;
   uint8_t* d = e->d_stage + (size_t)slot * slot_bytes;
@@ -1278,25 +1299,40 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
   const size_t npix = (size_t)height * width;
   int st = e->ensure_stage(npix);
   if (st != RATSDF_OK) return st;
-  const size_t slot_bytes = npix * 16;
+  const size_t slot_bytes = e->stage_pix * 16;  // the ring's stride (see ratsdf_integrate)
   auto sem = [&](int i) { return ht && lt && ht[i] && lt[i]; };  // tsdf_module.cc:27-31
   // Uploads run on their own stream, up to kStageSlots frames ahead of the frames that use them, so
   // the PCIe copy of later frames overlaps the integration of earlier ones (one stream would
   // serialise them).  Per device slot: up_ev = its upload has been executed, use_ev = the frame that
   // read it has been executed.  Layout of a slot: depth | ht | lt | rgb.
   static const bool two_streams = !(getenv("RATSDF_COPY_STREAMS") && atoi(getenv("RATSDF_COPY_STREAMS")) == 1);
-  auto upload = [&](int i) -> int {
-    const int slot = i % kStageSlots;
-    hipStream_t cs = ((i & 1) && two_streams) ? e->copy_stream2 : e->copy_stream;
-    uint8_t* d = e->d_stage + (size_t)slot * slot_bytes;
-    if (i >= kStageSlots) HIPCHK(hipStreamWaitEvent(cs, e->use_ev[slot], 0));
+  // a frame whose four images lie side by side in one page-locked block in the slot's own order (ratsdf::TSDFSystem's
+  // queue keeps them so): one copy instead of four -- each costs ~10 us of launch overhead on the copy engine
+  auto packed = [&](int i) {
     const uint8_t* h0 = reinterpret_cast<const uint8_t*>(depth[i]);
-    if (pinned && sem(i) && reinterpret_cast<const uint8_t*>(ht[i]) == h0 + npix * 4 &&
-        reinterpret_cast<const uint8_t*>(lt[i]) == h0 + npix * 8 &&
-        reinterpret_cast<const uint8_t*>(rgb[i]) == h0 + npix * 12) {
-      // the caller keeps a frame's four images side by side in the slot's own order (ratsdf::TSDFSystem's
-      // queue does): one copy instead of four -- each costs ~10 us of launch overhead on the copy engine
-      HIPCHK(hipMemcpyAsync(d, h0, npix * 15, hipMemcpyHostToDevice, cs));
+    return pinned && sem(i) && reinterpret_cast<const uint8_t*>(ht[i]) == h0 + npix * 4 &&
+           reinterpret_cast<const uint8_t*>(lt[i]) == h0 + npix * 8 &&
+           reinterpret_cast<const uint8_t*>(rgb[i]) == h0 + npix * 12;
+  };
+  unsigned copy_no = 0;
+  // uploads frames [i, i + *took), *took <= max_run: more than one when the frames are packed blocks that lie side
+  // by side in host memory at the ring's own stride (the blocks of one arena of ratsdf::HostBlockPool) and their
+  // slots do not wrap -- then ONE copy fills the slots (16 bytes per pixel: the 15 the frame has + the slot's pad)
+  auto upload = [&](int i, int max_run, int* took) -> int {
+    const int slot = i % kStageSlots;
+    int run = 1;
+    if (packed(i) && npix == e->stage_pix)
+      while (run < max_run && i + run < n && slot + run < kStageSlots && packed(i + run) &&
+             reinterpret_cast<const uint8_t*>(depth[i + run]) == reinterpret_cast<const uint8_t*>(depth[i]) + (size_t)run * slot_bytes)
+        ++run;
+    *took = run;
+    hipStream_t cs = ((copy_no++ & 1) && two_streams) ? e->copy_stream2 : e->copy_stream;
+    uint8_t* d = e->d_stage + (size_t)slot * slot_bytes;
+    for (int j = 0; j < run; ++j)
+      if (i + j >= kStageSlots) HIPCHK(hipStreamWaitEvent(cs, e->use_ev[slot + j], 0));
+    const uint8_t* h0 = reinterpret_cast<const uint8_t*>(depth[i]);
+    if (packed(i)) {
+      HIPCHK(hipMemcpyAsync(d, h0, (size_t)(run - 1) * slot_bytes + npix * 15, hipMemcpyHostToDevice, cs));
     } else if (pinned) {  // straight from the caller's page-locked buffers
       HIPCHK(hipMemcpyAsync(d, depth[i], npix * 4, hipMemcpyHostToDevice, cs));
       if (sem(i)) {
@@ -1322,9 +1358,14 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
       } else {
         for (int q = 0; q < np; ++q) memcpy(pieces[q].dst, pieces[q].src, pieces[q].bytes);
       }
-      HIPCHK(hipMemcpyAsync(d, h, sem(i) ? npix * 15 : slot_bytes, hipMemcpyHostToDevice, cs));
+      if (sem(i)) {
+        HIPCHK(hipMemcpyAsync(d, h, npix * 15, hipMemcpyHostToDevice, cs));
+      } else {  // depth | (no ht, lt) | rgb
+        HIPCHK(hipMemcpyAsync(d, h, npix * 4, hipMemcpyHostToDevice, cs));
+        HIPCHK(hipMemcpyAsync(d + npix * 12, h + npix * 12, npix * 3, hipMemcpyHostToDevice, cs));
+      }
     }
-    HIPCHK(hipEventRecord(e->stage_ev[slot], cs));
+    for (int j = 0; j < run; ++j) HIPCHK(hipEventRecord(e->stage_ev[slot + j], cs));
     return RATSDF_OK;
   };
   auto input = [&](int i) {
@@ -1350,14 +1391,18 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
   HIPCHK(hipEventRecord(e->use_ev[kStageSlots], e->stream));
   HIPCHK(hipStreamWaitEvent(e->copy_stream, e->use_ev[kStageSlots], 0));
   HIPCHK(hipStreamWaitEvent(e->copy_stream2, e->use_ev[kStageSlots], 0));
-  const int ahead = kStageSlots - 1;  // uploads enqueued ahead of the frame being launched
+  // Uploads are enqueued up to `ahead` frames in front of the frame being launched: slot (u % kStageSlots) was last
+  // read by frame u - kStageSlots, whose use_ev must have been RECORDED (i.e. that frame launched) before a copy
+  // stream is told to wait for it.
+  const int ahead = kStageSlots - 1;
   int uploaded = 0;
   for (int i = 0; i < n; ++i) {
     // frame i's launches host the look-ahead of frame i+1: both uploads precede them
     while (uploaded < n && uploaded <= i + 1) {
-      st = upload(uploaded);
+      int took = 0;
+      st = upload(uploaded, std::min(kUploadRun, i + ahead - uploaded + 1), &took);
       if (st != RATSDF_OK) return fail(st);
-      ++uploaded;
+      uploaded += took;
     }
     if (hipStreamWaitEvent(e->stream, e->stage_ev[i % kStageSlots], 0) != hipSuccess ||
         (i + 1 < n && hipStreamWaitEvent(e->stream, e->stage_ev[(i + 1) % kStageSlots], 0) != hipSuccess))
@@ -1370,11 +1415,15 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
     // frame i's images were last read by its candidate pass, which ran in frame i-1's launches or
     // before; recording after frame i is the simple, safe point
     if (hipEventRecord(e->use_ev[i % kStageSlots], e->stream) != hipSuccess) return fail(RATSDF_ERR_DEVICE);
-    // run further ahead with the uploads while the queue is busy
-    while (uploaded < n && uploaded <= i + ahead) {
-      st = upload(uploaded);
+    // run further ahead with the uploads while the queue is busy -- in whole runs (or the batch's tail), so that
+    // side-by-side frames keep going up together instead of one by one as slots fall free
+    while (uploaded < n) {
+      const int want = std::min(kUploadRun, n - uploaded);
+      if (uploaded + want - 1 > i + ahead) break;
+      int took = 0;
+      st = upload(uploaded, want, &took);
       if (st != RATSDF_OK) return fail(st);
-      ++uploaded;
+      uploaded += took;
     }
   }
   st = e->sticky();

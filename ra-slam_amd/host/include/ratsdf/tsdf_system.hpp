@@ -28,22 +28,44 @@ namespace ratsdf {
 struct HostBlock {
   void* ptr = nullptr;
   size_t bytes = 0;
+  bool pinned = true;  // false: page-locked memory ran out, the block is ordinary memory (the engine stages it)
 };
 
 // Page-locked blocks (Api::host_alloc) recycled between frames: the queue's deep copies live in them
 // so that the worker uploads without a second copy.
+//   * Blocks come from ARENAS of kArenaBlocks consecutive blocks (one host_alloc each) and the free block of
+//     lowest address goes out first, so the frames of a batch usually lie side by side in memory and the
+//     engine uploads runs of them with one copy (include/ratsdf.h, ratsdf_integrate_batch).
+//   * Nothing is given back to the system while frames flow: release() parks.  trim() -- called by the worker
+//     when its queue has drained -- returns whole idle arenas beyond kParkedBytes.  (Until round 5 release()
+//     itself enforced a 256 MiB cap = 52 blocks at 640x480, below the 2 x 32 frames + queue a running system
+//     has in flight: every further frame was a hipHostMalloc + hipHostFree pair.)
+//   * A failed allocation is not fatal: the block is ordinary memory (pinned = false) and the batch that
+//     contains it is handed over as pageable.
 class HostBlockPool {
  public:
+  static constexpr size_t kArenaBlocks = 8;
+  static constexpr size_t kParkedBytes = (size_t)256 << 20;
   explicit HostBlockPool(const Api* api) : api_(api) {}
   ~HostBlockPool();
   HostBlock acquire(size_t bytes);
   void release(const HostBlock& b);
-  bool pinned() const { return true; }
+  void trim();
+  // host_alloc / host_free calls so far (a steady stream of equal-sized frames must not move them)
+  size_t system_allocs() const { return allocs_; }
+  size_t system_frees() const { return frees_; }
 
  private:
+  struct Arena {
+    uint8_t* base = nullptr;
+    size_t block_bytes = 0, blocks = 0, in_use = 0;
+    bool pinned = true;
+  };
   const Api* api_;
   std::mutex mtx_;
-  std::vector<HostBlock> free_;
+  std::vector<Arena> arenas_;
+  std::vector<HostBlock> free_;  // sorted by address, descending (the lowest is at the back)
+  size_t allocs_ = 0, frees_ = 0;
 };
 
 // The deep copy of a frame into its queue element (cv::Mat::clone x 4, tsdf_module.cc:28-35: 4.6 MB at
@@ -108,6 +130,8 @@ class TSDFSystem {
   size_t QueueSize();
   int NumActiveBlock();
   size_t frames_integrated();
+  size_t pool_system_allocs() { return pool_.system_allocs(); }   // host_alloc calls of the queue's block pool
+  size_t pool_system_frees() { return pool_.system_frees(); }
 
  private:
   void Run();

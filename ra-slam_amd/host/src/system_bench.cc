@@ -81,6 +81,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 2 * n && i < 64; ++i) push(fr[(size_t)(i % n)]);  // warm-up: map built, pools filled
   sys.Flush();
   size_t max_queue = 0;
+  const size_t allocs0 = sys.pool_system_allocs(), frees0 = sys.pool_system_frees();
   const auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < total; ++i) {
     const int k = i % (2 * n);
@@ -90,12 +91,15 @@ int main(int argc, char** argv) {
   const double t_push = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   sys.Flush();
   const double t_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  // page-locked allocations / frees of the queue's block pool INSIDE the timed region (0 / 0 once the pool is warm)
+  const size_t pool_allocs = sys.pool_system_allocs() - allocs0, pool_frees = sys.pool_system_frees() - frees0;
   const double bytes = (double)npix * (sem ? 15.0 : 7.0);
   printf("{\"frames\": %d, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"producer_seconds\": %.4f, "
          "\"producer_frames_per_s\": %.1f, \"h2d_gbps\": %.2f, \"max_queue\": %zu, \"semantics\": %s, "
-         "\"width\": %d, \"height\": %d, \"active_blocks\": %d}\n",
+         "\"width\": %d, \"height\": %d, \"active_blocks\": %d, \"pool_allocs_steady_state\": %zu, "
+         "\"pool_frees_steady_state\": %zu}\n",
          total, t_all, total / t_all, t_push, total / t_push, total * bytes / t_all / 1e9, max_queue,
-         sem ? "true" : "false", W, H, sys.NumActiveBlock());
+         sem ? "true" : "false", W, H, sys.NumActiveBlock(), pool_allocs, pool_frees);
   sys.terminate();
   return 0;
 }

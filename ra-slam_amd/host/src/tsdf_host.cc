@@ -201,41 +201,87 @@ int TSDFGrid::NumActiveBlock() {
 
 // ---- page-locked block pool -----------------------------------------------------------------
 HostBlock HostBlockPool::acquire(size_t bytes) {
-  {
-    std::lock_guard<std::mutex> lock(mtx_);
-    for (size_t i = 0; i < free_.size(); ++i)
-      if (free_[i].bytes == bytes) {
-        const HostBlock b = free_[i];
-        free_.erase(free_.begin() + (long)i);
-        return b;
-      }
+  std::lock_guard<std::mutex> lock(mtx_);
+  for (size_t i = free_.size(); i-- > 0;)  // lowest address first
+    if (free_[i].bytes == bytes) {
+      const HostBlock b = free_[i];
+      free_.erase(free_.begin() + (long)i);
+      for (Arena& a : arenas_)
+        if (static_cast<uint8_t*>(b.ptr) >= a.base && static_cast<uint8_t*>(b.ptr) < a.base + a.block_bytes * a.blocks)
+          ++a.in_use;
+      return b;
+    }
+  // a new arena; under memory pressure a single block; without page-locked memory an ordinary one
+  Arena a;
+  a.block_bytes = bytes;
+  void* base = nullptr;
+  for (size_t blocks : {kArenaBlocks, (size_t)1}) {
+    ++allocs_;
+    if (api_->host_alloc(bytes * blocks, &base) == RATSDF_OK && base) {
+      a.blocks = blocks;
+      break;
+    }
+    base = nullptr;
   }
-  HostBlock b;
-  b.bytes = bytes;
-  if (api_->host_alloc(bytes, &b.ptr) != RATSDF_OK || !b.ptr) {
-    fprintf(stderr, "[ratsdf] cannot allocate %zu bytes of page-locked memory\n", bytes);
-    abort();
+  if (!base) {
+    fprintf(stderr, "[ratsdf] no page-locked memory for a %zu-byte frame block: using pageable memory\n", bytes);
+    base = malloc(bytes);
+    if (!base) return HostBlock{nullptr, bytes, false};  // the caller drops the frame and reports it
+    a.blocks = 1;
+    a.pinned = false;
   }
-  return b;
+  a.base = static_cast<uint8_t*>(base);
+  a.in_use = 1;
+  arenas_.push_back(a);
+  for (size_t k = a.blocks; k-- > 1;) {
+    const HostBlock b{a.base + k * bytes, bytes, a.pinned};
+    free_.insert(std::lower_bound(free_.begin(), free_.end(), b,
+                                  [](const HostBlock& x, const HostBlock& y) { return x.ptr > y.ptr; }), b);
+  }
+  return HostBlock{a.base, bytes, a.pinned};
 }
 
 void HostBlockPool::release(const HostBlock& b) {
-  {
-    std::lock_guard<std::mutex> lock(mtx_);
-    // page-locked memory is not reclaimable: keep at most 256 MiB of it parked per TSDFSystem (52 blocks at
-    // 640x480, 17 at 1280x720 -- more than the two batches of kMaxBatch frames that are ever in flight)
-    size_t parked = 0;
-    for (const HostBlock& f : free_) parked += f.bytes;
-    if (parked + b.bytes <= ((size_t)256 << 20)) {
-      free_.push_back(b);
-      return;
+  if (!b.ptr) return;
+  std::lock_guard<std::mutex> lock(mtx_);
+  for (Arena& a : arenas_)
+    if (static_cast<uint8_t*>(b.ptr) >= a.base && static_cast<uint8_t*>(b.ptr) < a.base + a.block_bytes * a.blocks)
+      --a.in_use;
+  free_.insert(std::lower_bound(free_.begin(), free_.end(), b,
+                                [](const HostBlock& x, const HostBlock& y) { return x.ptr > y.ptr; }), b);
+}
+
+// Whole idle arenas beyond kParkedBytes of parked memory go back to the system (page-locked memory is not
+// reclaimable by anybody else).  Called when no frame is queued or in flight.
+void HostBlockPool::trim() {
+  std::lock_guard<std::mutex> lock(mtx_);
+  size_t parked = 0;
+  for (const HostBlock& f : free_) parked += f.bytes;
+  for (size_t i = arenas_.size(); i-- > 0 && parked > kParkedBytes;) {
+    const Arena a = arenas_[i];
+    if (a.in_use) continue;
+    free_.erase(std::remove_if(free_.begin(), free_.end(),
+                               [&](const HostBlock& f) {
+                                 return static_cast<uint8_t*>(f.ptr) >= a.base &&
+                                        static_cast<uint8_t*>(f.ptr) < a.base + a.block_bytes * a.blocks;
+                               }),
+                free_.end());
+    if (a.pinned) {
+      ++frees_;
+      api_->host_free(a.base);
+    } else {
+      free(a.base);
     }
+    parked -= a.block_bytes * a.blocks;
+    arenas_.erase(arenas_.begin() + (long)i);
   }
-  api_->host_free(b.ptr);
 }
 
 HostBlockPool::~HostBlockPool() {
-  for (const HostBlock& b : free_) api_->host_free(b.ptr);
+  for (const Arena& a : arenas_) {
+    if (a.pinned) api_->host_free(a.base);
+    else free(a.base);
+  }
 }
 
 // ---- parallel clone ---------------------------------------------------------------------------
@@ -320,6 +366,10 @@ void TSDFSystem::Integrate(const SE3<float>& posecam_T_world, const Image& rgb, 
   // worker can upload it without another copy.  Missing ht / lt stay missing: the engine treats
   // them as the all-ones images the reference would build here (tsdf_module.cc:29-31).
   in->block = pool_.acquire(npix * 16);
+  if (!in->block.ptr) {  // no memory at all for the queue's copy: the frame is dropped, like a reference run
+    fprintf(stderr, "[TSDF System] out of memory: frame dropped\n");  // whose cv::Mat::clone threw
+    return;
+  }
   in->has_sem = !(ht.empty() || lt.empty());
   uint8_t* b = static_cast<uint8_t*>(in->block.ptr);
   {
@@ -400,7 +450,9 @@ void TSDFSystem::Run() {
       std::vector<const uint8_t*> rgb(n);
       std::vector<const float*> depth(n), ht(n), lt(n);
       std::vector<SE3<float>> poses(n);
+      bool pinned = true;
       for (size_t i = 0; i < n; ++i) {
+        pinned = pinned && batch[i]->block.pinned;
         const uint8_t* b = static_cast<const uint8_t*>(batch[i]->block.ptr);
         depth[i] = reinterpret_cast<const float*>(b);
         ht[i] = batch[i]->has_sem ? reinterpret_cast<const float*>(b + npix * 4) : nullptr;
@@ -409,15 +461,18 @@ void TSDFSystem::Run() {
         poses[i] = batch[i]->cam_T_world;
       }
       tsdf_.IntegrateBatch((int)n, rgb.data(), depth.data(), ht.data(), lt.data(), batch[0]->rows,
-                           batch[0]->cols, max_depth_, intrinsics_, poses.data(), pool_.pinned());
+                           batch[0]->cols, max_depth_, intrinsics_, poses.data(), pinned);
     }
     for (auto& in : batch) pool_.release(in->block);
+    bool idle;
     {
       std::lock_guard<std::mutex> lock(mtx_queue_);
       busy_ = false;
       frames_done_ += batch.size();
+      idle = inputs_.empty();
     }
     cv_queue_.notify_all();
+    if (idle) pool_.trim();  // (only when nothing is queued: the steady state never returns memory)
   }
 }
 

@@ -144,6 +144,7 @@ class DirectoryDeltaExchange(DirectoryExchange):
         self._replica = [torch.zeros((0, 3), **i32) for _ in range(self.world)]
         self.last_sent = (0, 0)
         self._last_counts = None
+        self.resyncs = 0                                           # exchanges restarted because an engine's delete log overflowed
 
     def _restart(self):
         """Back to the state before the first exchange: the next one carries whole directories again (in
@@ -241,6 +242,15 @@ class DirectoryDeltaExchange(DirectoryExchange):
         rows = recv.reshape(self.world, 2 + 3 * (C + 1))
         counts = rows[:, :2].cpu()
         self._last_counts = counts
+        if any(int(counts[r, 1]) == 0x7FFFFFFF for r in range(self.world)):
+            # An engine could not log its deletes (ratsdf_export_directory_delta_device: a frame that carves more
+            # than kSmallCarve blocks inside a batch -- a new view, a large move -- is finalised where logging is
+            # not possible, and the log itself is finite): its delta is unusable.  Ordinary operation, not an
+            # error: every rank reads the same counts, so every rank restarts together and the next exchange
+            # carries whole directories; the replicas stay as they were until then.
+            self._restart()
+            self.resyncs += 1
+            return True
         over = [(r, int(counts[r, 0]), int(counts[r, 1])) for r in range(self.world)
                 if int(counts[r, 0]) + int(counts[r, 1]) > C]
         if over:   # every rank sees the same counts: every rank raises, nobody is left in a collective
@@ -261,12 +271,15 @@ class DirectoryDeltaExchange(DirectoryExchange):
                 rep = rep[~torch.isin(self._pos_key(rep), self._pos_key(drop))]
             rep = torch.cat([rep, body[:na].clone()])
             self._replica[r] = rep[torch.argsort(self._pos_key(rep))]
+        return False
 
     def flush(self):
-        """apply what has been received (reads the last collective's counts: waits for it)"""
+        """apply what has been received (reads the last collective's counts: waits for it); True = the exchange
+        restarted instead (an engine's delete log had overflowed): the next one carries whole directories"""
         if self._todo is not None:
             (todo, C), self._todo = self._todo, None
-            self._apply(todo, C)
+            return self._apply(todo, C)
+        return False
 
     def all_gather(self):
         torch = self.torch
@@ -281,6 +294,7 @@ class DirectoryDeltaExchange(DirectoryExchange):
             self._make_delta()
         recv = self.recv2[self._slot % len(self.recv2)]
         self._slot += 1
+        C = self._C
         if self.world == 1:
             recv.copy_(self.send)
         else:
@@ -289,8 +303,9 @@ class DirectoryDeltaExchange(DirectoryExchange):
             ev2 = torch.cuda.Event()
             ev2.record(torch.cuda.current_stream(self.device))
             es.wait_event(ev2)
-        self.flush()          # the PREVIOUS exchange (finished long ago): no stall
-        self._todo = (recv, self._C)
+        if self.flush():      # the PREVIOUS exchange (finished long ago): no stall
+            return            # ... it restarted the exchange: this one's deltas build on replicas nobody has
+        self._todo = (recv, C)
         if self._first:       # from now on: deltas, in the smaller payload buffers
             self._first = False
             self.flush()      # (the pool-sized buffers are released)
@@ -443,6 +458,57 @@ def export_blocks(engine, positions):
     return pos, t, c, p
 
 
+def _gather_block_data(part, nmax, world, device):
+    """all-gather of the voxel data of up to `nmax` blocks per rank (an export_blocks() tuple; tsdf | rgbw | prob as
+    3 x 512 int32 words per block): list of [nmax, 1536] int32 numpy arrays, one per rank.  One
+    all_gather_into_tensor on `device` (cuda under "nccl"; None = CPU tensors for gloo)."""
+    import torch
+    import torch.distributed as dist
+    pos, t, c, p = part
+    send = np.zeros((nmax, 3 * 512), dtype=np.int32)
+    if len(pos):
+        send[:len(pos), 0:512] = t.view(np.int32)
+        send[:len(pos), 512:1024] = np.ascontiguousarray(c).view(np.int32).reshape(-1, 512)
+        send[:len(pos), 1024:1536] = p.view(np.int32)
+    if world == 1:
+        return [send]
+    dev = device if device is not None else "cpu"
+    s_t = torch.from_numpy(send).to(dev).reshape(-1)
+    r_t = torch.empty(world * s_t.numel(), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(r_t, s_t)
+    got = r_t.cpu().numpy().reshape(world, nmax, 3 * 512)
+    return [got[q] for q in range(world)]
+
+
+def _gather_arrays(arrays, world, device):
+    """all-gather of a few flat numpy arrays whose lengths differ between ranks: list over ranks of lists of arrays
+    (same dtypes as `arrays`).  Two collectives (byte lengths, padded payload) on `device`."""
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else "cpu"
+    raw = [np.ascontiguousarray(a).reshape(-1).view(np.uint8) for a in arrays]
+    n = torch.tensor([len(r) for r in raw], dtype=torch.int64, device=dev)
+    ns = torch.zeros(world * len(raw), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(ns, n)
+    ns = ns.cpu().numpy().reshape(world, len(raw))
+    width = max(int(ns.sum(axis=1).max()), 1)
+    send = torch.zeros(width, dtype=torch.uint8, device=dev)
+    flat = np.concatenate(raw)
+    if len(flat):
+        send[:len(flat)].copy_(torch.from_numpy(flat.copy()))
+    recv = torch.empty(world * width, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    rows = recv.cpu().numpy().reshape(world, width)
+    out = []
+    for q in range(world):
+        o, parts = 0, []
+        for a, m in zip(arrays, ns[q]):
+            parts.append(rows[q, o:o + int(m)].copy().view(np.asarray(a).dtype))
+            o += int(m)
+        out.append(parts)
+    return out
+
+
 def mesh_with_halo(engine, scratch, halo):
     """The mesh of the blocks `engine` owns, with the cells on its subvolume's +x seam closed: `scratch` (a fresh
     engine with the same voxel size and shard parameters) receives the engine's own blocks and the neighbours'
@@ -458,13 +524,14 @@ def mesh_with_halo(engine, scratch, halo):
     return scratch.gather_valid_mesh()
 
 
-def mesh_across_shards(engine, make_scratch, per_rank):
+def mesh_across_shards(engine, make_scratch, per_rank, device=None):
     """TSDFSystem::DownloadAllMesh (tsdf_module.cc:66-86) of a map that is spread over ranks by block ownership:
     halo exchange (one all-gather of the seam blocks' voxel data, 6 KiB per block), per-rank meshing with the
     seam closed, one all-gather of the meshes.  `per_rank` = the replicated directories
     (DirectoryExchange.result()); `make_scratch()` builds an empty engine like `engine`.  Returns (vertices [n, 3],
     triangles [m, 3], vertex probability [n]) of the whole map on every rank; as a multiset of triangles it is the
-    mesh of the same map held by one engine."""
+    mesh of the same map held by one engine.  `device`: where the collectives' buffers live -- a torch cuda device
+    under backend "nccl" (RCCL takes device tensors only), None = CPU tensors (gloo), as multi.query."""
     import torch
     import torch.distributed as dist
     from ._abi import RGBW_DTYPE
@@ -474,24 +541,14 @@ def mesh_across_shards(engine, make_scratch, per_rank):
     # what I send to anybody, once; everybody knows everybody's list, so the buffers have agreed sizes
     out_lists = [sorted(set(p for r in range(world) for p in plan[q][r])) for q in range(world)]
     nmax = max(1, max(len(l) for l in out_lists))
-    pos, t, c, p = export_blocks(engine, out_lists[rank])
-    send = torch.zeros((nmax, 3 * 512), dtype=torch.int32)
-    if len(pos):
-        send[:len(pos), 0:512] = torch.from_numpy(t.view(np.int32))
-        send[:len(pos), 512:1024] = torch.from_numpy(np.ascontiguousarray(c).view(np.int32).reshape(-1, 512))
-        send[:len(pos), 1024:1536] = torch.from_numpy(p.view(np.int32))
-    if world > 1:
-        recv = [torch.zeros_like(send) for _ in range(world)]
-        dist.all_gather(recv, send)
-    else:
-        recv = [send]
+    recv = _gather_block_data(export_blocks(engine, out_lists[rank]), nmax, world, device)
     hp, ht, hc, hprob = [], [], [], []
     for q in range(world):
         if q == rank or not plan[q][rank]:
             continue
         row_of = {pp: i for i, pp in enumerate(out_lists[q])}
         rows = np.array([row_of[pp] for pp in plan[q][rank]], dtype=np.int64)
-        data = recv[q].numpy()[rows]
+        data = recv[q][rows]
         hp.append(np.array(plan[q][rank], dtype=np.int16))
         ht.append(data[:, 0:512].copy().view(np.float32))
         hc.append(data[:, 512:1024].copy().view(RGBW_DTYPE).reshape(-1, 512))
@@ -508,8 +565,9 @@ def mesh_across_shards(engine, make_scratch, per_rank):
         scratch.close()
     if world == 1:
         return v, tri, vp
-    parts = [None] * world
-    dist.all_gather_object(parts, (v, tri, vp))
+    parts = _gather_arrays([np.asarray(v, dtype=np.float32).reshape(-1), np.asarray(tri, dtype=np.int32).reshape(-1),
+                            np.asarray(vp, dtype=np.float32).reshape(-1)], world, device)
+    parts = [(a.reshape(-1, 3), b.reshape(-1, 3), c_) for a, b, c_ in parts]
     off, vs_, ts_, ps_ = 0, [], [], []
     for (vv, tt, pp) in parts:
         vs_.append(vv)
@@ -605,10 +663,12 @@ def raycast_strip(scratch, parts, intrinsics, height, width, pose, max_depth, ro
     return rgba[rows[0]:rows[1]].copy(), normal[rows[0]:rows[1]].copy()
 
 
-def raycast_across_shards(engine, make_scratch, per_rank, intrinsics, height, width, pose, max_depth, voxel_size):
+def raycast_across_shards(engine, make_scratch, per_rank, intrinsics, height, width, pose, max_depth, voxel_size,
+                          device=None):
     """TSDFGrid::RayCast of a map spread over ranks by block ownership (comment above): returns the whole
     (rgba, normal) images, H x W x 4 uint8, on every rank -- equal to one engine's rendering of the same map.
-    `per_rank` = the replicated directories; `make_scratch()` builds an empty, UNsharded engine."""
+    `per_rank` = the replicated directories; `make_scratch()` builds an empty, UNsharded engine; `device` as
+    mesh_across_shards (a cuda device under "nccl")."""
     import torch
     import torch.distributed as dist
     from ._abi import RGBW_DTYPE
@@ -619,24 +679,14 @@ def raycast_across_shards(engine, make_scratch, per_rank, intrinsics, height, wi
     # what I send to the others, once; everybody knows everybody's list, so the buffers have agreed sizes
     out_lists = [sorted(set(p for r in range(world) if r != q for p in plan[q][r])) for q in range(world)]
     nmax = max(1, max(len(l) for l in out_lists))
-    pos, t, c, p = export_blocks(engine, out_lists[rank])
-    send = torch.zeros((nmax, 3 * 512), dtype=torch.int32)
-    if len(pos):
-        send[:len(pos), 0:512] = torch.from_numpy(t.view(np.int32))
-        send[:len(pos), 512:1024] = torch.from_numpy(np.ascontiguousarray(c).view(np.int32).reshape(-1, 512))
-        send[:len(pos), 1024:1536] = torch.from_numpy(p.view(np.int32))
-    if world > 1:
-        recv = [torch.zeros_like(send) for _ in range(world)]
-        dist.all_gather(recv, send)
-    else:
-        recv = [send]
+    recv = _gather_block_data(export_blocks(engine, out_lists[rank]), nmax, world, device)
     parts = [export_blocks(engine, plan[rank][rank])]
     for q in range(world):
         if q == rank or not plan[q][rank]:
             continue
         row_of = {pp: i for i, pp in enumerate(out_lists[q])}
         rows = np.array([row_of[pp] for pp in plan[q][rank]], dtype=np.int64)
-        data = recv[q].numpy()[rows]
+        data = recv[q][rows]
         parts.append((np.array(plan[q][rank], dtype=np.int16), data[:, 0:512].copy().view(np.float32),
                       data[:, 512:1024].copy().view(RGBW_DTYPE).reshape(-1, 512),
                       data[:, 1024:1536].copy().view(np.float32)))
@@ -647,6 +697,6 @@ def raycast_across_shards(engine, make_scratch, per_rank, intrinsics, height, wi
         scratch.close()
     if world == 1:
         return mine
-    got = [None] * world
-    dist.all_gather_object(got, mine)
-    return np.concatenate([g[0] for g in got], axis=0), np.concatenate([g[1] for g in got], axis=0)
+    got = _gather_arrays([mine[0].reshape(-1), mine[1].reshape(-1)], world, device)
+    return (np.concatenate([g[0].reshape(-1, width, 4) for g in got], axis=0),
+            np.concatenate([g[1].reshape(-1, width, 4) for g in got], axis=0))

@@ -196,6 +196,31 @@ int main(int argc, char** argv) {
     CHECK(std::fabs(I.GetR().w) > 0.999999f && std::fabs(I.GetT().x) < 1e-6f);
   }
 
+  // 8: the queue's page-locked block pool.  A paused system lets 100 frames pile up (more than two batches of 32
+  // and more than the 52 blocks = 256 MiB-at-640x480 the round-4 pool parked before it freed on every release):
+  // the second round of the same load must not allocate or free anything, the map must be the frame-by-frame
+  // one, and an idle system gives memory back only beyond kParkedBytes (nothing at this image size).
+  {
+    TSDFSystem sys(vs, tr, md, K, SE3<float>::Identity(), 0, &api);
+    TSDFGrid ref(vs, tr, 0, &api);
+    auto load = [&](bool both) {
+      for (int i = 0; i < 100; ++i) {
+        const Frame& f = frames[(size_t)i % frames.size()];
+        sys.Integrate(f.pose, img(f.rgb), img(f.depth), img(f.ht), img(f.lt));
+        if (both) ref.Integrate(img(f.rgb), img(f.depth), img(f.ht), img(f.lt), md, K, f.pose);
+      }
+      sys.Flush();
+    };
+    load(true);
+    const size_t a0 = sys.pool_system_allocs(), f0 = sys.pool_system_frees();
+    CHECK(a0 >= 1 && a0 <= 100 / HostBlockPool::kArenaBlocks + 1 && f0 == 0);
+    load(true);
+    CHECK(sys.pool_system_allocs() == a0 && sys.pool_system_frees() == 0);
+    CHECK(sys.frames_integrated() == 200);
+    const BoundingCube<float> all{-10, 10, -10, 10, -10, 10};
+    CHECK(same(sys.Query(all), ref.GatherVoxels(all)));
+  }
+
   // bad arguments are reported, not fatal (the reference only asserts)
   {
     TSDFGrid g(vs, tr, 0, &api);

@@ -49,3 +49,28 @@ def test_two_ranks_through_the_plain_entry_point():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["streams"] == 2
     assert d["directory_blocks_all_ranks"] > 0          # the directory exchange ran
+
+
+@pytest.mark.gpu
+def test_one_stream_over_two_subvolume_ranks_through_the_plain_entry_point():
+    """BASELINE configs[3] end to end through `python bench.py --gpus 2 --shard`: rank 0 owns the stream, the frames
+    reach rank 1 by broadcast (inside the timed region), each rank integrates its subvolume (checked against the
+    sharded CPU oracle on the bytes it received), the directory deltas are all-gathered, and every block of the
+    union sits on its owner and nowhere else.  Both ranks on the one device, gloo instead of RCCL."""
+    r = _run(["--gpus", "2", "--shard", "--steps", "2", "--warmup", "1", "--reps", "1", "--frames-per-step", "12",
+              "--bcast-chunk", "4", "--cpu-frames", "4"],
+             {"RATSDF_BENCH_DEVICE": "0", "RATSDF_BENCH_BACKEND": "gloo"}, 600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["streams"] == 1 and d["value"] > 0
+    fb = d["frame_broadcast"]
+    assert fb["in_timed_region"] and fb["chunk_frames"] == 4 and fb["frames_ahead"] == 8 and fb["broadcast_gbps"] > 0
+    assert fb["bytes_per_frame"] == 640 * 480 * 15 + 64
+    # the directory exchange ran, and the union of the ranks' block sets is what check_sharded_directories expects:
+    # every block on its owner, on no other rank
+    assert d["directory_blocks_all_ranks"] == d["directory_union_blocks"] > 0
+    assert len(d["shards"]) == 2 and all(s["active_blocks"] > 0 for s in d["shards"])
+    assert sum(s["active_blocks"] for s in d["shards"]) == d["directory_union_blocks"]
+    assert d["parity"]["frames"] == 4 and d["parity"]["max_abs_tsdf"] == 0.0 and d["parity"]["max_abs_prob"] < 1e-4

@@ -494,3 +494,70 @@ def test_directory_delta_exchange_on_the_device(make_engine):
             sent.append((sum(ex.last_sent), len(want)))
     assert sent[0][0] == sent[0][1] and all(0 < d < n for d, n in sent[1:]), sent
     eng.synchronize()   # the export never touches the engine's sticky error
+
+
+def test_host_frames_of_alternating_sizes_without_waiting(make_engine, make_oracle):
+    """ratsdf_integrate does not wait for its frame (the images sit in a slot of the page-locked staging ring when
+    it returns).  The slots' stride belongs to the ring, not to the call: a smaller image after a larger one lands
+    in the slot its events guard, not inside the memory of other slots that earlier, still running frames read
+    (ADVICE r4).  40 calls alternating between two image sizes (the ring has 16 slots), one query at the end."""
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    big = synthetic.stream("room", 20, scale=0.5, noise=True, holes=True)
+    small = synthetic.stream("room", 20, scale=0.25, noise=True, holes=True)
+    assert big[0]["depth"].shape != small[0]["depth"].shape
+    order = [f for pair in zip(big, small) for f in pair]
+    for f in order:
+        gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+    oracle_run(cpu, order, md)
+    assert_maps_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+    # ... and the batch entry point right behind frames of the other size that are still in flight
+    for f in small[:3]:
+        gpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], md, f["intrinsics"], f["pose"])
+    gpu.integrate_batch(big[:5], md)
+    oracle_run(cpu, small[:3] + big[:5], md)
+    assert_maps_equal(gpu, cpu)
+
+
+def test_pinned_batches_upload_runs_of_side_by_side_frames(make_engine, make_oracle):
+    """ratsdf_integrate_batch(pinned): frames whose page-locked blocks lie side by side at the staging ring's stride
+    (16 bytes per pixel) go up several per copy; blocks elsewhere, frames without semantics and a mixture of both
+    take the per-frame copies.  40 frames per call: the 16-slot ring wraps twice.  Same map as the oracle's."""
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    frames = synthetic.stream("room", 40, scale=0.25, noise=True, holes=True)
+    h, w = frames[0]["depth"].shape
+    npx = h * w
+    arena = gpu.host_alloc((len(frames) * npx * 16,), np.uint8)
+
+    def views(blk, f):
+        g = dict(f)
+        g["depth"] = blk[:npx * 4].view(np.float32).reshape(h, w)
+        g["ht"] = blk[npx * 4:npx * 8].view(np.float32).reshape(h, w)
+        g["lt"] = blk[npx * 8:npx * 12].view(np.float32).reshape(h, w)
+        g["rgb"] = blk[npx * 12:npx * 15].reshape(h, w, 3)
+        for k in ("rgb", "depth", "ht", "lt"):
+            g[k][...] = f[k]
+        return g
+    side_by_side = [views(arena[i * npx * 16:(i + 1) * npx * 16], f) for i, f in enumerate(frames)]
+    gpu.integrate_batch(side_by_side, md, pinned=True)
+    oracle_run(cpu, frames, md)
+    assert_maps_equal(gpu, cpu)
+    # every third block out of place (reversed pairs break the runs), then a call without semantics
+    order = list(range(len(frames)))
+    for i in range(0, len(order) - 1, 3):
+        order[i], order[i + 1] = order[i + 1], order[i]
+    shuffled = [views(arena[j * npx * 16:(j + 1) * npx * 16], frames[i]) for i, j in enumerate(order)]
+    gpu.integrate_batch(shuffled, md, pinned=True)
+    oracle_run(cpu, frames, md)
+    assert_maps_equal(gpu, cpu)
+    nosem = [dict(g, ht=None, lt=None) for g in side_by_side[:20]]
+    for i, g in enumerate(nosem):   # (the views were overwritten by `shuffled`: fill them again)
+        for k in ("rgb", "depth"):
+            g[k][...] = frames[i][k]
+    gpu.integrate_batch(nosem, md, pinned=True)
+    oracle_run(cpu, [dict(f, ht=None, lt=None) for f in frames[:20]], md)
+    assert_maps_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+    gpu.host_free(arena)
