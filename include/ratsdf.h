@@ -160,11 +160,19 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
                                   const void* const* d_lt, int height, int width, float max_depth,
                                   const ratsdf_intrinsics* intrinsics,
                                   const ratsdf_pose* cam_T_world);
+/* Optional: builds ahead of time what the first ratsdf_integrate_device_batch(n, height, width) would build on
+ * the spot (image-sized scratch, the HIP graph of an n-frame batch), so that the first batch of a caller with a
+ * deadline costs what every later one costs.  Launches nothing.  The reference has no counterpart (its
+ * TSDFGrid allocates for 1920x1080 in the constructor, voxel_tsdf.cu:11-13,385-391).  HIP engine only. */
+int ratsdf_prepare_device_batch(ratsdf_engine* e, int n, int height, int width);
 /* n consecutive frames from HOST memory: the loop of the reference's TSDFSystem worker over its
  * queued inputs (modules/tsdf_module.cc:88-115), as one call.  rgb/depth/ht/lt are host arrays of n
  * host pointers (ht / lt may be NULL = all-ones images); uploads are enqueued ahead of the frames
- * that use them, frame i+1's map-independent part runs while frame i is integrated, and the call
- * blocks until all n frames are integrated (like n calls of ratsdf_integrate).  `pinned` != 0 says
+ * that use them, frame i+1's map-independent part runs while frame i is integrated.  Like
+ * ratsdf_integrate the call returns when the caller's buffers are no longer in use -- pageable images have been
+ * copied into the engine's staging ring, page-locked ones have been uploaded -- not when the frames have been
+ * integrated: the next call's uploads overlap this call's last kernels, and a device error of these frames is
+ * reported by the next entry point that synchronises (RATSDF_SYNC_INTEGRATE=1 restores the wait).  `pinned` != 0 says
  * that every image buffer comes from ratsdf_host_alloc (uploaded without a staging copy); a frame
  * whose four images lie side by side in one such block in the order depth | ht | lt | rgb goes up as
  * one copy instead of four (~10 us of copy-engine overhead each), and consecutive frames whose blocks

@@ -964,6 +964,7 @@ int ratsdf_oracle_stream(ratsdf_engine*, void** s) {
   return RATSDF_ERR_NOT_IMPLEMENTED;
 }
 
+int ratsdf_oracle_prepare_device_batch(ratsdf_engine*, int, int, int) { return RATSDF_ERR_NOT_IMPLEMENTED; }
 int ratsdf_oracle_profile_enable(ratsdf_engine*, int) { return RATSDF_ERR_NOT_IMPLEMENTED; }
 int ratsdf_oracle_pipeline_counters(ratsdf_engine*, int64_t*, int) { return RATSDF_ERR_NOT_IMPLEMENTED; }
 int ratsdf_oracle_export_directory_delta_device(ratsdf_engine*, void*, int32_t, void*) { return RATSDF_ERR_NOT_IMPLEMENTED; }

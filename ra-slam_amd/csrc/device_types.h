@@ -138,6 +138,7 @@ struct Ctl {
   unsigned long long stamps[32];  // diagnostic build only
   unsigned long long tstamps[16];  // diagnostic build only: wall-clock timeline of k_front's tail (kernels_frame.h)
   unsigned long long* debug_buf;  // diagnostic build only: per-wave stamps of k_integrate
+  unsigned long long dbg[8];      // diagnostic build only: counters of RATSDF_DEBUG=30 (integrate_body.inc)
 };
 constexpr int kNumLists = 8;  // one block list per XCD; list 8 (the 9th segment) holds this frame's new blocks
 

@@ -267,10 +267,10 @@ struct ratsdf_engine {
   hipEvent_t use_ev[kStageSlots + 1] = {};  // the frame that read the slot has been executed (+1: call fence)
   hipStream_t copy_stream = nullptr;   // uploads of ratsdf_integrate_batch: even frames
   hipStream_t copy_stream2 = nullptr;  // ... odd frames (two copy engines: one sustains ~31 GB/s)
-  // ratsdf_integrate (one frame of host images per call) uses the same slots as a ring and does not wait for
-  // the frame: the call returns when the images sit in the slot's page-locked memory
-  uint64_t single_no = 0;              // calls so far (slot = single_no % kStageSlots)
-  bool single_inflight = false;        // slots may still be in use by frames of such calls
+  // Both host-image entry points use the slots as ONE ring (slot = stage_no % kStageSlots, counted over every
+  // frame either of them has taken) and neither waits for its frames: what a slot's next user has to wait for is
+  // in the slot's two events, whichever call recorded them -- no fence between calls.
+  uint64_t stage_no = 0;
   bool sync_integrate = false;         // RATSDF_SYNC_INTEGRATE=1: wait for every frame (the round-3 behaviour)
   HostCopyPool* copy_pool = nullptr;
 
@@ -496,7 +496,6 @@ int ratsdf_engine::ensure_stage(size_t npix) {
   if (copy_stream) HIPCHK(hipStreamSynchronize(copy_stream));
   if (copy_stream2) HIPCHK(hipStreamSynchronize(copy_stream2));
   HIPCHK(hipStreamSynchronize(stream));
-  single_inflight = false;
   if (h_stage) (void)hipHostFree(h_stage);
   if (d_stage) (void)hipFree(d_stage);
   h_stage = nullptr;
@@ -712,18 +711,22 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
   const bool fused = fused_serial && vpl != 1;
+#ifdef RATSDF_STAMPS
   if (tab.tail_on)
     hipLaunchKernelGGL(k_front<true>, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
                        (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis + kFreshCap, seg_cap, pool,
                        carve_bufs(par ^ 1u), ctl, (uint32_t)par, d_stats, 1u | front_prio, ahead_a);
   else
+#endif
     hipLaunchKernelGGL(k_front<false>, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
                        (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis + kFreshCap, seg_cap, pool,
                        carve_bufs(par ^ 1u), ctl, (uint32_t)par, d_stats, 0u, ahead_a);
-  if (!fused) {
+#ifdef RATSDF_STAMPS
+  if (!fused) {  // (the serial role as a launch of its own: the round-1 layout, kept for A/B in the diagnostic build)
     st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
     if (st != RATSDF_OK) return st;
   }
+#endif
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // (sampled: events perturb the stream; mode 2 times every frame, for latency distributions)
@@ -762,6 +765,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
                         stream, ev0, ev1, 0, ia, P, (EnginePtr)d_eng, (uint32_t)integrate_grid,         \
                         n_serial_wg, (uint32_t)extra_c, commit_rot, ahead_c)
   // (the voxels-per-lane variants 1 / 4 / 8 are tuning options: without the front-tail path)
+#ifdef RATSDF_STAMPS
   switch (vpl) {
     case 1: RATSDF_LAUNCH_INTEGRATE(1, false, 512); break;
     case 8: RATSDF_LAUNCH_INTEGRATE(8, false, RATSDF_INTEG_NT); break;
@@ -770,6 +774,9 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
       if (tab.tail_on) RATSDF_LAUNCH_INTEGRATE(2, true, RATSDF_INTEG_NT);
       else RATSDF_LAUNCH_INTEGRATE(2, false, RATSDF_INTEG_NT);
   }
+#else
+  RATSDF_LAUNCH_INTEGRATE(2, false, RATSDF_INTEG_NT);  // the one form the product ships
+#endif
 #undef RATSDF_LAUNCH_INTEGRATE
 
   HIPCHK(hipGetLastError());
@@ -879,7 +886,7 @@ int ratsdf_engine::batch_graph(int n, int H, int W, BatchGraph** out) {
   const Geom g0 = geometry(H, W, false, 0, 0);
   const uint32_t n_serial_wg = 8u;
   const uint32_t commit_rot = commit_rotation(g0.grid, g0.grid);
-  const uint32_t tail = (tab.tail_on ? 1u : 0u) | front_prio;
+  [[maybe_unused]] const uint32_t tail = (tab.tail_on ? 1u : 0u) | front_prio;
   EnginePtr engs = (EnginePtr)d_eng;
   if (hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) != hipSuccess) return fail("hipStreamBeginCapture");
   {
@@ -893,16 +900,19 @@ int ratsdf_engine::batch_graph(int n, int H, int W, BatchGraph** out) {
     const Geom& gg = has_next ? g1 : g0;
     JobPtr cur = (JobPtr)(g.d_jobs + f);
     JobPtr nxt = (JobPtr)(g.d_jobs + (has_next ? f + 1 : f));
+#ifdef RATSDF_STAMPS
     if (tab.tail_on)
       hipLaunchKernelGGL(k_front_g<true>, dim3(gg.n_front_wg, 1), dim3(256), 0, stream, engs, cur, nxt,
                          (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, tail, gg.a);
     else
+#endif
       hipLaunchKernelGGL(k_front_g<false>, dim3(gg.n_front_wg, 1), dim3(256), 0, stream, engs, cur, nxt,
                          (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, 0u, gg.a);
     const unsigned extra_c = ((gg.c.n_tiles + 3) / 4 + 7u) & ~7u;
 #define RATSDF_GRAPH_INTEGRATE(V, T)                                                                                \
   hipLaunchKernelGGL((k_integrate_g<V, T>), dim3(gg.grid + n_serial_wg + extra_c, 1), dim3(RATSDF_INTEG_NT), 0, stream, \
                      engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg, (uint32_t)extra_c, commit_rot, gg.c)
+#ifdef RATSDF_STAMPS
     switch (vpl) {
       case 8: RATSDF_GRAPH_INTEGRATE(8, false); break;
       case 4: RATSDF_GRAPH_INTEGRATE(4, false); break;
@@ -910,6 +920,9 @@ int ratsdf_engine::batch_graph(int n, int H, int W, BatchGraph** out) {
         if (tab.tail_on) RATSDF_GRAPH_INTEGRATE(2, true);
         else RATSDF_GRAPH_INTEGRATE(2, false);
     }
+#else
+    RATSDF_GRAPH_INTEGRATE(2, false);
+#endif
 #undef RATSDF_GRAPH_INTEGRATE
   }
   const hipError_t launch_err = hipGetLastError();
@@ -949,6 +962,14 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   e->shard_count = cfg->shard_count > 1 ? cfg->shard_count : 1;
   e->shard_slab_bits = cfg->shard_slab_bits > 0 ? cfg->shard_slab_bits : 2;
   e->S = (int)ceilf(2.f * e->trunc / e->vs / RATSDF_BLOCK_LEN) + 2;
+  // What the environment may change in the shipped library: the two documented behaviours below (and
+  // RATSDF_COPY_STREAMS in ratsdf_integrate_batch).  Every tuning and ablation switch of the measurements in
+  // DESIGN.md / profiles/ -- voxels per lane, look-ahead split, grid, the serial role as a launch of its own or at
+  // the tail of k_front, fault injection -- exists in the diagnostic build only (make stamps, -DRATSDF_STAMPS),
+  // together with the kernel variants it selects.
+  if (const char* v = getenv("RATSDF_SYNC_INTEGRATE")) e->sync_integrate = atoi(v) != 0;
+  if (const char* v = getenv("RATSDF_GRAPH")) e->use_graphs = atoi(v) != 0;
+#ifdef RATSDF_STAMPS
   if (const char* v = getenv("RATSDF_VPL")) {
     const int x = atoi(v);
     if (x == 1 || x == 2 || x == 4 || x == 8) e->vpl = x;
@@ -974,8 +995,6 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   if (const char* v = getenv("RATSDF_FUSED_SERIAL")) e->fused_serial = atoi(v) != 0;  // 0: k_alloc_rank launch
   if (const char* v = getenv("RATSDF_FRONT_TAIL")) e->front_tail = atoi(v) != 0;  // 0: the role always in k_integrate
   if (const char* v = getenv("RATSDF_FRONT_PRIO")) e->front_prio = atoi(v) ? 2u : 0u;
-  if (const char* v = getenv("RATSDF_SYNC_INTEGRATE")) e->sync_integrate = atoi(v) != 0;
-  if (const char* v = getenv("RATSDF_GRAPH")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("RATSDF_SERIAL_LDS")) {
     const int x = atoi(v);
     if (x >= kSerialLdsBytes && x <= 160 * 1024) e->serial_lds = (unsigned)x;
@@ -991,6 +1010,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
       e->grid_from_env = true;
     }
   }
+#endif
   Table& t = e->tab;
   t.tail_on = (e->front_tail && e->fused_serial && e->vpl == 2) ? 1u : 0u;
   t.delta_on = 0;
@@ -1200,6 +1220,25 @@ int ratsdf_integrate_device_batch(ratsdf_engine* e, int n, const void* const* d_
   return RATSDF_OK;
 }
 
+// Builds what the first ratsdf_integrate_device_batch of this shape would build on the spot -- image-sized scratch
+// and the HIP graph of an n-frame batch -- so that a caller with a deadline does not pay for allocation, capture
+// and instantiation inside its first batch.  Nothing is launched; a shape the engine launches frame by frame
+// anyway (n < 2, graphs off) only gets its scratch.
+int ratsdf_prepare_device_batch(ratsdf_engine* e, int n, int height, int width) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e || n < 0 || height <= 0 || width <= 0) return RATSDF_ERR_BAD_ARGUMENT;
+  const size_t npix = (size_t)height * width;
+  if (npix * (size_t)e->S >= 0xFFFFFFFFull) return RATSDF_ERR_BAD_ARGUMENT;
+  const int st = e->ensure_image(npix, npix * (size_t)e->S);
+  if (st != RATSDF_OK) return st;
+  if (e->use_graphs && n >= 2 && !e->cand_ready && e->fused_serial && e->vpl != 1) {
+    ratsdf_engine::BatchGraph* g = nullptr;
+    (void)e->batch_graph(n, height, width, &g);  // (a failed capture is remembered: such batches go frame by frame)
+  }
+  return RATSDF_OK;
+}
+
 int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, const float* ht,
                      const float* lt, int height, int width, float max_depth,
                      const ratsdf_intrinsics* K, const ratsdf_pose* T) {
@@ -1222,7 +1261,7 @@ int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, c
   // memory the slot's events guard -- with a per-call stride its bytes would fall inside other slots that frames of
   // earlier calls, which are not waited for, may still be reading)
   const size_t slot_bytes = e->stage_pix * 16;
-  const int slot = (int)(e->single_no++ % kStageSlots);
+  const int slot = (int)(e->stage_no++ % kStageSlots);
   uint8_t* h = e->h_stage + (size_t)slot * slot_bytes;
   uint8_t* d = e->d_stage + (size_t)slot * slot_bytes;
   HIPCHK(hipEventSynchronize(e->stage_ev[slot]));  // (an event never recorded counts as complete)
@@ -1254,17 +1293,11 @@ int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, c
     (void)hipStreamSynchronize(e->copy_stream);
     (void)hipStreamSynchronize(e->copy_stream2);
     e->abandon_pipeline();
-    e->single_inflight = false;
     return status;
   };
-  // the slot's device memory was last read by the frame of 8 calls ago; nothing earlier on the engine's
-  // stream (another entry point's work) may be overtaken either
+  // the slot's device memory was last read by the frame that used it kStageSlots frames ago (of either host-image
+  // entry point): its use_ev.  Nothing else on the engine's stream reads the staging slots.
   if (hipStreamWaitEvent(cs, e->use_ev[slot], 0) != hipSuccess) return fail(RATSDF_ERR_DEVICE);
-  if (!e->single_inflight) {
-    if (hipEventRecord(e->use_ev[kStageSlots], e->stream) != hipSuccess ||
-        hipStreamWaitEvent(cs, e->use_ev[kStageSlots], 0) != hipSuccess)
-      return fail(RATSDF_ERR_DEVICE);
-  }
   if (ht) {
     if (hipMemcpyAsync(d, h, npix * 15, hipMemcpyHostToDevice, cs) != hipSuccess) return fail(RATSDF_ERR_DEVICE);
   } else {
@@ -1275,7 +1308,6 @@ int ratsdf_integrate(ratsdf_engine* e, const uint8_t* rgb, const float* depth, c
   if (hipEventRecord(e->stage_ev[slot], cs) != hipSuccess ||
       hipStreamWaitEvent(e->stream, e->stage_ev[slot], 0) != hipSuccess)
     return fail(RATSDF_ERR_DEVICE);
-  e->single_inflight = true;
   const ratsdf_engine::FrameIn in{d + npix * 12, d, ht ? d + npix * 4 : nullptr,
                                   ht ? d + npix * 8 : nullptr, K, T};
   st = e->frame(in, nullptr, height, width, max_depth);
@@ -1300,6 +1332,9 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
   int st = e->ensure_stage(npix);
   if (st != RATSDF_OK) return st;
   const size_t slot_bytes = e->stage_pix * 16;  // the ring's stride (see ratsdf_integrate)
+  const uint64_t base = e->stage_no;            // frame i of this call takes slot (base + i) % kStageSlots
+  e->stage_no += (uint64_t)n;
+  auto slot_of = [&](int i) { return (int)((base + (uint64_t)i) % kStageSlots); };
   auto sem = [&](int i) { return ht && lt && ht[i] && lt[i]; };  // tsdf_module.cc:27-31
   // Uploads run on their own stream, up to kStageSlots frames ahead of the frames that use them, so
   // the PCIe copy of later frames overlaps the integration of earlier ones (one stream would
@@ -1319,7 +1354,7 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
   // by side in host memory at the ring's own stride (the blocks of one arena of ratsdf::HostBlockPool) and their
   // slots do not wrap -- then ONE copy fills the slots (16 bytes per pixel: the 15 the frame has + the slot's pad)
   auto upload = [&](int i, int max_run, int* took) -> int {
-    const int slot = i % kStageSlots;
+    const int slot = slot_of(i);
     int run = 1;
     if (packed(i) && npix == e->stage_pix)
       while (run < max_run && i + run < n && slot + run < kStageSlots && packed(i + run) &&
@@ -1328,8 +1363,8 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
     *took = run;
     hipStream_t cs = ((copy_no++ & 1) && two_streams) ? e->copy_stream2 : e->copy_stream;
     uint8_t* d = e->d_stage + (size_t)slot * slot_bytes;
-    for (int j = 0; j < run; ++j)
-      if (i + j >= kStageSlots) HIPCHK(hipStreamWaitEvent(cs, e->use_ev[slot + j], 0));
+    // (the slot's last reader: a frame of this call or of an earlier one; an event never recorded counts as complete)
+    for (int j = 0; j < run; ++j) HIPCHK(hipStreamWaitEvent(cs, e->use_ev[slot + j], 0));
     const uint8_t* h0 = reinterpret_cast<const uint8_t*>(depth[i]);
     if (packed(i)) {
       HIPCHK(hipMemcpyAsync(d, h0, (size_t)(run - 1) * slot_bytes + npix * 15, hipMemcpyHostToDevice, cs));
@@ -1342,7 +1377,7 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
       HIPCHK(hipMemcpyAsync(d + npix * 12, rgb[i], npix * 3, hipMemcpyHostToDevice, cs));
     } else {
       uint8_t* h = e->h_stage + (size_t)slot * slot_bytes;
-      if (i >= kStageSlots) HIPCHK(hipEventSynchronize(e->stage_ev[slot]));  // its last upload is done
+      HIPCHK(hipEventSynchronize(e->stage_ev[slot]));  // the slot's last upload has left its page-locked memory
       // (the frame's images side by side, by the engine's copy helpers: HostCopyPool)
       HostCopyPool::Piece pieces[4];
       int np = 0;
@@ -1369,7 +1404,7 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
     return RATSDF_OK;
   };
   auto input = [&](int i) {
-    uint8_t* d = e->d_stage + (size_t)(i % kStageSlots) * slot_bytes;
+    uint8_t* d = e->d_stage + (size_t)slot_of(i) * slot_bytes;
     return ratsdf_engine::FrameIn{d + npix * 12, d, sem(i) ? d + npix * 4 : nullptr,
                                   sem(i) ? d + npix * 8 : nullptr, &K[i], &T[i]};
   };
@@ -1380,17 +1415,10 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
     e->abandon_pipeline();
     return status;
   };
-  // frames of earlier ratsdf_integrate calls may still be using the slots (those calls do not wait): let them
-  // finish first; and nothing earlier on the engine's stream may be overtaken by the uploads
-  if (e->single_inflight) {
-    HIPCHK(hipStreamSynchronize(e->copy_stream));
-    HIPCHK(hipStreamSynchronize(e->copy_stream2));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    e->single_inflight = false;
-  }
-  HIPCHK(hipEventRecord(e->use_ev[kStageSlots], e->stream));
-  HIPCHK(hipStreamWaitEvent(e->copy_stream, e->use_ev[kStageSlots], 0));
-  HIPCHK(hipStreamWaitEvent(e->copy_stream2, e->use_ev[kStageSlots], 0));
+  // (No fence against earlier calls: frames of earlier host-image calls that are still in flight are what the
+  // slots' events stand for, and nothing else on the engine's stream touches the staging slots.  Until round 5
+  // every call began by making both copy streams wait for ALL earlier work of the engine's stream and ended with
+  // a synchronisation: the link idled ~0.4 ms per 32-frame call, 13 % of it -- tools/copy_gaps.py.)
   // Uploads are enqueued up to `ahead` frames in front of the frame being launched: slot (u % kStageSlots) was last
   // read by frame u - kStageSlots, whose use_ev must have been RECORDED (i.e. that frame launched) before a copy
   // stream is told to wait for it.
@@ -1404,8 +1432,8 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
       if (st != RATSDF_OK) return fail(st);
       uploaded += took;
     }
-    if (hipStreamWaitEvent(e->stream, e->stage_ev[i % kStageSlots], 0) != hipSuccess ||
-        (i + 1 < n && hipStreamWaitEvent(e->stream, e->stage_ev[(i + 1) % kStageSlots], 0) != hipSuccess))
+    if (hipStreamWaitEvent(e->stream, e->stage_ev[slot_of(i)], 0) != hipSuccess ||
+        (i + 1 < n && hipStreamWaitEvent(e->stream, e->stage_ev[slot_of(i + 1)], 0) != hipSuccess))
       return fail(RATSDF_ERR_DEVICE);
     const ratsdf_engine::FrameIn cur = input(i);
     ratsdf_engine::FrameIn nxt{};
@@ -1414,7 +1442,7 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
     if (st != RATSDF_OK) return fail(st);
     // frame i's images were last read by its candidate pass, which ran in frame i-1's launches or
     // before; recording after frame i is the simple, safe point
-    if (hipEventRecord(e->use_ev[i % kStageSlots], e->stream) != hipSuccess) return fail(RATSDF_ERR_DEVICE);
+    if (hipEventRecord(e->use_ev[slot_of(i)], e->stream) != hipSuccess) return fail(RATSDF_ERR_DEVICE);
     // run further ahead with the uploads while the queue is busy -- in whole runs (or the batch's tail), so that
     // side-by-side frames keep going up together instead of one by one as slots fall free
     while (uploaded < n) {
@@ -1426,6 +1454,15 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
       uploaded += took;
     }
   }
+  // The call returns when the caller's buffers are no longer in use: at once for pageable images (they were copied
+  // into the staging ring), after the last upload for page-locked ones.  It does not wait for the frames'
+  // kernels -- the next call's uploads overlap them -- so a device error of these frames is reported by the next
+  // entry point that synchronises, as for ratsdf_integrate.
+  if (pinned) {
+    if (hipStreamSynchronize(e->copy_stream) != hipSuccess || hipStreamSynchronize(e->copy_stream2) != hipSuccess)
+      return fail(RATSDF_ERR_DEVICE);
+  }
+  if (!e->sync_integrate) return RATSDF_OK;
   st = e->sticky();
   if (st == RATSDF_ERR_DEVICE) return fail(st);
   return st;
@@ -1609,6 +1646,18 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
                   done[done.size() * 99 / 100] - t0, last - t0);
     }
   }
+  return RATSDF_OK;
+}
+
+// diagnostic (stamps build only): Ctl::dbg -- RATSDF_DEBUG=30 counts update waves that changed no voxel:
+// [0] such waves, [1] waves, [2] blocks without an update, [3] blocks; read and reset
+extern "C" int ratsdf_debug_counters(ratsdf_engine* e, unsigned long long* out8) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e || !out8) return RATSDF_ERR_BAD_ARGUMENT;
+  HIPCHK(hipMemcpyAsync(out8, e->ctl->dbg, 8 * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemsetAsync(e->ctl->dbg, 0, 8 * 8, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
   return RATSDF_OK;
 }
 
@@ -2385,6 +2434,7 @@ int ratsdf_group_create(ratsdf_engine* const* engines, int n, ratsdf_group** out
   g->S = n;
   g->eng.assign(engines, engines + n);
   g->ev_member.assign((size_t)n, nullptr);
+#ifdef RATSDF_STAMPS
   if (const char* v = getenv("RATSDF_GROUP_SPLIT")) {  // "a[,b]" like RATSDF_CAND_SPLIT
     const int x = atoi(v);
     if (x >= 0 && x <= 100) {
@@ -2396,6 +2446,7 @@ int ratsdf_group_create(ratsdf_engine* const* engines, int n, ratsdf_group** out
       }
     }
   }
+#endif
 #define GROUP_CHK(expr)                                                  \
   do {                                                                   \
     if ((expr) != hipSuccess) {                                          \
@@ -2566,17 +2617,21 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
     const ratsdf_engine::Geom& gg = has_next ? g1 : g0;
     JobPtr cur = (JobPtr)(g->d_jobs + (size_t)f * S);
     JobPtr nxt = (JobPtr)(g->d_jobs + (size_t)(has_next ? f + 1 : f) * S);
+#ifdef RATSDF_STAMPS
     if (e0->tab.tail_on)
       hipLaunchKernelGGL(k_front_g<true>, dim3(gg.n_front_wg, S), dim3(256), 0, g->stream, engs, cur, nxt,
                          (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, 1u | e0->front_prio, gg.a);
     else
+#endif
       hipLaunchKernelGGL(k_front_g<false>, dim3(gg.n_front_wg, S), dim3(256), 0, g->stream, engs, cur, nxt,
                          (uint32_t)gg.n_vis_wg, (uint32_t)gg.parts, 0u, gg.a);
+#ifdef RATSDF_STAMPS
     if (!fused) {
       const unsigned extra_b = gg.b.n_tiles ? (gg.b.n_tiles + gg.b.tiles_per_wg - 1) / gg.b.tiles_per_wg : 0;
       hipLaunchKernelGGL(k_alloc_rank_g, dim3(1 + extra_b, S), dim3(1024), kSerialLdsBytes, g->stream,
                          engs, cur, nxt, gg.b);
     }
+#endif
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g->profiling && (g->prof_frame++ % 4 == 0) && g->prof_used < g->prof_events.size()) {
       ev0 = g->prof_events[g->prof_used].first;
@@ -2588,6 +2643,7 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
   hipExtLaunchKernelGGL((k_integrate_g<V, T>), dim3(gg.grid + n_serial_wg + extra_c, S), dim3(NT), 0,  \
                         g->stream, ev0, ev1, 0, engs, cur, nxt, (uint32_t)gg.grid, n_serial_wg,        \
                         (uint32_t)extra_c, commit_rot, gg.c)
+#ifdef RATSDF_STAMPS
     switch (e0->vpl) {
       case 1: RATSDF_LAUNCH_INTEGRATE_G(1, false, 512); break;
       case 8: RATSDF_LAUNCH_INTEGRATE_G(8, false, RATSDF_INTEG_NT); break;
@@ -2596,6 +2652,9 @@ int ratsdf_group_integrate_device_batch(ratsdf_group* g, int n, const void* cons
         if (e0->tab.tail_on) RATSDF_LAUNCH_INTEGRATE_G(2, true, RATSDF_INTEG_NT);
         else RATSDF_LAUNCH_INTEGRATE_G(2, false, RATSDF_INTEG_NT);
     }
+#else
+    RATSDF_LAUNCH_INTEGRATE_G(2, false, RATSDF_INTEG_NT);
+#endif
 #undef RATSDF_LAUNCH_INTEGRATE_G
     if (hipGetLastError() != hipSuccess) {  // a launch of this frame was refused
       abandon(f);

@@ -24,6 +24,7 @@ struct Api {
                          const ratsdf_intrinsics*, const ratsdf_pose*, int) = nullptr;
   int (*host_alloc)(size_t, void**) = nullptr;
   int (*host_free)(void*) = nullptr;
+  int (*synchronize)(ratsdf_engine*) = nullptr;
   int (*query)(ratsdf_engine*, const ratsdf_bounds*, ratsdf_voxel_tsdf**, size_t*) = nullptr;
   int (*gather_valid)(ratsdf_engine*, ratsdf_voxel_tsdf**, size_t*) = nullptr;
   int (*gather_valid_semantic)(ratsdf_engine*, ratsdf_voxel_segm**, size_t*) = nullptr;
@@ -76,6 +77,9 @@ class TSDFGrid {
   void DownloadAllMesh(const std::string& vertices_path, const std::string& indices_path,
                        const std::string& prob_path);  // tsdf_module.cc:66-86
   int NumActiveBlock();                            // voxel_hash.cu:225
+  // cudaStreamSynchronize(stream_), voxel_tsdf.cu:450: the Integrate* calls do not wait for their frames; this does,
+  // and it is where a device error of those frames surfaces (last_status())
+  void Synchronize();
   int last_status() const { return status_; }
   ratsdf_engine* handle() { return engine_; }
   const Api& api() const { return *api_; }

@@ -36,36 +36,50 @@ struct HostBlock {
 //   * Blocks come from ARENAS of kArenaBlocks consecutive blocks (one host_alloc each) and the free block of
 //     lowest address goes out first, so the frames of a batch usually lie side by side in memory and the
 //     engine uploads runs of them with one copy (include/ratsdf.h, ratsdf_integrate_batch).
-//   * Nothing is given back to the system while frames flow: release() parks.  trim() -- called by the worker
-//     when its queue has drained -- returns whole idle arenas beyond kParkedBytes.  (Until round 5 release()
-//     itself enforced a 256 MiB cap = 52 blocks at 640x480, below the 2 x 32 frames + queue a running system
-//     has in flight: every further frame was a hipHostMalloc + hipHostFree pair.)
-//   * A failed allocation is not fatal: the block is ordinary memory (pinned = false) and the batch that
-//     contains it is handed over as pageable.
+//   * The first block of a size reserves `reserve_blocks` of them at once (what a running system has in flight:
+//     two batches + a short queue), so that a steady stream never allocates: page-locking memory takes
+//     milliseconds per arena and holds up every other HIP call of the process while it runs -- measured in round
+//     5: 28 arenas allocated while the queue grew cost the worker half its rate.
+//   * Page-locked memory is bounded (kPinnedBytes): a queue that outgrows it -- the reference's queue is unbounded,
+//     modules/tsdf_module.cc:99-100 only warns -- continues in ordinary memory (pinned = false; the worker hands
+//     such frames over as pageable), freed on release.
+//   * Nothing page-locked is given back while frames flow: release() parks.  trim() -- called by the worker when
+//     its queue has drained -- returns whole idle arenas beyond max(kParkedBytes, the reserve).  (Until round 5
+//     release() itself enforced a 256 MiB cap = 52 blocks at 640x480, below the 2 x 32 frames + queue a running
+//     system has in flight: every further frame was a hipHostMalloc + hipHostFree pair.)
+//   * A failed page-locked allocation is not fatal: ordinary memory, as above.
 class HostBlockPool {
  public:
   static constexpr size_t kArenaBlocks = 8;
   static constexpr size_t kParkedBytes = (size_t)256 << 20;
-  explicit HostBlockPool(const Api* api) : api_(api) {}
+  static constexpr size_t kPinnedBytes = (size_t)768 << 20;
+  explicit HostBlockPool(const Api* api, size_t reserve_blocks = 0) : api_(api), reserve_(reserve_blocks) {}
+  void set_pinned_budget(size_t bytes) { budget_ = bytes; }  // before the first acquire()
   ~HostBlockPool();
-  HostBlock acquire(size_t bytes);
+  HostBlock acquire(size_t bytes, bool grow_ok = true, bool pageable_ok = true);
   void release(const HostBlock& b);
+  bool wait_for_release(int ms);  // true: a block came back since the call began
   void trim();
   // host_alloc / host_free calls so far (a steady stream of equal-sized frames must not move them)
   size_t system_allocs() const { return allocs_; }
   size_t system_frees() const { return frees_; }
+  size_t pageable_blocks() const { return pageable_; }  // blocks handed out in ordinary memory so far
 
  private:
   struct Arena {
     uint8_t* base = nullptr;
     size_t block_bytes = 0, blocks = 0, in_use = 0;
-    bool pinned = true;
   };
+  bool grow(size_t bytes);  // one more arena of `bytes`-sized blocks; false: cap reached or no page-locked memory
+  Arena* arena_of(const void* p);
   const Api* api_;
+  size_t reserve_;
   std::mutex mtx_;
   std::vector<Arena> arenas_;
-  std::vector<HostBlock> free_;  // sorted by address, descending (the lowest is at the back)
-  size_t allocs_ = 0, frees_ = 0;
+  std::vector<HostBlock> free_;  // page-locked, sorted by address, descending (the lowest is at the back)
+  size_t pinned_bytes_ = 0, reserved_for_ = 0, budget_ = kPinnedBytes;
+  size_t allocs_ = 0, frees_ = 0, pageable_ = 0, releases_ = 0;
+  std::condition_variable cv_release_;
 };
 
 // The deep copy of a frame into its queue element (cv::Mat::clone x 4, tsdf_module.cc:28-35: 4.6 MB at
@@ -132,6 +146,12 @@ class TSDFSystem {
   size_t frames_integrated();
   size_t pool_system_allocs() { return pool_.system_allocs(); }   // host_alloc calls of the queue's block pool
   size_t pool_system_frees() { return pool_.system_frees(); }
+  size_t pool_pageable_blocks() { return pool_.pageable_blocks(); }  // frames the queue kept in ordinary memory
+  // page-locked memory the queue may hold (default HostBlockPool::kPinnedBytes); call before the first Integrate
+  void SetPinnedBudget(size_t bytes) { pool_.set_pinned_budget(bytes); }
+  // true (default): Integrate() waits for the worker once two batches + an arena of frames (72) are queued or in
+  // flight; false: the reference's unbounded queue (tsdf_module.cc:99-100).  Call before the first Integrate.
+  void SetQueueBounded(bool bounded) { bounded_ = bounded; }
 
  private:
   void Run();
@@ -147,6 +167,7 @@ class TSDFSystem {
   std::queue<std::unique_ptr<TSDFSystemInput>> inputs_;
   std::condition_variable cv_queue_;  // the reference busy-polls (tsdf_module.cc:101)
   bool busy_ = false;
+  bool bounded_ = true;
   std::mutex mtx_read_;
   std::mutex mtx_terminate_;
   bool terminate_ = false;

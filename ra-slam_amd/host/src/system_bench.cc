@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 2 * n && i < 64; ++i) push(fr[(size_t)(i % n)]);  // warm-up: map built, pools filled
   sys.Flush();
   size_t max_queue = 0;
-  const size_t allocs0 = sys.pool_system_allocs(), frees0 = sys.pool_system_frees();
+  const size_t allocs0 = sys.pool_system_allocs(), frees0 = sys.pool_system_frees(), pageable0 = sys.pool_pageable_blocks();
   const auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < total; ++i) {
     const int k = i % (2 * n);
@@ -97,9 +97,10 @@ int main(int argc, char** argv) {
   printf("{\"frames\": %d, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"producer_seconds\": %.4f, "
          "\"producer_frames_per_s\": %.1f, \"h2d_gbps\": %.2f, \"max_queue\": %zu, \"semantics\": %s, "
          "\"width\": %d, \"height\": %d, \"active_blocks\": %d, \"pool_allocs_steady_state\": %zu, "
-         "\"pool_frees_steady_state\": %zu}\n",
+         "\"pool_frees_steady_state\": %zu, \"frames_queued_in_pageable_memory\": %zu}\n",
          total, t_all, total / t_all, t_push, total / t_push, total * bytes / t_all / 1e9, max_queue,
-         sem ? "true" : "false", W, H, sys.NumActiveBlock(), pool_allocs, pool_frees);
+         sem ? "true" : "false", W, H, sys.NumActiveBlock(), pool_allocs, pool_frees,
+         sys.pool_pageable_blocks() - pageable0);
   sys.terminate();
   return 0;
 }

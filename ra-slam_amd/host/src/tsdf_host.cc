@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,6 +57,7 @@ const Api& Api::Load(const char* path, const char* prefix) {
   api.integrate_batch = reinterpret_cast<decltype(api.integrate_batch)>(sym("integrate_batch"));
   api.host_alloc = reinterpret_cast<decltype(api.host_alloc)>(sym("host_alloc"));
   api.host_free = reinterpret_cast<decltype(api.host_free)>(sym("host_free"));
+  api.synchronize = reinterpret_cast<decltype(api.synchronize)>(sym("synchronize"));
   api.query = reinterpret_cast<decltype(api.query)>(sym("query"));
   api.gather_valid = reinterpret_cast<decltype(api.gather_valid)>(sym("gather_valid"));
   api.gather_valid_semantic =
@@ -193,6 +195,10 @@ void TSDFGrid::DownloadAll(const std::string& path) {
   if (engine_) note(api_->download_all(engine_, path.c_str()), "DownloadAll");
 }
 
+void TSDFGrid::Synchronize() {
+  if (engine_) note(api_->synchronize(engine_), "Synchronize");
+}
+
 int TSDFGrid::NumActiveBlock() {
   int32_t n = 0;
   if (engine_) note(api_->num_active_blocks(engine_, &n), "NumActiveBlock");
@@ -200,64 +206,95 @@ int TSDFGrid::NumActiveBlock() {
 }
 
 // ---- page-locked block pool -----------------------------------------------------------------
-HostBlock HostBlockPool::acquire(size_t bytes) {
-  std::lock_guard<std::mutex> lock(mtx_);
-  for (size_t i = free_.size(); i-- > 0;)  // lowest address first
-    if (free_[i].bytes == bytes) {
-      const HostBlock b = free_[i];
-      free_.erase(free_.begin() + (long)i);
-      for (Arena& a : arenas_)
-        if (static_cast<uint8_t*>(b.ptr) >= a.base && static_cast<uint8_t*>(b.ptr) < a.base + a.block_bytes * a.blocks)
-          ++a.in_use;
-      return b;
-    }
-  // a new arena; under memory pressure a single block; without page-locked memory an ordinary one
-  Arena a;
-  a.block_bytes = bytes;
-  void* base = nullptr;
-  for (size_t blocks : {kArenaBlocks, (size_t)1}) {
+HostBlockPool::Arena* HostBlockPool::arena_of(const void* p) {
+  const uint8_t* q = static_cast<const uint8_t*>(p);
+  for (Arena& a : arenas_)
+    if (q >= a.base && q < a.base + a.block_bytes * a.blocks) return &a;
+  return nullptr;
+}
+
+bool HostBlockPool::grow(size_t bytes) {
+  for (size_t blocks : {kArenaBlocks, (size_t)1}) {  // under memory pressure: single blocks
+    if (pinned_bytes_ + bytes * blocks > budget_) continue;
+    void* base = nullptr;
     ++allocs_;
-    if (api_->host_alloc(bytes * blocks, &base) == RATSDF_OK && base) {
-      a.blocks = blocks;
-      break;
+    if (api_->host_alloc(bytes * blocks, &base) != RATSDF_OK || !base) continue;
+    Arena a;
+    a.base = static_cast<uint8_t*>(base);
+    a.block_bytes = bytes;
+    a.blocks = blocks;
+    arenas_.push_back(a);
+    pinned_bytes_ += bytes * blocks;
+    for (size_t k = blocks; k-- > 0;) {
+      const HostBlock b{a.base + k * bytes, bytes, true};
+      free_.insert(std::lower_bound(free_.begin(), free_.end(), b,
+                                    [](const HostBlock& x, const HostBlock& y) { return x.ptr > y.ptr; }), b);
     }
-    base = nullptr;
+    return true;
   }
-  if (!base) {
-    fprintf(stderr, "[ratsdf] no page-locked memory for a %zu-byte frame block: using pageable memory\n", bytes);
-    base = malloc(bytes);
-    if (!base) return HostBlock{nullptr, bytes, false};  // the caller drops the frame and reports it
-    a.blocks = 1;
-    a.pinned = false;
+  return false;
+}
+
+bool HostBlockPool::wait_for_release(int ms) {
+  std::unique_lock<std::mutex> lock(mtx_);
+  const size_t seen = releases_;
+  return cv_release_.wait_for(lock, std::chrono::milliseconds(ms), [&] { return releases_ != seen; });
+}
+
+// grow: may page-lock more memory when no block is free (beyond the reserve, which the first block of a size takes
+// in any case); pageable: may hand out ordinary memory when page-locked memory is exhausted.  Neither: nullptr.
+HostBlock HostBlockPool::acquire(size_t bytes, bool grow_ok, bool pageable_ok) {
+  std::lock_guard<std::mutex> lock(mtx_);
+  if (reserved_for_ != bytes) {  // the first block of this size: everything a running system keeps in flight
+    reserved_for_ = bytes;
+    size_t have = 0;
+    for (const Arena& a : arenas_)
+      if (a.block_bytes == bytes) have += a.blocks;
+    while (have < reserve_ && grow(bytes)) have += arenas_.back().blocks;
   }
-  a.base = static_cast<uint8_t*>(base);
-  a.in_use = 1;
-  arenas_.push_back(a);
-  for (size_t k = a.blocks; k-- > 1;) {
-    const HostBlock b{a.base + k * bytes, bytes, a.pinned};
-    free_.insert(std::lower_bound(free_.begin(), free_.end(), b,
-                                  [](const HostBlock& x, const HostBlock& y) { return x.ptr > y.ptr; }), b);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    for (size_t i = free_.size(); i-- > 0;)  // lowest address first
+      if (free_[i].bytes == bytes) {
+        const HostBlock b = free_[i];
+        free_.erase(free_.begin() + (long)i);
+        if (Arena* a = arena_of(b.ptr)) ++a->in_use;
+        return b;
+      }
+    // (a pool without any block of this size -- the reserve could not be page-locked -- grows whatever the caller says)
+    bool have = false;
+    for (const Arena& a : arenas_) have = have || a.block_bytes == bytes;
+    if (attempt == 0 && ((!grow_ok && have) || !grow(bytes))) break;
   }
-  return HostBlock{a.base, bytes, a.pinned};
+  if (!pageable_ok) {
+    bool have = false;
+    for (const Arena& a : arenas_) have = have || a.block_bytes == bytes;
+    if (have) return HostBlock{nullptr, bytes, true};  // the caller waits for a release
+  }
+  // the page-locked budget is spent (or there is no such memory): ordinary memory, staged by the engine
+  ++pageable_;
+  return HostBlock{malloc(bytes), bytes, false};  // (nullptr: the caller drops the frame and says so)
 }
 
 void HostBlockPool::release(const HostBlock& b) {
   if (!b.ptr) return;
+  if (!b.pinned) {
+    free(b.ptr);
+    return;
+  }
   std::lock_guard<std::mutex> lock(mtx_);
-  for (Arena& a : arenas_)
-    if (static_cast<uint8_t*>(b.ptr) >= a.base && static_cast<uint8_t*>(b.ptr) < a.base + a.block_bytes * a.blocks)
-      --a.in_use;
+  if (Arena* a = arena_of(b.ptr)) --a->in_use;
   free_.insert(std::lower_bound(free_.begin(), free_.end(), b,
                                 [](const HostBlock& x, const HostBlock& y) { return x.ptr > y.ptr; }), b);
+  ++releases_;
+  cv_release_.notify_all();
 }
 
-// Whole idle arenas beyond kParkedBytes of parked memory go back to the system (page-locked memory is not
-// reclaimable by anybody else).  Called when no frame is queued or in flight.
+// Whole idle arenas beyond the larger of kParkedBytes and the reserve go back to the system (page-locked memory
+// is not reclaimable by anybody else).  Called when no frame is queued or in flight.
 void HostBlockPool::trim() {
   std::lock_guard<std::mutex> lock(mtx_);
-  size_t parked = 0;
-  for (const HostBlock& f : free_) parked += f.bytes;
-  for (size_t i = arenas_.size(); i-- > 0 && parked > kParkedBytes;) {
+  const size_t keep = std::max(kParkedBytes, reserve_ * reserved_for_);
+  for (size_t i = arenas_.size(); i-- > 0 && pinned_bytes_ > keep;) {
     const Arena a = arenas_[i];
     if (a.in_use) continue;
     free_.erase(std::remove_if(free_.begin(), free_.end(),
@@ -266,22 +303,15 @@ void HostBlockPool::trim() {
                                         static_cast<uint8_t*>(f.ptr) < a.base + a.block_bytes * a.blocks;
                                }),
                 free_.end());
-    if (a.pinned) {
-      ++frees_;
-      api_->host_free(a.base);
-    } else {
-      free(a.base);
-    }
-    parked -= a.block_bytes * a.blocks;
+    ++frees_;
+    api_->host_free(a.base);
+    pinned_bytes_ -= a.block_bytes * a.blocks;
     arenas_.erase(arenas_.begin() + (long)i);
   }
 }
 
 HostBlockPool::~HostBlockPool() {
-  for (const Arena& a : arenas_) {
-    if (a.pinned) api_->host_free(a.base);
-    else free(a.base);
-  }
+  for (const Arena& a : arenas_) api_->host_free(a.base);
 }
 
 // ---- parallel clone ---------------------------------------------------------------------------
@@ -338,7 +368,7 @@ TSDFSystem::TSDFSystem(float voxel_size, float truncation, float max_depth,
                        const CameraIntrinsics<float>& intrinsics, const SE3<float>& extrinsics,
                        int device, const Api* api)
     : tsdf_(voxel_size, truncation, device, api),
-      pool_(&tsdf_.api()),
+      pool_(&tsdf_.api(), 2 * kMaxBatch + HostBlockPool::kArenaBlocks),
       copier_(getenv("RATSDF_COPY_THREADS") ? atoi(getenv("RATSDF_COPY_THREADS")) : 3),
       max_depth_(max_depth),
       intrinsics_(intrinsics),
@@ -365,7 +395,20 @@ void TSDFSystem::Integrate(const SE3<float>& posecam_T_world, const Image& rgb, 
   // clone(), tsdf_module.cc:28-35 -- into ONE page-locked block [depth | ht | lt | rgb] so that the
   // worker can upload it without another copy.  Missing ht / lt stay missing: the engine treats
   // them as the all-ones images the reference would build here (tsdf_module.cc:29-31).
-  in->block = pool_.acquire(npix * 16);
+  // The queue's copy lives in a page-locked block.  By default the queue is BOUNDED by the pool's reserve (two
+  // batches + an arena of frames): when every block is in flight the producer waits for the worker -- a knowing
+  // deviation from the reference, whose queue grows without bound and only warns (tsdf_module.cc:99-100); there a
+  // producer that outruns the integration runs out of memory, here out of page-locked memory first.
+  // SetQueueBounded(false) restores the reference's behaviour (page-locked up to the budget, then ordinary memory).
+  in->block = pool_.acquire(npix * 16, /*grow=*/!bounded_, /*pageable=*/!bounded_);
+  while (!in->block.ptr && bounded_) {
+    {
+      std::lock_guard<std::mutex> tl(mtx_terminate_);
+      if (terminate_) return;  // nobody will ever free a block: the frame is dropped, like every frame queued now
+    }
+    pool_.wait_for_release(2);
+    in->block = pool_.acquire(npix * 16, false, false);
+  }
   if (!in->block.ptr) {  // no memory at all for the queue's copy: the frame is dropped, like a reference run
     fprintf(stderr, "[TSDF System] out of memory: frame dropped\n");  // whose cv::Mat::clone threw
     return;
@@ -436,9 +479,11 @@ void TSDFSystem::Run() {
                 inputs_.size());
       // everything that is queued right now (same image size), at most kMaxBatch frames: one engine
       // call, uploads overlapped with integration; the reference takes one frame per iteration
+      // (... and the same kind of memory: frames the queue had to keep in ordinary memory go as pageable calls)
       while (!inputs_.empty() && batch.size() < kMaxBatch &&
              (batch.empty() || (inputs_.front()->rows == batch[0]->rows &&
-                                inputs_.front()->cols == batch[0]->cols))) {
+                                inputs_.front()->cols == batch[0]->cols &&
+                                inputs_.front()->block.pinned == batch[0]->block.pinned))) {
         batch.push_back(std::move(inputs_.front()));
         inputs_.pop();
       }
@@ -497,14 +542,19 @@ void TSDFSystem::SetPause(bool pause) {
 }
 
 void TSDFSystem::Flush() {
-  std::unique_lock<std::mutex> lock(mtx_queue_);
-  while (!inputs_.empty() || busy_) {
-    {
-      std::lock_guard<std::mutex> tl(mtx_terminate_);
-      if (terminate_) return;
+  {
+    std::unique_lock<std::mutex> lock(mtx_queue_);
+    while (!inputs_.empty() || busy_) {
+      {
+        std::lock_guard<std::mutex> tl(mtx_terminate_);
+        if (terminate_) return;
+      }
+      cv_queue_.wait_for(lock, std::chrono::milliseconds(2));
     }
-    cv_queue_.wait_for(lock, std::chrono::milliseconds(2));
   }
+  // the worker's engine calls return when the images are on their way, not when the frames are integrated
+  std::lock_guard<std::mutex> lock(mtx_read_);
+  tsdf_.Synchronize();
 }
 
 size_t TSDFSystem::QueueSize() {

@@ -67,7 +67,7 @@ assert VOXEL_SEGM_DTYPE.itemsize == 20 and RGBW_DTYPE.itemsize == 4
 # every symbol include/ratsdf.h declares (without prefix)
 SYMBOLS = [
     "create", "create_ex", "destroy", "integrate", "integrate_device", "integrate_device_batch",
-    "integrate_batch", "host_alloc", "host_free", "synchronize", "stream",
+    "prepare_device_batch", "integrate_batch", "host_alloc", "host_free", "synchronize", "stream",
     "profile_enable", "profile_read", "profile_read_frames", "totals", "pipeline_counters",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "raycast", "raycast_device", "gather_valid_mesh", "download_all_mesh",
@@ -114,6 +114,7 @@ class Library:
         self.fn["integrate_device"].argtypes = self.fn["integrate"].argtypes
         self.fn["integrate_device_batch"].argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
                                                       C.c_float, vp, vp]
+        self.fn["prepare_device_batch"].argtypes = [vp, C.c_int, C.c_int, C.c_int]
         self.fn["integrate_batch"].argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float,
                                                vp, vp, C.c_int]
         self.fn["host_alloc"].argtypes = [C.c_size_t, C.POINTER(vp)]
@@ -272,6 +273,10 @@ class Engine:
         n, rgb, depth, ht, lt, h, w, md, ks, ps = batch
         st = self.lib.fn["integrate_device_batch"](self._h, n, rgb, depth, ht, lt, h, w, md, ks, ps)
         _check(st, "integrate_device_batch")
+
+    def prepare_device_batch(self, n, height, width):
+        """scratch + HIP graph of an n-frame batch ahead of time (ratsdf_prepare_device_batch); launches nothing"""
+        _check(self.lib.fn["prepare_device_batch"](self._h, int(n), int(height), int(width)), "prepare_device_batch")
 
     def host_alloc(self, shape, dtype):
         """numpy array in page-locked host memory (ratsdf_host_alloc); release with host_free()."""

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -196,27 +197,67 @@ int main(int argc, char** argv) {
     CHECK(std::fabs(I.GetR().w) > 0.999999f && std::fabs(I.GetT().x) < 1e-6f);
   }
 
-  // 8: the queue's page-locked block pool.  A paused system lets 100 frames pile up (more than two batches of 32
-  // and more than the 52 blocks = 256 MiB-at-640x480 the round-4 pool parked before it freed on every release):
-  // the second round of the same load must not allocate or free anything, the map must be the frame-by-frame
-  // one, and an idle system gives memory back only beyond kParkedBytes (nothing at this image size).
+  // 8: the queue's page-locked block pool, bounded queue (the default).  The first frame reserves what a running
+  // system keeps in flight (two batches of 32 + an arena = 72 blocks = 9 arenas); 100 frames pushed as fast as
+  // possible never allocate or free anything further -- the producer waits for the worker instead (the round-4 pool
+  // parked 52 blocks and then freed on EVERY release) -- and the map is the frame-by-frame one.
   {
     TSDFSystem sys(vs, tr, md, K, SE3<float>::Identity(), 0, &api);
     TSDFGrid ref(vs, tr, 0, &api);
-    auto load = [&](bool both) {
+    auto load = [&]() {
       for (int i = 0; i < 100; ++i) {
         const Frame& f = frames[(size_t)i % frames.size()];
         sys.Integrate(f.pose, img(f.rgb), img(f.depth), img(f.ht), img(f.lt));
-        if (both) ref.Integrate(img(f.rgb), img(f.depth), img(f.ht), img(f.lt), md, K, f.pose);
+        ref.Integrate(img(f.rgb), img(f.depth), img(f.ht), img(f.lt), md, K, f.pose);
       }
       sys.Flush();
     };
-    load(true);
-    const size_t a0 = sys.pool_system_allocs(), f0 = sys.pool_system_frees();
-    CHECK(a0 >= 1 && a0 <= 100 / HostBlockPool::kArenaBlocks + 1 && f0 == 0);
-    load(true);
-    CHECK(sys.pool_system_allocs() == a0 && sys.pool_system_frees() == 0);
-    CHECK(sys.frames_integrated() == 200);
+    sys.Integrate(frames[0].pose, img(frames[0].rgb), img(frames[0].depth), img(frames[0].ht), img(frames[0].lt));
+    ref.Integrate(img(frames[0].rgb), img(frames[0].depth), img(frames[0].ht), img(frames[0].lt), md, K, frames[0].pose);
+    const size_t reserve = sys.pool_system_allocs();
+    CHECK(reserve == (2 * 32 + HostBlockPool::kArenaBlocks) / HostBlockPool::kArenaBlocks);  // 72 blocks = 9 arenas
+    load();
+    load();
+    CHECK(sys.pool_system_allocs() == reserve && sys.pool_system_frees() == 0 && sys.pool_pageable_blocks() == 0);
+    CHECK(sys.frames_integrated() == 201);
+    CHECK(sys.QueueSize() == 0);
+    const BoundingCube<float> all{-10, 10, -10, 10, -10, 10};
+    CHECK(same(sys.Query(all), ref.GatherVoxels(all)));
+    // a producer that waits for a free block is released by terminate() (nobody would ever free one): no deadlock
+    std::atomic<int> pushed{0};
+    std::thread producer([&] {
+      for (int i = 0; i < 2000; ++i) {
+        const Frame& f = frames[(size_t)i % frames.size()];
+        sys.Integrate(f.pose, img(f.rgb), img(f.depth), img(f.ht), img(f.lt));
+        ++pushed;
+      }
+    });
+    std::this_thread::sleep_for(std::chrono::milliseconds(30));
+    sys.terminate();
+    producer.join();
+    CHECK(pushed.load() == 2000);
+  }
+
+  // 9: SetQueueBounded(false) = the reference's unbounded queue (tsdf_module.cc:99-100): a queue that outgrows its
+  // page-locked budget continues in ordinary memory.  The budget here is 12 blocks and 300 frames are pushed as fast
+  // as possible; frames of both kinds of memory reach the engine in order (separate calls): same map as frame by frame
+  {
+    TSDFSystem sys(vs, tr, md, K, SE3<float>::Identity(), 0, &api);
+    sys.SetPinnedBudget((size_t)12 * W * H * 16);
+    sys.SetQueueBounded(false);
+    TSDFGrid ref(vs, tr, 0, &api);
+    for (int i = 0; i < 300; ++i) {
+      const Frame& f = frames[(size_t)i % frames.size()];
+      sys.Integrate(f.pose, img(f.rgb), img(f.depth), img(f.ht), img(f.lt));
+    }
+    for (int i = 0; i < 300; ++i) {
+      const Frame& f = frames[(size_t)i % frames.size()];
+      ref.Integrate(img(f.rgb), img(f.depth), img(f.ht), img(f.lt), md, K, f.pose);
+    }
+    sys.Flush();
+    CHECK(sys.frames_integrated() == 300);
+    CHECK(sys.pool_system_allocs() <= 12);
+    if (std::string(api.backend()) == "cpu-oracle") CHECK(sys.pool_pageable_blocks() > 0);  // (the oracle is slow enough)
     const BoundingCube<float> all{-10, 10, -10, 10, -10, 10};
     CHECK(same(sys.Query(all), ref.GatherVoxels(all)));
   }

@@ -66,55 +66,6 @@ def test_batches_match_oracle(chunks, graph, monkeypatch, make_engine, make_orac
     assert_stats_equal(gpu, cpu)
 
 
-@pytest.mark.parametrize("front_tail", ["1", "0"])
-def test_where_the_serial_role_runs(front_tail, monkeypatch, make_engine, make_oracle):
-    """Ordinary frames (no chained buckets, at most 2 048 requests / 768 winners) have their allocation-order
-    pass done by the last directory workgroup of k_front (front_tail_role) and their new blocks handed to
-    k_integrate as work-list items; RATSDF_FRONT_TAIL=0 keeps the pass inside k_integrate (the form every
-    other frame takes).  Same map either way, and the engine says which form the frames took."""
-    monkeypatch.setenv("RATSDF_FRONT_TAIL", front_tail)
-    vs, md = 0.02, 4.0
-    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
-    monkeypatch.delenv("RATSDF_FRONT_TAIL")
-    frames = synthetic.stream("room", 14, scale=0.25, noise=True, holes=True)
-    frames = frames + frames[::-1][:6]
-    dev = device_frames(frames)
-    lo = 0
-    for n in (1, 2, 9, 8):
-        gpu.integrate_device_batch(make_batch(gpu, frames, dev, lo, lo + n, md))
-        oracle_run(cpu, frames[lo:lo + n], md)
-        lo += n
-        assert_maps_equal(gpu, cpu)
-        assert_stats_equal(gpu, cpu)
-    check_totals(gpu, cpu)
-    c = gpu.pipeline_counters()
-    assert sum(c.values()) == len(frames), c
-    if front_tail == "1":
-        assert c["front_tail"] >= len(frames) - 1, c   # (the first frame of the view may be too large)
-    else:
-        assert c["front_tail"] == 0 and c["in_launch"] == len(frames), c
-
-
-def test_front_tail_at_full_size_with_fallbacks(monkeypatch, make_engine, make_oracle):
-    """640x480 / 5 mm, the benchmark's stream: the first frame of the view files thousands of requests (the
-    role runs inside k_integrate), the following ones are ordinary (tail of k_front); a 60-degree jump in the
-    middle of the batch sends one frame back to the in-launch form.  Parity over the whole sequence."""
-    vs, md = 0.005, 4.0
-    monkeypatch.setenv("RATSDF_FRONT_TAIL", "1")
-    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=16)
-    monkeypatch.delenv("RATSDF_FRONT_TAIL")
-    idx = [0, 1, 2, 3, 4, 64, 65, 66, 5, 6]
-    frames = [synthetic.frame("room", i, noise=True, holes=True) for i in idx]
-    dev = device_frames(frames)
-    gpu.integrate_device_batch(make_batch(gpu, frames, dev, 0, len(frames), md))
-    oracle_run(cpu, frames, md)
-    assert_maps_equal(gpu, cpu)
-    assert_stats_equal(gpu, cpu)
-    check_totals(gpu, cpu)
-    c = gpu.pipeline_counters()
-    assert sum(c.values()) == len(frames) and c["front_tail"] >= 5 and c["in_launch"] + c["in_launch_general"] >= 2, c
-
-
 def test_resolver_and_shared_claim_pass_in_one_frame(make_engine, make_oracle):
     """A frame with chained-bucket requests AND more than 4 096 ordinary ones: the resolver (workgroup 0 of
     k_integrate) resets claims of buckets it locks, and the pass over the requests is shared with the seven
@@ -175,27 +126,6 @@ def test_chained_buckets_in_the_pipeline(bucket_bits, make_engine, make_oracle):
         slow_seen += cpu.last_frame_stats()["slow_requests"]
     check_totals(gpu, cpu)
     assert slow_seen > 0  # the configuration really exercises the chained-bucket paths
-
-
-@pytest.mark.parametrize("kw", [dict(), dict(bucket_bits=9, block_bits=13)])
-def test_serial_role_as_a_launch_of_its_own(kw, monkeypatch, make_engine, make_oracle):
-    """RATSDF_FUSED_SERIAL=0 (read when the engine is created): the frame's allocation-order role runs
-    as k_alloc_rank between k_front and k_integrate instead of inside k_integrate -- the layout the
-    stand-alone test hooks use, kept for A/B measurements.  Same map either way."""
-    monkeypatch.setenv("RATSDF_FUSED_SERIAL", "0")
-    vs, md = 0.02, 4.0
-    gpu, cpu = make_engine(vs, 6 * vs, **kw), make_oracle(vs, 6 * vs, **kw)
-    monkeypatch.delenv("RATSDF_FUSED_SERIAL")
-    frames = synthetic.stream("room", 12, scale=0.25, noise=True, holes=True)
-    dev = device_frames(frames)
-    lo = 0
-    for n in (1, 5, 6):
-        gpu.integrate_device_batch(make_batch(gpu, frames, dev, lo, lo + n, md))
-        oracle_run(cpu, frames[lo:lo + n], md)
-        lo += n
-        assert_maps_equal(gpu, cpu)
-        assert_stats_equal(gpu, cpu)
-    check_totals(gpu, cpu)
 
 
 def test_more_chained_requests_than_the_lds_resolver_takes(make_engine, make_oracle):
