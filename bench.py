@@ -367,6 +367,11 @@ def bench_flythrough(ratsdf, torch, dev, dev_index, cam, vs, md, nframes, cpu_th
                                     p99=round(q(ks, .99), 1), max=round(float(ks[-1]), 1)),
                 allocated_blocks_per_frame=round(tot["allocated_blocks"] / max(tot["frames"], 1), 1),
                 deleted_blocks_per_frame=round(tot["deleted_blocks"] / max(tot["frames"], 1), 1),
+                # (what the update has to do per frame -- compare `frame.avg_visible_blocks` of the repeating sweep:
+                # a map that has been seen once keeps every block of the truncation band, a map that has been swept
+                # many times has had the empty ones carved away)
+                visible_blocks_per_frame=round(tot["visible_blocks"] / max(tot["frames"], 1), 1),
+                updated_voxels_per_frame=round(tot["updated_voxels"] / max(tot["frames"], 1), 1),
                 allocated_blocks_first_frame=None, active_blocks=stats["active_blocks"],
                 map_voxel_bytes=stats["active_blocks"] * 6144,
                 parity=dict(frames=n_par, max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"],

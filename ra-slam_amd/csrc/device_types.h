@@ -130,7 +130,7 @@ struct Ctl {
   int32_t num_free;       // VoxelMemPool::num_free_blocks_
   uint32_t error;         // sticky ratsdf_status
   uint32_t n_sel;         // selected blocks of a query / export
-  uint32_t pad0;
+  int32_t free_low;       // lowest num_free ever: pool indices below it have never been handed out (Table::active)
   unsigned long long totals[5];  // frames, sum V, sum U, sum allocated, sum deleted
   // frames by where their serial role ran: tail of k_front | in k_integrate: ordinary, resolver, general path
   unsigned long long paths[4];
@@ -203,6 +203,13 @@ struct Table {
   uint32_t* dclaim;         // per-bucket claim of the carve pass (its own table: k_integrate both
                             // releases allocation claims and places carve claims)
   unsigned long long* occ;  // occupancy bitmap of the directory: bit e set <=> entries[e].idx >= 0
+  // The live blocks BY POOL INDEX (round 5): active[idx] = {position, idx, hash entry} while pool block idx is in
+  // the directory, idx = -1 otherwise.  Written where an entry's pool index is written (commit_request,
+  // carve_candidate, carve_resolve_slow).  The per-frame visible list is a dense scan of the slots that have ever
+  // been in use -- pool indices are handed out from the top, so those are [Ctl::free_low, num_block) -- instead of a
+  // scan of the 512 KiB occupancy bitmap followed by a gather of 12-byte entries out of the 48 MiB table
+  // (visible_append_role; SURVEY 7 step 6: "persistent compact active-block list").
+  VisItem* active;
   uint32_t num_bucket, num_entry, bucket_mask, entry_mask;
   int32_t num_block;
   // What changed since the last directory-delta export (ratsdf_export_directory_delta_device):

@@ -1199,6 +1199,7 @@ __device__ inline void alloc_rank_role(const Table& tab, Request* req, uint32_t 
     F->n_win = take;
     F->pending = 1;  // the frame (or test pass) now owes a carve_finalize
     ctl->num_free = nf - (int32_t)take;
+    atomicMin(&ctl->free_low, nf - (int32_t)take);  // (Table::active: the slots ever in use; no reply awaited)
   }
   RATSDF_STAMP(ctl->stamps, 11);
 }
@@ -1241,6 +1242,7 @@ __device__ inline bool commit_request(const Table& tab, const Pool& pool, const 
     pe[2] = (uint32_t)idx;
     atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
     if (kMark) mark_dirty(tab, e);
+    reinterpret_cast<uint4*>(tab.active)[idx] = make_uint4(key0(r.x, r.y), key1(r.z), (uint32_t)idx, e);
   }
   *out_idx = idx;
   *out_entry = e;

@@ -82,6 +82,7 @@ __device__ inline void carve_candidate(const Table& tab, const CarveBufs& cb, Ct
     pe[1] = key1(it.z);  // offset = 0
     pe[2] = (uint32_t)-1;
     occ_clear(tab, it.entry);
+    reinterpret_cast<uint32_t*>(tab.active + it.idx)[2] = (uint32_t)-1;  // the slot is empty
     const uint32_t slot = atomicAdd(&F->n_delcand, 1u);
     if (slot < cb.del_cap) {
       cb.del[slot] = DelItem{it.entry, it.idx};
@@ -147,6 +148,9 @@ __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb,
       st_agent(pn + 1, nw.w1 & 0xFFFFu);
       st_agent(pn + 2, (uint32_t)-1);
       occ_clear(tab, nxt);  // the head keeps its bit unless it was its own successor
+      // Table::active: the deleted block's slot is empty, the block that moved into the head lives at `last` now
+      if (freed >= 0) st_agent(reinterpret_cast<uint32_t*>(tab.active + freed) + 2, (uint32_t)-1);
+      if (nxt != last && nw.idx >= 0) st_agent(reinterpret_cast<uint32_t*>(tab.active + nw.idx) + 3, last);
       if (nxt != last) mark_dirty(tab, last);  // (the block that moved into the head: same position, new entry words)
     } else {                                                            // voxel_hash.cu:142-158
       for (uint32_t g = 0; g < tab.num_entry; ++g) {
@@ -166,6 +170,7 @@ __device__ inline void carve_resolve_slow(const Table& tab, const CarveBufs& cb,
           st_agent(pcur + 1, cw.w1 & 0xFFFFu);
           st_agent(pcur + 2, (uint32_t)-1);
           occ_clear(tab, cur);
+          if (freed >= 0) st_agent(reinterpret_cast<uint32_t*>(tab.active + freed) + 2, (uint32_t)-1);
           break;
         }
         last = cur;

@@ -294,6 +294,7 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
       pe[2] = (uint32_t)idx;
       atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
       mark_dirty(tab, e);
+      reinterpret_cast<uint4*>(tab.active)[idx] = make_uint4(w0, w1, (uint32_t)idx, e);
       // Which of the 8 per-XCD lists: the image tile of the pixel that asked first (block_list_of projects the
       // block's centre -- ~100 vector instructions; placement only affects speed, any list is correct).
       // Approximate float arithmetic on purpose; the same on every run.
@@ -354,6 +355,7 @@ __device__ __forceinline__ void front_tail_role(const Table& tab, const FramePar
     F->pending = 1;  // this frame now owes a carve_finalize
     F->front_done = 1;
     ctl->num_free = nf - (int32_t)take;
+    atomicMin(&ctl->free_low, nf - (int32_t)take);  // (Table::active: the slots ever in use; no reply awaited)
     atomicAdd(&ctl->paths[0], 1ull);
 #ifdef RATSDF_STAMPS
     tt[3] = wall_clock64();
@@ -421,7 +423,7 @@ __device__ inline void front_body(const Table& tab, const FrameParams& P, uint32
                         slow_cap, ctl, F, gate, *reinterpret_cast<ReqBuf*>(role_lds));
     }
   } else {
-    if (!RATSDF_DBG(P, 3)) visible_append_role(tab, P, blockIdx.x, vis, seg_cap, ctl, F, gate, role_lds);
+    if (!RATSDF_DBG(P, 3)) visible_append_role(tab, P, blockIdx.x, n_vis_wg, vis, seg_cap, ctl, F, gate, role_lds);
   }
   // (a workgroup whose gate expired does not report: the directory may be half-edited, the tail must not
   // run on it -- the sticky error says the frame is incomplete)
@@ -587,6 +589,7 @@ __device__ inline void serial_frame_role(const Table& tab, const Pool& pool, con
     F->n_winlist = total;
     F->pending = 1;  // this frame now owes a carve_finalize
     ctl->num_free = nf - (int32_t)take;
+    atomicMin(&ctl->free_low, nf - (int32_t)take);  // (Table::active: the slots ever in use; no reply awaited)
   }
   SSTAMP(5);
 #ifdef RATSDF_STAMPS

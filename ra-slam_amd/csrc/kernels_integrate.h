@@ -430,6 +430,7 @@ __device__ __forceinline__ uint32_t serial_role256(EnginePtr E, uint32_t par, ui
     st_agent(&F->n_winlist, total);
     F->pending = 1;  // this frame now owes a carve_finalize
     ctl->num_free = nf - (int32_t)take;
+    atomicMin(&ctl->free_low, nf - (int32_t)take);  // (Table::active: the slots ever in use; no reply awaited)
     atomicAdd(&ctl->paths[n_slow ? 2 : 1], 1ull);
   }
   RATSDF_STAMP(ctl->stamps, 11);

@@ -73,69 +73,88 @@ __device__ inline void select_flags_role(const Table& tab, const FrameParams& P,
 }
 
 // Visibility of the blocks that exist before this frame (check_visibility_kernel +
-// gather_visible_blocks_kernel, voxel_tsdf.cu:98-118): one lane per 64-entry occupancy word tests
-// the allocated entries of its word (any of the 8 corners in view) and the workgroup appends its
-// visible blocks to the frame's 8 work lists (one per XCD, see block_list_of) with one atomicAdd per
-// non-empty list.  The lists are unordered; nothing in a frame depends on their order (blocks are
+// gather_visible_blocks_kernel, voxel_tsdf.cu:98-118): every live block is tested (any of the 8 corners in view)
+// and the workgroup appends its visible blocks to the frame's 8 work lists (one per XCD, see block_list_of) with
+// one atomicAdd per non-empty list.  The lists are unordered; nothing in a frame depends on their order (blocks are
 // independent; the carve pass orders its pool releases by hash entry).
-// `gate()` makes sure the previous frame's queued deletes have happened (carve_resolve_gate); the
-// first load is issued before it so that the two round trips overlap.
-// The set bits of the workgroup's occupancy words are first compacted into an LDS list and then
-// handed out one per lane: a lane that walks the bits of its own word serially pays one dependent
-// memory round trip per block, and the launch waits for the unluckiest lane of 65 536.
+//
+// Where the live blocks come from (round 5): Table::active, one 16-byte item per POOL slot, kept by the code that
+// writes an entry's pool index.  Pool indices are handed out from the top (voxel_mem.cu:24,38-41), so the slots
+// that have ever been in use are [Ctl::free_low, num_block): lane m of the role takes slot num_block - 1 - m (then
+// every `lanes`-th slot further down).  Its first load needs nothing but the lane's own index -- it is issued
+// before anything else, beside the low-water mark it will be checked against -- and is a coalesced 16-byte read:
+// ONE memory round trip before the visibility test.  Until round 5 the role read the 512 KiB occupancy bitmap
+// (256 workgroups), compacted the set bits through LDS and gathered the 12-byte entries out of the 48 MiB table:
+// two dependent round trips, two more barriers, and 256 x 8 returning atomics on the eight list counters where
+// ~20 x 8 are made now (a 640x480 / 5 mm map has ~5 k live blocks: the workgroups below them find empty slots
+// and leave).
+// `gate()` makes sure the previous frame's queued deletes have happened (carve_resolve_gate: they edit `active`
+// with write-through stores); the first load is issued before it so that the two round trips overlap, and is
+// repeated past the caches when the gate had to wait.
 constexpr int kVisWordsPerLane = 1;
-constexpr uint32_t kVisListCap = 2048;  // entries per round (more occupied entries: more rounds)
+constexpr uint32_t kVisListCap = 2048;  // (LDS words the role may use: the front kernels size their buffer by it)
+constexpr int kVisSlotsPerLane = 2;     // pool slots a lane tests per round
+
+__device__ inline uint4 ld_agent_item(const VisItem* p) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+  return make_uint4(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                    __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                    __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                    __hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 
 template <typename Gate>
-__device__ inline void visible_append_role(const Table& tab, const FrameParams& P, uint32_t wg,
+__device__ inline void visible_append_role(const Table& tab, const FrameParams& P, uint32_t wg, uint32_t n_wg,
                                            VisItem* vis, uint32_t seg_cap, Ctl* ctl, FrameCtl* F,
-                                           Gate gate, uint32_t* list /* LDS, kVisListCap words */) {
-  __shared__ uint32_t n_items, more, cnt[kNumLists], base[kNumLists], cnt2[kNumLists];
-  const uint32_t nwords = tab.num_entry >> 6;
-  const uint32_t w = wg * kVisWG + threadIdx.x;
+                                           Gate gate, uint32_t* lds /* role LDS: unused words */) {
+  __shared__ uint32_t cnt[kNumLists], base[kNumLists], cnt2[kNumLists];
+  (void)lds;
   const uint32_t tid = threadIdx.x, nt = block_threads();
-  unsigned long long occ = w < nwords ? tab.occ[w] : 0ull;
+  const uint32_t lanes = n_wg * nt;
+  const uint32_t me = wg * nt + tid;
+  const uint32_t nb = (uint32_t)tab.num_block;
+  const uint4* act = reinterpret_cast<const uint4*>(tab.active);
+  // (an item is "empty" when its pool index is negative; loads are clamped into the array instead of selected
+  // against a constant item -- a select between two 16-byte objects made the compiler park one in scratch memory)
+  uint4 it[kVisSlotsPerLane];
+  it[0] = act[me < nb ? nb - 1u - me : 0u];      // (speculative: whatever the low-water mark says)
+  if (me >= nb) it[0].z = ~0u;
+  int32_t low = ctl->free_low;                    // written by earlier launches only
   const uint32_t g = gate();
   if (g == kGateExpired) return;  // uniform: the directory may be half-edited (sticky error set)
-  if (g != kGateOpen)  // rare: the directory changed after the load above was issued
-    occ = w < nwords ? __hip_atomic_load(&tab.occ[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-  for (;;) {  // one round unless the workgroup's 16 384 entries hold more than kVisListCap blocks
+  const bool stale = g != kGateOpen;  // rare: `active` was edited after the load above was issued
+  if (low < 0) low = 0;
+  const uint32_t used = nb - (uint32_t)low;       // slots [low, nb) have been in use at some time
+  // a workgroup whose first slot lies below the mark has nothing in any round (slots only go down from there)
+  if (wg * nt >= used) return;  // uniform
+  for (uint32_t first = 0; first < used; first += lanes * kVisSlotsPerLane) {  // uniform trip count
     if (tid < kNumLists) {
       cnt[tid] = 0;
       cnt2[tid] = 0;
     }
-    if (tid == 0) {
-      n_items = 0;
-      more = 0;
-    }
     __syncthreads();
-    if (occ) {
-      uint32_t at = atomicAdd(&n_items, (uint32_t)__popcll(occ));
-      while (occ && at < kVisListCap) {
-        const int b = __ffsll((long long)occ) - 1;
-        occ &= occ - 1;
-        list[at++] = w * 64 + (uint32_t)b;
+    uint32_t tag[kVisSlotsPerLane];
+#pragma unroll
+    for (int j = 0; j < kVisSlotsPerLane; ++j) {
+      const uint32_t o = first + (uint32_t)j * lanes + me;   // distance from the top of the pool
+      if (first != 0 || j != 0) {
+        it[j] = act[o < used ? nb - 1u - o : 0u];
+        if (o >= used) it[j].z = ~0u;
       }
-      if (occ) more = 1;
     }
-    __syncthreads();
-    const uint32_t n = n_items < kVisListCap ? n_items : kVisListCap;
-    const bool again = more != 0;
-    // one listed entry per lane: load, test (any corner in view, voxel_tsdf.cu:98-109), pick a list
-    EntryWords first{0, 0, -1};
-    for (uint32_t i = tid; i < n; i += nt) {
-      const uint32_t e = list[i];
-      const EntryWords ew = load_entry(tab.entries, e);
-      if (i == tid) first = ew;
-      const int bx = (int16_t)(ew.w0 & 0xFFFFu), by = (int16_t)(ew.w0 >> 16),
-                bz = (int16_t)(ew.w1 & 0xFFFFu);
-      uint32_t tag = 0;
-      if (block_visible<false>(bx, by, bz, P)) {
-        const int l = block_list_of(bx, by, bz, P);
-        atomicAdd(&cnt[l], 1u);
-        tag = 0x10000000u | ((uint32_t)l << 29);
+#pragma unroll
+    for (int j = 0; j < kVisSlotsPerLane; ++j) {
+      const uint32_t o = first + (uint32_t)j * lanes + me;
+      if (stale && o < used) it[j] = ld_agent_item(tab.active + (nb - 1u - o));
+      tag[j] = ~0u;
+      if (o < used && (int32_t)it[j].z >= 0) {  // a live block
+        const int bx = (int16_t)(it[j].x & 0xFFFFu), by = (int16_t)(it[j].x >> 16), bz = (int16_t)(it[j].y & 0xFFFFu);
+        if (block_visible<false>(bx, by, bz, P)) {
+          const int l = block_list_of(bx, by, bz, P);
+          atomicAdd(&cnt[l], 1u);
+          tag[j] = (uint32_t)l;
+        }
       }
-      list[i] = e | tag;  // entry indices use 27 bits at most (bucket_bits <= 26)
     }
     __syncthreads();
     if (tid < kNumLists) {
@@ -143,23 +162,18 @@ __device__ inline void visible_append_role(const Table& tab, const FrameParams& 
       base[tid] = c ? atomicAdd(&F->n_list[tid * kListStride], c) : 0u;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += nt) {
-      const uint32_t t = list[i];
-      if (!(t & 0x10000000u)) continue;
-      const uint32_t e = t & 0x0FFFFFFFu, l = t >> 29;
+#pragma unroll
+    for (int j = 0; j < kVisSlotsPerLane; ++j) {
+      if (tag[j] == ~0u) continue;
+      const uint32_t l = tag[j];
       const uint32_t pos = base[l] + atomicAdd(&cnt2[l], 1u);
       if (pos < seg_cap - kFreshCap) {  // (the next segment's new-block items start there)
-        const EntryWords ew = i == tid ? first : load_entry(tab.entries, e);
-        uint4 v;
-        v.x = ew.w0;
-        v.y = ew.w1;
-        v.z = (uint32_t)ew.idx;
-        v.w = e;
+        uint4 v = it[j];
+        v.y &= 0xFFFFu;  // {x | y << 16, z, pool index, hash entry}
         reinterpret_cast<uint4*>(vis)[(size_t)l * seg_cap + pos] = v;
       }
     }
-    if (!again) break;  // uniform
-    __syncthreads();
+    __syncthreads();  // (the counters are reset at the top of the next round)
   }
 }
 

@@ -362,7 +362,7 @@ FrameParams ratsdf_engine::base_params() const {
 
 int ratsdf_engine::free_all() {
   if (stream) (void)hipStreamSynchronize(stream);
-  void* ptrs[] = {tab.del_log, tab.del_count, tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
+  void* ptrs[] = {tab.active, tab.del_log, tab.del_count, tab.entries, tab.claim, tab.occ, pool.rgbw, pool.tsdf, pool.segm, pool.heap, ctl,
                   d_stats, d_eng, texA[0], texA[1], texB[0], texB[1], cand[0].list, cand[1].list, cand_count,
                   req, req_k, win_ranks, abitmap, asummary, aprefix,
                   slow, xlocks,
@@ -646,7 +646,9 @@ ratsdf_engine::Geom ratsdf_engine::geometry(int H, int W, bool has_next, int spl
     g.c.first_tile = tiles_a + tiles_b;
     g.c.n_tiles = tiles - tiles_a - tiles_b;
   }
-  g.n_vis_wg = (nwg + kVisWordsPerLane - 1) / kVisWordsPerLane;
+  // visible-list workgroups: one lane per pool slot, from the top of the pool down (kernels_visible.h); 128 of them
+  // cover a map of 65 536 blocks in one round of two loads per lane, larger maps take more rounds
+  g.n_vis_wg = std::min<unsigned>(128u, std::max<unsigned>(1u, ((unsigned)tab.num_block + 2 * 256 - 1) / (2 * 256)));
   // consumer workgroups per candidate list: every 16x16 super-tile reserves kCandReserve entries
   // (one pass of 256 lanes per consumer when nothing overflows); finer voxels need more
   const unsigned supers = ((unsigned)W + 15) / 16 * (((unsigned)H + 15) / 16);
@@ -1040,6 +1042,9 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   // occupancy bitmap, and behind it the dirty bitmap of the directory delta (device_types.h: Table)
   CREATE_CHK(hipMalloc(&t.occ, (size_t)occ_words * 8 * 2));
   CREATE_CHK(hipMemsetAsync(t.occ + occ_words, 0, (size_t)occ_words * 8, e->stream));
+  // the live blocks by pool index (device_types.h: Table::active): every slot empty (idx = -1)
+  CREATE_CHK(hipMalloc(&t.active, (size_t)t.num_block * sizeof(VisItem)));
+  CREATE_CHK(hipMemsetAsync(t.active, 0xFF, (size_t)t.num_block * sizeof(VisItem), e->stream));
   t.del_cap = (uint32_t)t.num_block;
   CREATE_CHK(hipMalloc(&t.del_log, (size_t)t.del_cap * sizeof(uint2)));
   CREATE_CHK(hipMalloc(&t.del_count, 128));
@@ -1094,6 +1099,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
                      e->pool.heap, t.num_block);
   const int32_t nf = t.num_block;
   CREATE_CHK(hipMemcpyAsync(&e->ctl->num_free, &nf, 4, hipMemcpyHostToDevice, e->stream));
+  CREATE_CHK(hipMemcpyAsync(&e->ctl->free_low, &nf, 4, hipMemcpyHostToDevice, e->stream));
   CREATE_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_alloc_rank),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
   hipLaunchKernelGGL(k_check_block_threads, dim3(3), dim3(192), 0, e->stream, &e->ctl->n_sel);

@@ -13,7 +13,7 @@ stats() {  # name, program + args
   rm -rf gpurun_out/kstats_$name
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats_$name -- "$@" > gpurun_out/kstats_$name.log 2>&1 &&
   cp "$(ls -t gpurun_out/kstats_$name/*/*kernel_stats.csv | head -1)" $O/${TAG}_kernel_stats_$name.csv &&
-  tail -1 gpurun_out/kstats_$name.log > $O/${TAG}_bench_line_under_rocprof_$name.json
+  { grep -E '^\{|^S [0-9]' gpurun_out/kstats_$name.log | tail -1 > $O/${TAG}_bench_line_under_rocprof_$name.json; }
   echo "stats $name rc=$?"
 }
 B="--cpu-frames 0 --host-frames 0 --no-secondary"
