@@ -491,3 +491,39 @@ def test_pinned_batches_upload_runs_of_side_by_side_frames(make_engine, make_ora
     assert_maps_equal(gpu, cpu)
     check_totals(gpu, cpu)
     gpu.host_free(arena)
+
+
+def test_visible_list_over_more_pool_slots_than_one_round_takes(make_engine, make_oracle):
+    """The frame's visible list is a scan of the pool slots that have ever been in use (Table::active, round 5):
+    128 workgroups x 256 lanes x 2 slots = 65 536 per round.  Here 80 k blocks far from the camera exist before the
+    frames come, so the frames' own blocks live in pool slots that only the SECOND round reaches; a fifth of the far
+    blocks is deleted again (holes in the slot array, their pool indices re-used by the frames' allocations).  The
+    frames' visible-block counts, directory, free list and a sample of the voxels must be the oracle's."""
+    from parity import assert_directory_equal, assert_heap_equal, assert_voxels_close
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs, threads=8)
+    rng = np.random.default_rng(5)
+    pos = np.unique(rng.integers(1000, 4000, size=(90000, 3)).astype(np.int16), axis=0)   # 160 m and more away
+    for lo in range(0, len(pos), 16384):
+        for _ in range(2):                # (one insertion per bucket per pass)
+            gpu.test_allocate(pos[lo:lo + 16384])
+            cpu.test_allocate(pos[lo:lo + 16384])
+    n_far = gpu.num_active_blocks()
+    assert n_far == cpu.num_active_blocks() and n_far > 80000
+    frames = synthetic.stream("room", 5, scale=0.25, noise=True, holes=True)
+    dev = device_frames(frames)
+    gpu.integrate_device_batch(make_batch(gpu, frames, dev, 0, 2, md))
+    oracle_run(cpu, frames[:2], md)
+    assert_stats_equal(gpu, cpu)
+    gpu.test_delete(pos[::5])
+    cpu.test_delete(pos[::5])
+    gpu.integrate_device_batch(make_batch(gpu, frames, dev, 2, 5, md))
+    oracle_run(cpu, frames[2:], md)
+    assert_stats_equal(gpu, cpu)
+    assert gpu.last_frame_stats()["visible_blocks"] > 50   # (16 cm blocks: the whole view is ~80 of them)
+    _, blocks = assert_directory_equal(gpu, cpu)
+    assert_heap_equal(gpu, cpu)
+    near = blocks["idx"][np.abs(blocks["x"].astype(np.int32)) < 500]
+    assert len(near) > 50
+    assert_voxels_close(gpu, cpu, near)
+    assert_voxels_close(gpu, cpu, blocks["idx"][::97])
