@@ -245,6 +245,12 @@ int ratsdf_free_buffer(void* p);
  * height*width*4 bytes (either may be NULL).  Step size is truncation / 2 (voxel_tsdf.cu:892). */
 int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* virtual_cam, int height, int width,
                    const ratsdf_pose* cam_T_world, float max_depth, uint8_t* rgba, uint8_t* normal);
+/* Rows [row0, row1) of the same rendering (buffers of (row1 - row0) * width * 4 bytes): what one rank of a map
+ * that is spread over GPUs renders when the IMAGE is partitioned (ratsdf.multi.raycast_across_shards) -- a strip
+ * cannot be had by shifting cy, that changes the float arithmetic of the rays.  No reference counterpart. */
+int ratsdf_raycast_rows(ratsdf_engine* e, const ratsdf_intrinsics* virtual_cam, int height, int width,
+                        const ratsdf_pose* cam_T_world, float max_depth, int row0, int row1, uint8_t* rgba,
+                        uint8_t* normal);
 /* Same, output to device buffers, asynchronous on the engine's stream.  HIP engine only. */
 int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* virtual_cam, int height,
                           int width, const ratsdf_pose* cam_T_world, float max_depth, void* d_rgba,

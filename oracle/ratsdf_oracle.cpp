@@ -611,16 +611,19 @@ struct ratsdf_engine {
   }
 
   // ---- ray_cast_kernel, voxel_tsdf.cu:278-374 ---------------------------------------------------
+  // rows [row0, row1) of the H x W image; the buffers hold those rows only
   void raycast(const Intr& K, int H, int W, const Se3& T, float max_depth, uint8_t* rgba,
-               uint8_t* normal) {
+               uint8_t* normal, int row0 = 0, int row1 = -1) {
+    if (row1 < 0) row1 = H;
     const Se3 Ti = T.inverse();
     const Intr Ki = K.inverse();
     const float step_size = trunc / 2;  // voxel_tsdf.cu:892
     const int max_step = f2i(ceilf(max_depth / step_size));
-    parallel_for((size_t)H, [&](size_t ylo, size_t yhi, int) {
-      for (size_t y = ylo; y < yhi; ++y)
+    parallel_for((size_t)(row1 - row0), [&](size_t ylo, size_t yhi, int) {
+      for (size_t yr = ylo; yr < yhi; ++yr)
         for (int x = 0; x < W; ++x) {
-          const size_t idx = y * W + x;
+          const size_t y = yr + (size_t)row0;
+          const size_t idx = yr * W + x;
           uint8_t out_c[4] = {0, 0, 0, 0}, out_n[4] = {0, 0, 0, 0};
           const V3 pc = Ki.mul(V3{(float)x, (float)y, 1.f});
           const float n2 = pc.x * pc.x + (pc.y * pc.y + pc.z * pc.z);
@@ -1081,6 +1084,16 @@ int ratsdf_oracle_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int heig
   if (!e || !K || !P || height <= 0 || width <= 0 || !(max_depth > 0)) return RATSDF_ERR_BAD_ARGUMENT;
   e->raycast(Intr{K->fx, K->fy, K->cx, K->cy}, height, width,
              Se3{{P->qx, P->qy, P->qz, P->qw}, {P->tx, P->ty, P->tz}}, max_depth, rgba, normal);
+  return RATSDF_OK;
+}
+int ratsdf_oracle_raycast_rows(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
+                               const ratsdf_pose* P, float max_depth, int row0, int row1, uint8_t* rgba,
+                               uint8_t* normal) {
+  if (!e || !K || !P || height <= 0 || width <= 0 || !(max_depth > 0) || row0 < 0 || row1 > height || row0 > row1)
+    return RATSDF_ERR_BAD_ARGUMENT;
+  if (row0 == row1) return RATSDF_OK;
+  e->raycast(Intr{K->fx, K->fy, K->cx, K->cy}, height, width,
+             Se3{{P->qx, P->qy, P->qz, P->qw}, {P->tx, P->ty, P->tz}}, max_depth, rgba, normal, row0, row1);
   return RATSDF_OK;
 }
 int ratsdf_oracle_raycast_device(ratsdf_engine*, const ratsdf_intrinsics*, int, int,

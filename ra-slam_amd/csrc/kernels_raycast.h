@@ -64,11 +64,12 @@ __device__ inline float retrieve_tsdf(const Table& tab, const Pool& pool, const 
 
 __global__ __launch_bounds__(256) void k_raycast(Table tab, Pool pool, FrameParams P,
                                                  float step_size, int max_step, uint32_t* out_rgba,
-                                                 uint32_t* out_normal) {
+                                                 uint32_t* out_normal, int row0, int row1) {
+  // rows [row0, row1) of the P.H x P.W image (the whole image: 0, P.H); the output buffers hold those rows only
   const int x = blockIdx.x * 16 + (threadIdx.x & 15);
-  const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (x >= P.W || y >= P.H) return;
-  const int idx = y * P.W + x;
+  const int y = row0 + blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= P.W || y >= row1) return;
+  const int idx = (y - row0) * P.W + x;
   uint32_t o_c = 0, o_n = 0;
   const V3 pc = intr_mul(P.Ki, V3{(float)x, (float)y, 1.f});                 // :289-290
   const float n2 = pc.x * pc.x + (pc.y * pc.y + pc.z * pc.z);

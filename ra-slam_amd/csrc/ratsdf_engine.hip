@@ -1868,13 +1868,14 @@ int ratsdf_free_buffer(void* p) {
   return RATSDF_OK;
 }
 
-int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
-                          const ratsdf_pose* T, float max_depth, void* d_rgba, void* d_normal) {
-  DeviceGuard guard(e ? e->device : -1);
-  if (!guard.ok()) return RATSDF_ERR_DEVICE;
-  if (!e || !K || !T || height <= 0 || width <= 0 || !(max_depth > 0))
+// rows [row0, row1) of the height x width rendering into device buffers that hold those rows
+static int raycast_rows_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
+                               const ratsdf_pose* T, float max_depth, int row0, int row1, void* d_rgba,
+                               void* d_normal) {
+  if (!e || !K || !T || height <= 0 || width <= 0 || !(max_depth > 0) || row0 < 0 || row1 > height || row0 > row1)
     return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
+  if (row0 == row1) return RATSDF_OK;
   FrameParams P = e->base_params();
   P.T = Se3{Quat{T->qx, T->qy, T->qz, T->qw}, V3{T->tx, T->ty, T->tz}};
   P.Ti = se3_inverse(P.T);                      // voxel_tsdf.cu:892 cam_T_world.Inverse()
@@ -1885,21 +1886,29 @@ int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int heig
   const float step_size = e->trunc / 2;         // voxel_tsdf.cu:892
   const float ms = ceilf(max_depth / step_size);
   const int max_step = ms >= 2147483648.f ? 2147483647 : (int)ms;  // voxel_tsdf.cu:298
-  hipLaunchKernelGGL(k_raycast, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, e->stream,
-                     e->tab, e->pool, P, step_size, max_step, (uint32_t*)d_rgba, (uint32_t*)d_normal);
+  hipLaunchKernelGGL(k_raycast, dim3((width + 15) / 16, (row1 - row0 + 15) / 16), dim3(256), 0, e->stream,
+                     e->tab, e->pool, P, step_size, max_step, (uint32_t*)d_rgba, (uint32_t*)d_normal, row0, row1);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }
 
-int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
-                   const ratsdf_pose* T, float max_depth, uint8_t* rgba, uint8_t* normal) {
+int ratsdf_raycast_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
+                          const ratsdf_pose* T, float max_depth, void* d_rgba, void* d_normal) {
   DeviceGuard guard(e ? e->device : -1);
   if (!guard.ok()) return RATSDF_ERR_DEVICE;
-  if (!e || height <= 0 || width <= 0) return RATSDF_ERR_BAD_ARGUMENT;
-  const size_t bytes = (size_t)height * width * 4;
+  return raycast_rows_device(e, K, height, width, T, max_depth, 0, height, d_rgba, d_normal);
+}
+
+int ratsdf_raycast_rows(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
+                        const ratsdf_pose* T, float max_depth, int row0, int row1, uint8_t* rgba, uint8_t* normal) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e || height <= 0 || width <= 0 || row0 < 0 || row1 > height || row0 > row1) return RATSDF_ERR_BAD_ARGUMENT;
+  const size_t bytes = (size_t)(row1 - row0) * width * 4;
+  if (bytes == 0) return raycast_rows_device(e, K, height, width, T, max_depth, row0, row1, nullptr, nullptr);
   uint8_t* d = nullptr;
   HIPCHK(hipMalloc(&d, bytes * 2));
-  int st = ratsdf_raycast_device(e, K, height, width, T, max_depth, d, d + bytes);
+  int st = raycast_rows_device(e, K, height, width, T, max_depth, row0, row1, d, d + bytes);
   if (st == RATSDF_OK) {
     hipError_t err = hipSuccess;
     if (rgba) err = hipMemcpyAsync(rgba, d, bytes, hipMemcpyDeviceToHost, e->stream);
@@ -1910,6 +1919,11 @@ int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int
   }
   (void)hipFree(d);
   return st;
+}
+
+int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
+                   const ratsdf_pose* T, float max_depth, uint8_t* rgba, uint8_t* normal) {
+  return ratsdf_raycast_rows(e, K, height, width, T, max_depth, 0, height, rgba, normal);
 }
 
 // exclusive positions of the set items of a 0/1 mask; returns the number of set items

@@ -70,7 +70,7 @@ SYMBOLS = [
     "prepare_device_batch", "integrate_batch", "host_alloc", "host_free", "synchronize", "stream",
     "profile_enable", "profile_read", "profile_read_frames", "totals", "pipeline_counters",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
-    "download_all", "free_buffer", "raycast", "raycast_device", "gather_valid_mesh", "download_all_mesh",
+    "download_all", "free_buffer", "raycast", "raycast_rows", "raycast_device", "gather_valid_mesh", "download_all_mesh",
     "export_directory_device", "export_directory_delta_device", "import_blocks", "group_create", "group_destroy", "group_size",
     "group_integrate_device_batch", "group_synchronize", "group_profile_enable", "group_profile_read",
     "test_allocate", "test_delete",
@@ -137,6 +137,8 @@ class Library:
         self.fn["raycast"].argtypes = [vp, C.POINTER(Intrinsics), C.c_int, C.c_int, C.POINTER(Pose),
                                        C.c_float, vp, vp]
         self.fn["raycast_device"].argtypes = self.fn["raycast"].argtypes
+        self.fn["raycast_rows"].argtypes = [vp, C.POINTER(Intrinsics), C.c_int, C.c_int, C.POINTER(Pose),
+                                            C.c_float, C.c_int, C.c_int, vp, vp]
         self.fn["gather_valid_mesh"].argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t),
                                                  C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
         self.fn["download_all_mesh"].argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p]
@@ -422,6 +424,16 @@ class Engine:
         _check(self.lib.fn["raycast"](self._h, C.byref(k), height, width, C.byref(p),
                                       float(max_depth), rgba.ctypes.data, normal.ctypes.data),
                "raycast")
+        return rgba, normal
+
+    def raycast_rows(self, intrinsics, height, width, pose, max_depth, row0, row1):
+        """rows [row0, row1) of raycast(): (rgba, normal), (row1 - row0) x W x 4 uint8 each"""
+        k, p = _as_intr(intrinsics), _as_pose(pose)
+        n = max(int(row1) - int(row0), 0)
+        rgba = np.zeros((n, width, 4), dtype=np.uint8)
+        normal = np.zeros((n, width, 4), dtype=np.uint8)
+        _check(self.lib.fn["raycast_rows"](self._h, C.byref(k), height, width, C.byref(p), float(max_depth),
+                                           int(row0), int(row1), rgba.ctypes.data, normal.ctypes.data), "raycast_rows")
         return rgba, normal
 
     def gather_valid_mesh(self):

@@ -659,8 +659,7 @@ def raycast_strip(scratch, parts, intrinsics, height, width, pose, max_depth, ro
     after importing `parts` (export_blocks() tuples): (rgba, normal) strips."""
     for part in parts:
         _import_chunks(scratch, part)
-    rgba, normal = scratch.raycast(intrinsics, height, width, pose, max_depth)
-    return rgba[rows[0]:rows[1]].copy(), normal[rows[0]:rows[1]].copy()
+    return scratch.raycast_rows(intrinsics, height, width, pose, max_depth, rows[0], rows[1])
 
 
 def raycast_across_shards(engine, make_scratch, per_rank, intrinsics, height, width, pose, max_depth, voxel_size,

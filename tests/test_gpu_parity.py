@@ -198,6 +198,10 @@ def test_raycast_matches_oracle(make_engine, make_oracle):
             # one-step difference on a handful of pixels
             assert d.max() <= 1, f"{name}: max byte difference {d.max()}"
             assert (d > 0).mean() < 1e-3, f"{name}: {(d > 0).sum()} bytes differ"
+        # ratsdf_raycast_rows: any row range is that part of the full rendering, byte for byte
+        for r0, r1 in ((0, hh), (5, 22), (hh - 17, hh), (9, 9)):
+            ra, rn = gpu.raycast_rows(k, hh, ww, pose, 8.0, r0, r1)
+            assert np.array_equal(ra, ga[r0:r1]) and np.array_equal(rn, gn[r0:r1]), (r0, r1)
 
 
 def _frame_like(depth, seed=0, pose=None, intr=(300.0, 300.0, 0.0, 0.0)):

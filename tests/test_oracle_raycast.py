@@ -17,6 +17,10 @@ def test_oracle_raycast_renders_wall(make_oracle):
     assert (rgba[~hit] == 0).all() and (normal[~hit] == 0).all()
     # a fronto-parallel wall faces the camera: diffuse shading close to white where ht is low
     assert normal[hit][:, 1].mean() > 100
+    # a row range of the same rendering (ratsdf_raycast_rows: the strips of multi.raycast_across_shards)
+    for r0, r1 in ((0, h), (7, 23), (h - 5, h), (11, 11)):
+        ra, rn = e.raycast_rows(f["intrinsics"], h, w, f["pose"], 8.0, r0, r1)
+        assert np.array_equal(ra, rgba[r0:r1]) and np.array_equal(rn, normal[r0:r1])
     # nothing integrated -> nothing rendered
     e2 = make_oracle(vs, 6 * vs)
     r2, n2 = e2.raycast(f["intrinsics"], h, w, f["pose"], 8.0)
