@@ -147,7 +147,7 @@ class FrameCaster:
             with torch.cuda.stream(self.side):
                 if self.free[slot] is not None:
                     self.side.wait_event(self.free[slot])   # the slot's previous chunk has been integrated
-                if self.world > 1:
+                if dist.is_initialized():   # (a group of one rank too: the collective still runs through RCCL)
                     dist.broadcast(buf, src=self.src, group=self.group)
                 self.hdr[slot].copy_(buf[self.C * self.stride:], non_blocking=True)
                 self.ready[slot].record(self.side)
