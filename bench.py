@@ -680,8 +680,13 @@ def main():
         cores = min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16")))
         cpu = Engine(load_oracle(), vs, 6 * vs, threads=cores)
         chk = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
+        # timed on the regime the GPU is timed on: the first two sweeps of the stream build and saturate the map
+        # (untimed), the rest revisits it (the whole prefix from an empty map was timed before)
+        n_build = 2 * len(frames) if ncpu >= 4 * len(frames) else 0
         t0 = time.perf_counter()
         for j in range(ncpu):
+            if j == n_build:
+                t0 = time.perf_counter()
             f = frames[j % len(frames)]
             cpu.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"],
                           f["pose"])
@@ -694,10 +699,12 @@ def main():
         worst = assert_maps_equal(chk, cpu)
         parity = dict(frames=ncpu, max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"],
                       directory="bit-exact")
-        cpu_baseline = dict(value=ncpu / t_cpu, unit="frames/s", cores=cores, kind="port",
+        cpu_baseline = dict(value=(ncpu - n_build) / t_cpu, unit="frames/s", cores=cores, kind="port",
                             seconds=round(t_cpu, 2),
-                            sample=f"first {ncpu} frames of the same stream from an empty map "
-                                   f"(oracle/ratsdf_oracle.cpp, {cores} threads)")
+                            sample=(f"frames {n_build} .. {ncpu} of the same stream: the map has been built and "
+                                    f"saturated by the {n_build} untimed frames before them, as in the GPU's timed "
+                                    f"region" if n_build else f"first {ncpu} frames of the same stream from an empty map") +
+                                   f" (oracle/ratsdf_oracle.cpp, {cores} threads)")
         chk.close()
         cpu.close()
 
