@@ -140,7 +140,7 @@ def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", en
                                 if engines == 1 else "every 4th launch of the timed region carries HIP events"),
                 launch_also_hosts=("the frame's serial allocation-order role (workgroup 0; the commit of the "
                                    "frame's new blocks waits for it inside the launch)" +
-                                   ("; 80 % of the NEXT frame's candidate pass (its workgroups come first in "
+                                   ("; 90 % of the NEXT frame's candidate pass (its workgroups come first in "
                                     "the grid; engine default at 640x480)" if config == "vga5mm" and
                                     engines == 1 else "")),
                 frame_frac=(round(whole_frame_gbps / HBM_PEAK_GBPS, 4) if whole_frame_gbps else None),

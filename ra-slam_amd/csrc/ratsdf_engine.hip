@@ -196,7 +196,10 @@ struct ratsdf_engine {
   unsigned parity = 0;                   // which texel buffer / candidate set the NEXT frame uses
   bool cand_ready = false;               // that frame's candidate pass has already been enqueued
   bool cand_split_env = false;
-  unsigned cand_split = 20;              // percent of the look-ahead pass placed in k_front,
+#ifndef RATSDF_CAND_SPLIT_DEFAULT
+#define RATSDF_CAND_SPLIT_DEFAULT 10  // (round 5, with the cheaper visible-list role: 5 - 15 % measure the same, 0 and 20 % are 1.5 % slower)
+#endif
+  unsigned cand_split = RATSDF_CAND_SPLIT_DEFAULT;  // percent of the look-ahead pass placed in k_front,
   unsigned cand_split_b = 0;             // in k_alloc_rank; the rest rides in k_integrate
   bool fused_serial = true;              // the frame's serial role rides in k_integrate (no k_alloc_rank)
   // ... or, in ordinary frames, at the tail of k_front (front_tail_role, RATSDF_FRONT_TAIL=1).  Off by default:
@@ -681,7 +684,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
     hipLaunchKernelGGL(k_cand, dim3((job.n_tiles + 3) / 4), dim3(256), 0, stream, job, ctl);
   }
   // Where the NEXT frame's candidate pass rides (interleaved A/B, profiles/r02_split_ab.txt): at
-  // 640x480 20 % in k_front and the rest at the head of k_integrate's grid (10-30 % measure the same,
+  // 640x480 10 % in k_front (20 % until round 5) and the rest at the head of k_integrate's grid (10-30 % measured the same,
   // 0 and 40 % are ~2.5 % slower: k_front is a chain of dependent round trips that a few riders do not
   // lengthen, the voxel update hides the rest); at 1280x720 all of it in k_front (best by 1-3 %, and
   // k_integrate stays the pure voxel update its roofline figure is about)
