@@ -196,6 +196,16 @@ struct ratsdf_engine {
   unsigned parity = 0;                   // which texel buffer / candidate set the NEXT frame uses
   bool cand_ready = false;               // that frame's candidate pass has already been enqueued
   bool cand_split_env = false;
+// (compile-time defaults that tools/ build variants of for same-box sweeps)
+#ifndef RATSDF_GRID_VGA
+#define RATSDF_GRID_VGA 4096
+#endif
+#ifndef RATSDF_GRID_HD
+#define RATSDF_GRID_HD 8192
+#endif
+#ifndef RATSDF_CAND_SPLIT_HD
+#define RATSDF_CAND_SPLIT_HD 100
+#endif
 #ifndef RATSDF_CAND_SPLIT_DEFAULT
 #define RATSDF_CAND_SPLIT_DEFAULT 10  // (round 5, with the cheaper visible-list role: 5 - 15 % measure the same, 0 and 20 % are 1.5 % slower)
 #endif
@@ -665,7 +675,7 @@ ratsdf_engine::Geom ratsdf_engine::geometry(int H, int W, bool has_next, int spl
   // visible blocks).  Round 2 measured 16 384 as best (profiles/r02_grid_sweep.txt); with round 4's kernels 8 192
   // is: 60.3 vs 62.4 us per frame on the 20-frame ping-pong (6 144: 61.9, 12 288: 61.5), 11 316 vs 10 838
   // frames/s on the 416 MB map -- a workgroup takes 1.5 - 2.6 blocks, fewer workgroups to dispatch
-  g.grid = grid_from_env ? integrate_grid : (npix >= 600000 ? 8192u : 4096u);
+  g.grid = grid_from_env ? integrate_grid : (npix >= 600000 ? (unsigned)RATSDF_GRID_HD : (unsigned)RATSDF_GRID_VGA);
   return g;
 }
 
@@ -689,7 +699,7 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   // lengthen, the voxel update hides the rest); at 1280x720 all of it in k_front (best by 1-3 %, and
   // k_integrate stays the pure voxel update its roofline figure is about)
   // (k_integrate<1> runs 512-thread workgroups and hosts no look-ahead: everything in k_front then)
-  const int split = vpl == 1 ? 100 : (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
+  const int split = vpl == 1 ? 100 : (int)(cand_split_env ? cand_split : (npix >= 600000 ? (unsigned)RATSDF_CAND_SPLIT_HD : cand_split));
   const int split_b = (fused_serial && vpl != 1) ? 0 : (int)(cand_split_env ? cand_split_b : 0u);
   const Geom g = geometry(H, W, next != nullptr, split, split_b);
   // shares of the next frame's candidate pass: k_front, k_alloc_rank, k_integrate
@@ -886,7 +896,7 @@ int ratsdf_engine::batch_graph(int n, int H, int W, BatchGraph** out) {
         hipEventCreateWithFlags(&g.ev[i], hipEventDisableTiming) != hipSuccess)
       return fail("staging allocation");
   const size_t npix = (size_t)H * W;
-  const int split = vpl == 1 ? 100 : (int)(cand_split_env ? cand_split : (npix >= 600000 ? 100u : cand_split));
+  const int split = vpl == 1 ? 100 : (int)(cand_split_env ? cand_split : (npix >= 600000 ? (unsigned)RATSDF_CAND_SPLIT_HD : cand_split));
   const Geom g1 = geometry(H, W, true, split, 0);
   const Geom g0 = geometry(H, W, false, 0, 0);
   const uint32_t n_serial_wg = 8u;
