@@ -10,7 +10,9 @@
 //   * terminate() stops the worker at the top of its loop, DISCARDING queued frames, exactly like
 //     the reference (tsdf_module.cc:91-94,119-125).  Knowingly fixed: terminate() is idempotent
 //     (the reference's destructor joins a second time and would throw), and Flush() is added so a
-//     harness can wait for the queue to drain first.
+//     harness can wait for the queue to drain first.  Knowingly different: the queue is BOUNDED by default (its
+//     elements live in a reserve of page-locked blocks; Integrate() waits for the worker when all are in flight --
+//     the reference's queue grows without bound, tsdf_module.cc:99-100); SetQueueBounded(false) restores that.
 //   * Render writes into host buffers instead of OpenGL textures.
 #pragma once
 #include <condition_variable>
