@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--bcast-ring", type=int, default=3,
                     help="--shard: chunk buffers per rank; the broadcasts run (ring - 1) chunks ahead of the integration")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of k_integrate")
+    ap.add_argument("--with-torch", action="store_true",
+                    help="N = 1, diagnostic: device memory through PyTorch as for N > 1 (the process then runs on the "
+                         "HIP runtime bundled with the PyTorch wheel) -- for same-box comparisons of the two runtimes")
     ap.add_argument("--host-frames", type=int, default=60,
                     help="frames timed through the host-image entry point, PCIe included (0 = skip)")
     ap.add_argument("--sync-every", type=int, default=0,
@@ -597,16 +600,33 @@ def main():
         if "WORLD_SIZE" not in os.environ and a.gpus > 1:
             self_launch(a)   # does not return
         a.gpus = world
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the TSDF engine has no CPU path")
     # RATSDF_BENCH_DEVICE / RATSDF_BENCH_BACKEND exist only to rehearse the N > 1 control flow on a
     # one-GPU box (all ranks on device 0, gloo instead of RCCL); the driver never sets them.
     dev_index = int(os.environ.get("RATSDF_BENCH_DEVICE", local_rank))
     backend = os.environ.get("RATSDF_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    dist = None
+    if world == 1 and not a.with_torch:
+        # N = 1 needs device memory and nothing else of PyTorch: hipMalloc / hipMemcpy through the runtime libratsdf.so
+        # links (ratsdf.devmem).  A process has ONE HIP runtime: with torch imported (first, or it finds no GPU) that is
+        # the one bundled with the PyTorch wheel; without, the system ROCm runtime a C / C++ caller of the library links.
+        # Same-box A/B of the two (--with-torch, profiles/r05_runtime_ab.txt): frames/s equal within 1 %, host cost of
+        # enqueueing a frame 1.0 vs 1.9 us -- and no `import torch` (a minute or two on a fresh box) in front of the run.
+        # N > 1 needs torch.distributed and runs on torch's runtime.
+        from ratsdf import devmem
+        if devmem.runtime_library_present():
+            torch = devmem.TorchLike()
+            dev = dev_index
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs an MI355X: the TSDF engine has no CPU path")
+        else:   # (no HIP runtime library to bind by name: PyTorch's allocator then -- decided before anything is loaded)
+            a.with_torch = True
+    if world > 1 or a.with_torch:
+        import torch
+        import torch.distributed as dist
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the TSDF engine has no CPU path")
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -665,7 +685,6 @@ def main():
 
     shard_kw = dict(shard_rank=rank, shard_count=world, shard_slab_bits=2) if (a.shard and world > 1) else {}
     eng = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index, **shard_kw)
-    ext = torch.cuda.ExternalStream(eng.stream(), device=dev)
 
     # ---- parity + CPU baseline on a bounded prefix (rank 0, N = 1) ---------------------------
     cpu_baseline = None
@@ -811,80 +830,21 @@ def main():
     #               ratsdf::TSDFSystem's worker does with its queue); uploads on a copy stream
     #   pinned      the same call on page-locked buffers (ratsdf_host_alloc), 32 frames per call:
     #               no staging copy, bound by the PCIe link (63 GB/s spec)
+    # (Measured in a CHILD process that does not load PyTorch -- tools/host_paths.py -- like the C++ TSDFSystem leg: the
+    # system ROCm runtime a C / C++ caller links, whatever this process runs on.)
     host_path = None
     pinned_path = None
     if rank == 0 and world == 1 and a.host_frames > 0:
-        hp = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
-        nh = min(a.host_frames, len(frames))
-        for f in frames[:4]:
-            hp.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"], f["pose"])
-        hp.synchronize()
-        nh_total = 0
-        th = time.perf_counter()
-        for _ in range(5):   # (the calls do not wait for their frames: the timed region ends with a synchronisation)
-            for f in frames[:nh]:
-                hp.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], a.max_depth, f["intrinsics"], f["pose"])
-            nh_total += nh
-        hp.synchronize()
-        th = time.perf_counter() - th
-        nh = nh_total
-        hp.integrate_batch(frames[:8], a.max_depth)
-        hp.synchronize()
-        nb = 0
-        tb = time.perf_counter()
-        for _ in range(4):
-            for c0 in range(0, len(frames) - 7, 8):
-                hp.integrate_batch(frames[c0:c0 + 8], a.max_depth)
-                nb += 8
-        hp.synchronize()   # (the calls return when the images are staged, not when the frames are integrated)
-        tb = time.perf_counter() - tb
-        bytes_per_frame = sum(frames[0][k].nbytes for k in ("rgb", "depth", "ht", "lt"))
-        host_path = dict(frames_per_s=round(nh / th, 1), frames=nh, batched_frames_per_s=round(nb / tb, 1),
-                         batched_frames=nb, batched_h2d_gbps=round(nb * bytes_per_frame / tb / 1e9, 1),
-                         note="ratsdf_integrate with pageable host images, one call per frame (the calling "
-                              "convention of examples/tsdf/offline.cc:169): staging copy into the engine's "
-                              "page-locked ring (4.6 MB/frame, 4 threads), H2D on a copy stream, frame enqueued; "
-                              "one synchronisation at the end of the timed region; batched = "
-                              "ratsdf_integrate_batch, 8 frames per call from pageable memory")
-        # page-locked copies of the stream's frames: ONE arena, a block of 16 bytes per pixel per frame, the
-        # frame's images side by side in it as depth | ht | lt | rgb -- the order and stride of the engine's staging
-        # ring, so a frame goes up as one copy and neighbouring frames up to four per copy (include/ratsdf.h,
-        # ratsdf_integrate_batch; ratsdf::TSDFSystem's queue lays its frames out the same way)
-        pin = []
-        npx = frames[0]["depth"].size
-        arena = hp.host_alloc((len(frames) * npx * 16,), np.uint8)
-        for i, f in enumerate(frames):
-            blk = arena[i * npx * 16:(i + 1) * npx * 16]
-            g = dict(f)
-            g["depth"] = blk[:npx * 4].view(np.float32).reshape(f["depth"].shape)
-            g["ht"] = blk[npx * 4:npx * 8].view(np.float32).reshape(f["ht"].shape)
-            g["lt"] = blk[npx * 8:npx * 12].view(np.float32).reshape(f["lt"].shape)
-            g["rgb"] = blk[npx * 12:npx * 15].reshape(f["rgb"].shape)
-            for k in ("rgb", "depth", "ht", "lt"):
-                g[k][...] = f[k]
-            pin.append(g)
-        C = 32
-        chunks = [pin[c0:c0 + C] for c0 in range(0, len(pin) - C + 1, C)] or [pin]
-        calls = [hp.make_host_batch(ch, a.max_depth, pinned=True) for ch in chunks]   # pointer tables built once
-        hp.integrate_host_batch(calls[0])
-        hp.synchronize()
-        npin = 0
-        tp = time.perf_counter()
-        while npin < 2000:
-            for ch, call in zip(chunks, calls):
-                hp.integrate_host_batch(call)
-                npin += len(ch)
-        hp.synchronize()   # (a call returns when its images have been uploaded)
-        tp = time.perf_counter() - tp
-        pinned_path = dict(frames_per_s=round(npin / tp, 1), frames=npin,
-                           h2d_gbps=round(npin * bytes_per_frame / tp / 1e9, 1), link_gbps_spec=63.0,
-                           note=f"ratsdf_integrate_batch(pinned=1), {len(chunks[0])} frames per call from one "
-                                "ratsdf_host_alloc arena (a 16 B/pixel block per frame, depth | ht | lt | rgb): up to "
-                                "4 neighbouring frames per copy, on the engine's two copy streams, up to 15 frames "
-                                "ahead of the integration; a call returns when its uploads are done, one "
-                                "synchronisation at the end of the timed region")
-        hp.host_free(arena)
-        hp.close()
+        import subprocess
+        r = subprocess.run([sys.executable, str(ROOT / "tools" / "host_paths.py"), "--cam", a.cam, "--scene", a.scene,
+                            "--voxel", str(vs), "--max-depth", str(a.max_depth), "--frames", str(len(frames)),
+                            "--host-frames", str(a.host_frames), "--device", str(dev_index)],
+                           capture_output=True, text=True, timeout=600)
+        if r.returncode == 0 and r.stdout.strip():
+            hp_out = json.loads(r.stdout.strip().splitlines()[-1])
+            host_path, pinned_path = hp_out["host_image_path"], hp_out["pinned_h2d_path"]
+        else:
+            host_path = dict(error=(r.stdout + r.stderr)[-400:])
 
     # ---- S streams on this GPU through one launch triple per frame step ------------------------
     multi = None
@@ -930,6 +890,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "hip_runtime": ("the system ROCm runtime libratsdf.so links (no PyTorch in this process: device memory "
+                            "through ratsdf.devmem)" if (world == 1 and not a.with_torch) else
+                            "the HIP runtime bundled with the PyTorch wheel (torch.distributed / RCCL need torch in the process)"),
             "config": {
                 "workload": f"synthetic '{a.scene}' RGB-D+ht/lt stream, {a.cam} intrinsics {W}x{H}, "
                             f"voxel {vs * 1e3:g} mm, truncation {6 * vs * 1e3:g} mm, max depth "
