@@ -1,3 +1,4 @@
+# k_front per-launch counters, round-4 visible-list role (build variant libratsdf_oldvis.so = commit d937e3e, tools/build_variant.sh) vs the current build
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 B=$GRAFT_REPO_ROOT/ra-slam_amd/csrc/build

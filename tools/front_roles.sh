@@ -1,3 +1,4 @@
+# k_front role ablations and look-ahead split on the diagnostic build (RATSDF_DEBUG 3 / 11 / 12, RATSDF_CAND_SPLIT)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 S=$GRAFT_REPO_ROOT/ra-slam_amd/csrc/build/libratsdf_stamps.so

@@ -1,3 +1,4 @@
+# same-box A/B of the HIP runtime under bench.py at N = 1: no PyTorch in the process vs --with-torch
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 L="--cpu-frames 0 --host-frames 0 --no-secondary --streams 0"
 for i in 1 2 3; do
