@@ -551,9 +551,9 @@ def _framecast_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_one_stream_broadcast_to_two_subvolume_ranks_gloo(oracle_lib):
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_stream_broadcast_to_two_subvolume_ranks_gloo(world, oracle_lib):
     import torch.multiprocessing as mp
-    world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
@@ -567,7 +567,7 @@ def test_one_stream_broadcast_to_two_subvolume_ranks_gloo(oracle_lib):
             p.kill()
             pytest.fail("rank hung")
         assert p.exitcode == 0
-    assert dict(ret) == {0: "ok", 1: "ok"}
+    assert dict(ret) == {r: "ok" for r in range(world)}
 
 
 def test_wire_chunk_layout():
