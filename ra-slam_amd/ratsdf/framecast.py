@@ -89,6 +89,7 @@ class Chunk:
         self.has_sem, self.frame_no, self.checksum = has_sem, frame_no, checksum
         self.d_rgb = self.d_depth = self.d_ht = self.d_lt = None   # device path: raw pointers per frame
         self.frames = None                                         # host path: numpy views per frame
+        self.pose_arr = self.intr_arr = None                       # [n, 7] / [n, 4] float32 copies of the headers
 
 
 class FrameCaster:
@@ -179,9 +180,11 @@ class FrameCaster:
         if not np.all(hi[:n, 12] == 1):
             raise RuntimeError("chunk header: valid frames are not a prefix")
         md = float(hf[0, 11]) if n else 0.0
-        ch = Chunk(slot, n, self.H, self.W, md, [tuple(float(v) for v in hf[i, 0:7]) for i in range(n)],
-                   [tuple(float(v) for v in hf[i, 7:11]) for i in range(n)], [bool(hi[i, 13]) for i in range(n)],
-                   [int(hi[i, 15]) for i in range(n)], [int(hu[i, 14]) for i in range(n)])
+        ch = Chunk(slot, n, self.H, self.W, md, [tuple(r) for r in hf[:n, 0:7].tolist()],
+                   [tuple(r) for r in hf[:n, 7:11].tolist()], [bool(v) for v in hi[:n, 13].tolist()],
+                   hi[:n, 15].tolist(), hu[:n, 14].tolist())
+        ch.pose_arr = np.ascontiguousarray(hf[:n, 0:7])     # (copies: the slot's header buffer is reused)
+        ch.intr_arr = np.ascontiguousarray(hf[:n, 7:11])
         npix, st = self.npix, self.stride
         rgb_off = npix * (12 if self.semantic else 4)
         if self.device is None:
@@ -197,12 +200,12 @@ class FrameCaster:
                     f["lt"] = img[npix * 8:npix * 12].view(np.float32).reshape(self.H, self.W)
                 ch.frames.append(f)
         else:
-            base = buf.data_ptr()
-            ch.d_depth = [base + i * st for i in range(n)]
-            ch.d_rgb = [base + i * st + rgb_off for i in range(n)]
+            off = buf.data_ptr() + np.arange(n, dtype=np.int64) * st
+            ch.d_depth = off.tolist()
+            ch.d_rgb = (off + rgb_off).tolist()
             sem = self.semantic and all(ch.has_sem)
-            ch.d_ht = [base + i * st + npix * 4 for i in range(n)] if sem else None
-            ch.d_lt = [base + i * st + npix * 8 for i in range(n)] if sem else None
+            ch.d_ht = (off + npix * 4).tolist() if sem else None
+            ch.d_lt = (off + npix * 8).tolist() if sem else None
         if verify:
             for i in range(n):
                 img = buf[i * st:i * st + rgb_off + npix * 3]
@@ -237,6 +240,13 @@ def integrate_chunk(engine, chunk, batch_cache=None):
         for f in chunk.frames:
             engine.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], chunk.max_depth, f["intrinsics"], f["pose"])
         return
-    batch = engine.make_batch(chunk.d_rgb, chunk.d_depth, chunk.d_ht, chunk.d_lt, chunk.height, chunk.width,
-                              chunk.max_depth, chunk.intrinsics, chunk.poses)
-    engine.integrate_device_batch(batch)
+    # (the pointer tables of ratsdf_integrate_device_batch straight from the header arrays: per-frame Python objects
+    # cost more host time than a 15-frame chunk takes on the GPU)
+    import ctypes as C
+    from ._abi import Intrinsics, Pose
+    n = chunk.n
+    arr = lambda ptrs: (C.c_void_p * n)(*ptrs) if ptrs is not None else None
+    ks = (Intrinsics * n).from_buffer_copy(chunk.intr_arr.tobytes())
+    ps = (Pose * n).from_buffer_copy(chunk.pose_arr.tobytes())
+    engine.integrate_device_batch((n, arr(chunk.d_rgb), arr(chunk.d_depth), arr(chunk.d_ht), arr(chunk.d_lt),
+                                   int(chunk.height), int(chunk.width), float(chunk.max_depth), ks, ps))
