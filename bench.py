@@ -223,6 +223,60 @@ def bench_streams(ratsdf, torch, dev, dev_index, S, scene, cam, vs, md, nfr, ste
     return out
 
 
+def bench_tsdf_only(ratsdf, frames, d_rgb, d_depth, intr, pose, vs, md, dev_index, cpu_threads, steps=20, reps=3):
+    """BASELINE configs[1]'s shape: the same stream without semantics (ht / lt NULL = the all-ones images of
+    modules/tsdf_module.cc:27-31), inputs resident in HBM.  A map that has never seen ht / lt holds probability 0.5
+    everywhere and a TSDF-only frame leaves it there, so the engine neither loads nor stores it for existing blocks
+    (FrameParams::segm_live): SURVEY 8d's TSDF-only algorithmic bytes, 7 W H + 12 V + 16 U."""
+    from oracle_binding import load_oracle
+    from parity import assert_maps_equal
+    from ratsdf._abi import Engine
+    H, W = frames[0]["depth"].shape
+    n = len(frames)
+    cpu = Engine(load_oracle(), vs, 6 * vs, threads=cpu_threads)
+    chk = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
+    n_par = 2 * n
+    for j in range(n_par):
+        f = frames[j % n]
+        cpu.integrate(f["rgb"], f["depth"], None, None, md, f["intrinsics"], f["pose"])
+        chk.integrate_device(d_rgb[j % n].data_ptr(), d_depth[j % n].data_ptr(), 0, 0, H, W, md, intr[j % n], pose[j % n])
+    worst = assert_maps_equal(chk, cpu)
+    chk.close()
+    cpu.close()
+    eng = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index)
+    batch = eng.make_batch([t.data_ptr() for t in d_rgb], [t.data_ptr() for t in d_depth], None, None, H, W, md, intr, pose)
+    for _ in range(3):
+        eng.integrate_device_batch(batch)
+    eng.synchronize()
+    eng.totals(reset=True)
+    eng.profile_enable(True)
+    rep_dt = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.integrate_device_batch(batch)
+        eng.synchronize()
+        rep_dt.append(time.perf_counter() - t0)
+    k_ms, k_n = eng.profile_read()
+    eng.profile_enable(False)
+    tot = eng.totals()
+    eng.close()
+    dt = sorted(rep_dt)[len(rep_dt) // 2]
+    fps = steps * n / dt
+    fr = max(tot["frames"], 1)
+    b_alg = 7.0 * W * H + 12.0 * tot["visible_blocks"] / fr + 16.0 * tot["updated_voxels"] / fr
+    k_us = k_ms / max(k_n, 1) * 1e3
+    return dict(workload=f"the same stream without ht / lt (TSDF-only), {W}x{H}, voxel {vs * 1e3:g} mm", value=round(fps, 1),
+                unit="frames/s", steps=steps, reps=reps,
+                roofline=dict(bound="hbm", kernel="k_integrate", alg_bytes_per_launch=round(b_alg),
+                              alg_bytes="7 W H + 12 V + 16 U (no probability traffic: SURVEY 8d's TSDF-only figure)",
+                              avg_launch_us=round(k_us, 2), achieved=round(b_alg / (k_us * 1e-6) / 1e9, 1) if k_n else None,
+                              peak=HBM_PEAK_GBPS, unit="GB/s",
+                              frac=round(b_alg / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if k_n else None, launches=k_n),
+                parity=dict(frames=n_par, max_abs_tsdf=worst["tsdf"], max_abs_prob=worst["prob"], directory="bit-exact",
+                            note="probability exactly 0.5 in both"))
+
+
 def bench_secondary(ratsdf, torch, dev, dev_index, md, cpu_threads, config="hd2mm"):
     """Bounded 1280x720 / 2 mm / L515 legs (BASELINE configs[3] workload on one GPU; north_star asks
     for both stream sizes): throughput, k_integrate roofline and parity against the CPU oracle.
@@ -857,6 +911,7 @@ def main():
     secondary = None
     flythrough = None
     system_path = None
+    tsdf_only = None
     if rank == 0 and world == 1 and a.config == "vga5mm" and not a.no_secondary and a.cpu_frames > 0:
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         nthr = min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16")))
@@ -865,6 +920,7 @@ def main():
         flythrough = bench_flythrough(ratsdf, torch, dev, dev_index, a.cam, vs, a.max_depth, a.flythrough_frames, nthr,
                                       n_par=a.flythrough_frames)  # checked against the oracle over the whole pass
         system_path = bench_tsdf_system(frames, a.max_depth, vs)
+        tsdf_only = bench_tsdf_only(ratsdf, frames, d_rgb, d_depth, intr, pose, vs, a.max_depth, dev_index, nthr)
 
     nframes = a.steps * len(frames)
     if rank == 0:
@@ -920,6 +976,7 @@ def main():
             "host_image_path": host_path,
             "pinned_h2d_path": pinned_path,
             "tsdf_system_path": system_path,
+            "tsdf_only": tsdf_only,
             "multi_stream": multi,
             "secondary": secondary,
             "flythrough": flythrough,

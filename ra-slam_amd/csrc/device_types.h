@@ -191,6 +191,11 @@ struct FrameParams {
   int W, H;
   int S;        // rank stride: max ray samples per pixel
   int has_sem;
+  // 0: no frame with ht / lt has ever been integrated into this map (and no block imported): every probability in it
+  // is exactly the initial 0.5 and a TSDF-only frame leaves it there -- log(0.5 / 0.5) = 0, exp(0) = 1, 1 / 2 -- so
+  // the update neither loads, computes nor stores the probability of existing blocks (new blocks are still
+  // initialised): SURVEY 8d's TSDF-only bytes, 16 instead of 24 per updated voxel
+  int segm_live;
   int shard_rank, shard_count, shard_slab_bits;
   int shard_bias;          // multiple of shard_count, >= 32768 (device_math.h: shard_owned)
   uint32_t shard_magic;    // floor(2^32 / shard_count) + 1

@@ -529,9 +529,19 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
   if (!RATSDF_DBG(P, 5)) VecIO<VPL>::load(pool.rgbw + v, cv);
   else
     for (int j = 0; j < VPL; ++j) cv[j] = 0;
+  // (FrameParams::segm_live == 0: a map that has never seen ht / lt holds 0.5 in every voxel and a TSDF-only frame
+  // leaves it there, so the probability of existing blocks is neither loaded nor stored)
+  const bool segm_live = P.segm_live != 0;  // uniform
   if (!fresh) {
     VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.tsdf + v), tv);
-    VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.segm + v), sv);
+    if (segm_live) {
+      VecIO<VPL>::load(reinterpret_cast<const uint32_t*>(pool.segm + v), sv);
+    } else {
+      // (whatever the registers hold: the probability computed from it is never stored.  An empty asm "defines"
+      // them without an instruction -- loading the constant 0.5 here cost the kernel registers it does not have)
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) asm volatile("" : "=v"(sv[j]));
+    }
   }
   const int gy = (int16_t)((int16_t)(item.y << 3) + ty);
   const int gz = (int16_t)((int16_t)(item.z << 3) + tz);
@@ -752,7 +762,9 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
         if (!upd[j]) continue;
         tv[j] = __float_as_uint(t_new[j]);
         cv[j] = ow[j];
-        // probability: see the loop below
+        // probability: see the loop below.  (P.segm_live == 0: not loaded, not stored, and what is computed here from
+        // an unloaded register is dropped -- a uniform branch around these twelve instructions cost the kernel two
+        // vector registers it does not have, i.e. scratch)
         const float pr = __uint_as_float(sv[j]);
         const float odds = pr * __builtin_amdgcn_rcpf(1.f - pr);
         const float L = __builtin_amdgcn_logf(odds) * 0.69314718f;
@@ -819,7 +831,7 @@ __device__ inline void integrate_block(const Pool& pool, const FrameParams& P, c
   WSTAMP(3);
   if ((nupd || fresh) && !RATSDF_DBG(P, 5) && !RATSDF_DBG(P, 7)) {
     VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.tsdf + v), tv);
-    VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), sv);
+    if (segm_live || fresh) VecIO<VPL>::store(reinterpret_cast<uint32_t*>(pool.segm + v), sv);
     VecIO<VPL>::store(pool.rgbw + v, cv);
   }
   // space_carving_kernel, :253-276: "min |tsdf| over the block >= 0.9" with fminf's NaN rule (a NaN

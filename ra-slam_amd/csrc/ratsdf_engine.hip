@@ -284,6 +284,8 @@ struct ratsdf_engine {
   // frame either of them has taken) and neither waits for its frames: what a slot's next user has to wait for is
   // in the slot's two events, whichever call recorded them -- no fence between calls.
   uint64_t stage_no = 0;
+  // a frame with ht / lt has been integrated, or blocks were imported with their probabilities (FrameParams::segm_live)
+  mutable bool ever_sem = false;
   bool sync_integrate = false;         // RATSDF_SYNC_INTEGRATE=1: wait for every frame (the round-3 behaviour)
   HostCopyPool* copy_pool = nullptr;
 
@@ -364,6 +366,7 @@ FrameParams ratsdf_engine::base_params() const {
   P.W = P.H = 0;
   P.S = 1;
   P.has_sem = 0;
+  P.segm_live = 1;
   P.shard_rank = shard_rank;
   P.shard_count = shard_count;
   P.shard_slab_bits = shard_slab_bits;
@@ -608,6 +611,8 @@ FrameParams ratsdf_engine::frame_params(const FrameIn& in, int H, int W, float m
   P.H = H;
   P.S = S;
   P.has_sem = (in.ht && in.lt) ? 1 : 0;
+  if (P.has_sem) ever_sem = true;  // (frames are prepared in the order they are integrated)
+  P.segm_live = ever_sem ? 1 : 0;
   return P;
 }
 
@@ -2164,6 +2169,7 @@ int ratsdf_import_blocks(ratsdf_engine* e, int32_t n, const int16_t* bp, const f
   if (!e || n < 0 || (n > 0 && (!bp || !tsdf || !rgbw || !prob))) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   if (n == 0) return e->sticky();
+  e->ever_sem = true;  // (the blocks come with their probabilities: FrameParams::segm_live)
   int st = e->ensure_image(0, (size_t)n);
   if (st != RATSDF_OK) return st;
   int16_t* d_pos = nullptr;

@@ -527,3 +527,47 @@ def test_visible_list_over_more_pool_slots_than_one_round_takes(make_engine, mak
     assert len(near) > 50
     assert_voxels_close(gpu, cpu, near)
     assert_voxels_close(gpu, cpu, blocks["idx"][::97])
+
+
+def test_tsdf_only_frames_skip_the_probability_only_while_it_is_untouched(make_engine, make_oracle):
+    """A map that has never seen ht / lt holds 0.5 in every voxel and a TSDF-only frame leaves it there, so the update
+    neither loads nor stores the probability of existing blocks (FrameParams::segm_live, SURVEY 8d's TSDF-only bytes).
+    The moment a frame with semantics arrives -- or blocks are imported with their probabilities -- every later frame,
+    TSDF-only ones included, takes the full update again.  Against the oracle over TSDF-only -> semantic -> TSDF-only
+    batches (the switch happens INSIDE a batch), with the probability exactly 0.5 before the switch."""
+    vs, md = 0.02, 4.0
+    gpu, cpu = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    frames = synthetic.stream("room", 12, scale=0.25, noise=True, holes=True)
+    nosem = [dict(f, ht=None, lt=None) for f in frames]
+    seq = nosem[:4] + frames[4:8] + nosem[8:12]
+    dev_all = device_frames(frames)
+    for lo, hi in ((0, 3), (3, 6), (6, 12)):    # batch 2 = one TSDF-only frame, then two with semantics
+        chunk = seq[lo:hi]
+        for i, f in enumerate(chunk):          # (a batch has one semantics setting: frame by frame where it is mixed)
+            d = dev_all[lo + i]
+            sem = f["ht"] is not None
+            gpu.integrate_device(d["rgb"].data_ptr(), d["depth"].data_ptr(), d["ht"].data_ptr() if sem else 0,
+                                 d["lt"].data_ptr() if sem else 0, *f["depth"].shape, md, f["intrinsics"], f["pose"])
+        oracle_run(cpu, chunk, md)
+        assert_maps_equal(gpu, cpu)
+        if hi <= 3:
+            _, blocks = gpu.dump_directory()
+            _, _, p = gpu.dump_voxels(blocks["idx"])
+            assert p.size and np.all(p == np.float32(0.5))
+    check_totals(gpu, cpu)
+    # batches of TSDF-only frames on a fresh map, then imported blocks switch the full update on
+    gpu2, cpu2 = make_engine(vs, 6 * vs), make_oracle(vs, 6 * vs)
+    dev = device_frames(frames, semantic=False)
+    gpu2.integrate_device_batch(make_batch(gpu2, nosem, dev, 0, 6, md))
+    oracle_run(cpu2, nosem[:6], md)
+    assert_maps_equal(gpu2, cpu2)
+    far = np.array([[300, 300, 300], [301, 300, 300]], dtype=np.int16)
+    t = np.full((2, 512), 0.25, np.float32)
+    pr = np.full((2, 512), 0.8, np.float32)
+    c = np.zeros((2, 512), dtype=[("r", "u1"), ("g", "u1"), ("b", "u1"), ("weight", "u1")])
+    c["weight"] = 3
+    for e in (gpu2, cpu2):
+        e.import_blocks(far, t, c, pr)
+    gpu2.integrate_device_batch(make_batch(gpu2, nosem, dev, 6, 12, md))
+    oracle_run(cpu2, nosem[6:12], md)
+    assert_maps_equal(gpu2, cpu2)

@@ -15,6 +15,7 @@ import numpy as np
 import ratsdf
 from ratsdf import synthetic
 hd = len(sys.argv) > 1 and sys.argv[1] == "hd"
+nosem = "nosem" in sys.argv[1:]   # TSDF-only frames (ht / lt NULL): BASELINE configs[1]'s shape
 cam, vs, n = ("l515_720p", 0.002, 15) if hd else ("scannet", 0.005, 45)
 half = [synthetic.frame("room", i, cam=cam, noise=True, holes=True) for i in range(n)]
 frames = half + half[::-1]
@@ -35,7 +36,8 @@ def up(a):
 
 d = [{k: up(f[k]) for k in ("rgb", "depth", "ht", "lt")} for f in half]
 d = d + d[::-1]
-batch = eng.make_batch([x["rgb"] for x in d], [x["depth"] for x in d], [x["ht"] for x in d], [x["lt"] for x in d],
+batch = eng.make_batch([x["rgb"] for x in d], [x["depth"] for x in d], None if nosem else [x["ht"] for x in d],
+                       None if nosem else [x["lt"] for x in d],
                        H, W, 4.0, [f["intrinsics"] for f in frames], [f["pose"] for f in frames])
 for _ in range(3):
     eng.integrate_device_batch(batch)
@@ -47,4 +49,4 @@ for rep in range(5):
         eng.integrate_device_batch(batch)
     eng.synchronize()
     best = max(best, 40 * len(frames) / (time.perf_counter() - t0))
-print(f"no-torch process, {W}x{H} / {vs * 1e3:g} mm: {best:.1f} frames/s (best of 5 x 40 batches of {len(frames)})")
+print(f"no-torch process, {W}x{H} / {vs * 1e3:g} mm{', TSDF-only' if nosem else ''}: {best:.1f} frames/s (best of 5 x 40 batches of {len(frames)})")
