@@ -328,6 +328,18 @@ int ratsdf_export_directory_delta_device(ratsdf_engine* e, void* d_payload, int3
  * frames integrated afterwards would update imported blocks like any other.  No reference counterpart. */
 int ratsdf_import_blocks(ratsdf_engine* e, int32_t n, const int16_t* block_pos, const float* tsdf,
                          const ratsdf_rgbw* rgbw, const float* prob);
+/* The same exchange with the voxel data staying in device memory (what the across-shard exports use under RCCL: the
+ * all-gather's device buffer is filled by the owner's engine and read by the receiver's scratch engine, no host copy
+ * of voxel data).  d_block_pos = n x 3 int16, d_voxels = n records of 1536 32-bit words {tsdf[512] | rgbw[512] |
+ * prob[512]}, voxel order x + 8y + 64z -- both DEVICE pointers of the engine's device.
+ *   export: record i = the voxels of the block at position i; a block the map does not hold leaves a record of zeros
+ *           and is counted in *d_missing (int32, device).  Asynchronous on the engine's stream.
+ *   import: as ratsdf_import_blocks.  Reads the buffers on the engine's stream (order them before it, e.g. by
+ *           synchronising the producer) and returns when the blocks are in.
+ * HIP engine only; the oracle reports RATSDF_ERR_NOT_IMPLEMENTED.  No reference counterpart. */
+int ratsdf_export_blocks_device(ratsdf_engine* e, int32_t n, const void* d_block_pos, void* d_voxels,
+                                void* d_missing);
+int ratsdf_import_blocks_device(ratsdf_engine* e, int32_t n, const void* d_block_pos, const void* d_voxels);
 
 /* ---- test / inspection hooks (mirror the reference's gtest kernels) ------------------------- */
 /* One allocation pass over an explicit list of block positions (3 x int16 each), request i having

@@ -270,11 +270,14 @@ __global__ void k_export_entries(const VisItem* sel, const uint32_t* n_sel, Entr
   }
 }
 
-// ratsdf_import_blocks: the voxels of block i of the list into the pool block its directory entry names; one wave
-// per block; blocks the directory does not hold are counted in *missing.
+// ratsdf_import_blocks[_device]: the voxels of block i of the list into the pool block its directory entry names; one
+// wave per block; blocks the directory does not hold are counted in *missing.  `stride`: 32-bit words between
+// consecutive blocks of one array (512: three arrays of n x 512 words, the host entry point's layout; 1536: one
+// record {tsdf | rgbw | prob} per block, the device entry points' layout -- tsdf / rgbw / prob then point 0 / 512 /
+// 1024 words into the first record).
 __global__ __launch_bounds__(256) void k_import_voxels(Table tab, Pool pool, const int16_t* pos, int n,
                                                        const float* tsdf, const uint32_t* rgbw, const float* prob,
-                                                       uint32_t* missing) {
+                                                       uint32_t stride, uint32_t* missing) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * block_threads() + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * block_threads()) >> 6;
@@ -285,11 +288,32 @@ __global__ __launch_bounds__(256) void k_import_voxels(Table tab, Pool pool, con
       if (lane == 0) atomicAdd(missing, 1u);
       continue;
     }
-    const size_t dst = ((size_t)w.idx << 9) + lane * 8, src = ((size_t)b << 9) + lane * 8;
+    const size_t dst = ((size_t)w.idx << 9) + lane * 8, src = (size_t)b * stride + lane * 8;
     for (int i = 0; i < 8; ++i) {
       pool.tsdf[dst + i] = tsdf[src + i];
       pool.rgbw[dst + i] = rgbw[src + i];
       pool.segm[dst + i] = prob[src + i];
+    }
+  }
+}
+
+// ratsdf_export_blocks_device: the reverse -- record b of `out` ({tsdf | rgbw | prob}, 1536 words) takes the voxels of
+// the block at position b of the list; a block the directory does not hold leaves a record of zeros and is counted.
+__global__ __launch_bounds__(256) void k_export_blocks(Table tab, Pool pool, const int16_t* pos, int n, uint32_t* out,
+                                                       uint32_t* missing) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * block_threads() + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * block_threads()) >> 6;
+  for (uint32_t b = wave; b < (uint32_t)n; b += nwaves) {
+    EntryWords w;
+    const uint32_t e = find_block(tab, pos[3 * b], pos[3 * b + 1], pos[3 * b + 2], &w);
+    const bool have = !(e == kInf || w.idx < 0 || w.idx == kPlaceholderIdx);
+    if (!have && lane == 0) atomicAdd(missing, 1u);
+    const size_t src = ((size_t)(have ? w.idx : 0) << 9) + lane * 8, dst = (size_t)b * 1536u + lane * 8;
+    for (int i = 0; i < 8; ++i) {
+      out[dst + i] = have ? __float_as_uint(pool.tsdf[src + i]) : 0u;
+      out[dst + 512 + i] = have ? pool.rgbw[src + i] : 0u;
+      out[dst + 1024 + i] = have ? __float_as_uint(pool.segm[src + i]) : 0u;
     }
   }
 }

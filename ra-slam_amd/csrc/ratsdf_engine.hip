@@ -2162,34 +2162,21 @@ int ratsdf_test_allocate(ratsdf_engine* e, const int16_t* bp, int32_t n) {
   return st != RATSDF_OK ? st : st2;
 }
 
-int ratsdf_import_blocks(ratsdf_engine* e, int32_t n, const int16_t* bp, const float* tsdf, const ratsdf_rgbw* rgbw,
-                         const float* prob) {
-  DeviceGuard guard(e ? e->device : -1);
-  if (!guard.ok()) return RATSDF_ERR_DEVICE;
-  if (!e || n < 0 || (n > 0 && (!bp || !tsdf || !rgbw || !prob))) return RATSDF_ERR_BAD_ARGUMENT;
-  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
-  if (n == 0) return e->sticky();
+// The blocks at d_pos (device, n x 3 int16) into the directory -- whatever the engine's shard filter says -- and
+// their voxels from device arrays laid out as k_import_voxels describes.  Synchronises the engine's stream (the number
+// of blocks the directory still lacks after a pass is read back: control data, 4 bytes per pass).
+static int import_from_device(ratsdf_engine* e, int32_t n, const int16_t* d_pos, const float* d_tsdf,
+                              const uint32_t* d_rgbw, const float* d_prob, uint32_t stride) {
   e->ever_sem = true;  // (the blocks come with their probabilities: FrameParams::segm_live)
   int st = e->ensure_image(0, (size_t)n);
   if (st != RATSDF_OK) return st;
-  int16_t* d_pos = nullptr;
-  uint8_t* d_vox = nullptr;
   uint32_t* d_missing = nullptr;
-  const size_t per = (size_t)n * 512 * 4;
-  st = upload_s3(e, bp, n, &d_pos);
-  if (st != RATSDF_OK) return st;
+  if (hipMalloc(&d_missing, 4) != hipSuccess) return RATSDF_ERR_DEVICE;
   auto cleanup = [&](int status) {
     (void)hipStreamSynchronize(e->stream);
-    if (d_pos) (void)hipFree(d_pos);
-    if (d_vox) (void)hipFree(d_vox);
-    if (d_missing) (void)hipFree(d_missing);
+    (void)hipFree(d_missing);
     return status;
   };
-  if (hipMalloc(&d_vox, per * 3) != hipSuccess || hipMalloc(&d_missing, 4) != hipSuccess) return cleanup(RATSDF_ERR_DEVICE);
-  if (hipMemcpyAsync(d_vox, tsdf, per, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-      hipMemcpyAsync(d_vox + per, rgbw, per, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-      hipMemcpyAsync(d_vox + 2 * per, prob, per, hipMemcpyHostToDevice, e->stream) != hipSuccess)
-    return cleanup(RATSDF_ERR_DEVICE);
   FrameParams P = e->base_params();
   P.shard_count = 1;  // whatever the engine's shard filter says
   uint32_t missing = (uint32_t)n;
@@ -2206,8 +2193,8 @@ int ratsdf_import_blocks(ratsdf_engine* e, int32_t n, const int16_t* bp, const f
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1024), 0, e->stream, e->tab, e->pool, e->carve_bufs(par), e->ctl, par,
                        (ratsdf_frame_stats*)nullptr);
     if (hipMemsetAsync(d_missing, 0, 4, e->stream) != hipSuccess) return cleanup(RATSDF_ERR_DEVICE);
-    hipLaunchKernelGGL(k_import_voxels, dim3((n + 3) / 4), dim3(256), 0, e->stream, e->tab, e->pool, d_pos, n,
-                       (const float*)d_vox, (const uint32_t*)(d_vox + per), (const float*)(d_vox + 2 * per), d_missing);
+    hipLaunchKernelGGL(k_import_voxels, dim3((n + 3) / 4), dim3(256), 0, e->stream, e->tab, e->pool, d_pos, n, d_tsdf,
+                       d_rgbw, d_prob, stride, d_missing);
     if (hipMemcpyAsync(&missing, d_missing, 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
         hipStreamSynchronize(e->stream) != hipSuccess)
       return cleanup(RATSDF_ERR_DEVICE);
@@ -2215,6 +2202,58 @@ int ratsdf_import_blocks(ratsdf_engine* e, int32_t n, const int16_t* bp, const f
   st = e->sticky();
   if (st == RATSDF_OK && missing != 0) st = RATSDF_ERR_CAPACITY;
   return cleanup(st);
+}
+
+int ratsdf_import_blocks(ratsdf_engine* e, int32_t n, const int16_t* bp, const float* tsdf, const ratsdf_rgbw* rgbw,
+                         const float* prob) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e || n < 0 || (n > 0 && (!bp || !tsdf || !rgbw || !prob))) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
+  if (n == 0) return e->sticky();
+  int16_t* d_pos = nullptr;
+  uint8_t* d_vox = nullptr;
+  const size_t per = (size_t)n * 512 * 4;
+  int st = upload_s3(e, bp, n, &d_pos);
+  if (st != RATSDF_OK) return st;
+  auto cleanup = [&](int status) {
+    (void)hipStreamSynchronize(e->stream);
+    if (d_pos) (void)hipFree(d_pos);
+    if (d_vox) (void)hipFree(d_vox);
+    return status;
+  };
+  if (hipMalloc(&d_vox, per * 3) != hipSuccess) return cleanup(RATSDF_ERR_DEVICE);
+  if (hipMemcpyAsync(d_vox, tsdf, per, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+      hipMemcpyAsync(d_vox + per, rgbw, per, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+      hipMemcpyAsync(d_vox + 2 * per, prob, per, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+    return cleanup(RATSDF_ERR_DEVICE);
+  return cleanup(import_from_device(e, n, d_pos, (const float*)d_vox, (const uint32_t*)(d_vox + per),
+                                    (const float*)(d_vox + 2 * per), 512u));
+}
+
+int ratsdf_import_blocks_device(ratsdf_engine* e, int32_t n, const void* d_block_pos, const void* d_voxels) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e || n < 0 || (n > 0 && (!d_block_pos || !d_voxels))) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
+  if (n == 0) return e->sticky();
+  const uint32_t* rec = (const uint32_t*)d_voxels;
+  return import_from_device(e, n, (const int16_t*)d_block_pos, (const float*)rec, rec + 512, (const float*)(rec + 1024),
+                            1536u);
+}
+
+int ratsdf_export_blocks_device(ratsdf_engine* e, int32_t n, const void* d_block_pos, void* d_voxels,
+                                void* d_missing) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e || n < 0 || !d_missing || (n > 0 && (!d_block_pos || !d_voxels))) return RATSDF_ERR_BAD_ARGUMENT;
+  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
+  HIPCHK(hipMemsetAsync(d_missing, 0, 4, e->stream));
+  if (n == 0) return RATSDF_OK;
+  hipLaunchKernelGGL(k_export_blocks, dim3((n + 3) / 4), dim3(256), 0, e->stream, e->tab, e->pool,
+                     (const int16_t*)d_block_pos, n, (uint32_t*)d_voxels, (uint32_t*)d_missing);
+  HIPCHK(hipGetLastError());
+  return RATSDF_OK;
 }
 
 int ratsdf_test_delete(ratsdf_engine* e, const int16_t* bp, int32_t n) {

@@ -71,7 +71,8 @@ SYMBOLS = [
     "profile_enable", "profile_read", "profile_read_frames", "totals", "pipeline_counters",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "raycast", "raycast_rows", "raycast_device", "gather_valid_mesh", "download_all_mesh",
-    "export_directory_device", "export_directory_delta_device", "import_blocks", "group_create", "group_destroy", "group_size",
+    "export_directory_device", "export_directory_delta_device", "import_blocks", "export_blocks_device",
+    "import_blocks_device", "group_create", "group_destroy", "group_size",
     "group_integrate_device_batch", "group_synchronize", "group_profile_enable", "group_profile_read",
     "test_allocate", "test_delete",
     "test_retrieve", "test_assign_rgbw", "dump_directory", "dump_voxels", "dump_heap",
@@ -145,6 +146,8 @@ class Library:
         self.fn["export_directory_device"].argtypes = [vp, vp, C.c_int32, vp]
         self.fn["export_directory_delta_device"].argtypes = [vp, vp, C.c_int32, vp]
         self.fn["import_blocks"].argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+        self.fn["export_blocks_device"].argtypes = [vp, C.c_int32, vp, vp, vp]
+        self.fn["import_blocks_device"].argtypes = [vp, C.c_int32, vp, vp]
         self.fn["group_create"].argtypes = [vp, C.c_int, C.POINTER(vp)]
         self.fn["group_destroy"].argtypes = [vp]
         self.fn["group_size"].argtypes = [vp, C.POINTER(C.c_int32)]
@@ -471,6 +474,18 @@ class Engine:
         p = np.ascontiguousarray(prob, dtype=np.float32).reshape(n, BLOCK_VOLUME)
         _check(self.lib.fn["import_blocks"](self._h, n, a.ctypes.data, t.ctypes.data, c.ctypes.data, p.ctypes.data),
                "import_blocks")
+
+    def export_blocks_device(self, n, d_block_pos, d_voxels, d_missing):
+        """record i of d_voxels (1536 words: tsdf | rgbw | prob) = the voxels of the block at position i of d_block_pos
+        (n x 3 int16); all three are device pointers; *d_missing (int32) counts listed blocks the map does not hold.
+        Asynchronous on the engine's stream."""
+        _check(self.lib.fn["export_blocks_device"](self._h, int(n), d_block_pos or None, d_voxels or None, d_missing),
+               "export_blocks_device")
+
+    def import_blocks_device(self, n, d_block_pos, d_voxels):
+        """import_blocks() from device buffers in export_blocks_device()'s layout (read on the engine's stream)"""
+        _check(self.lib.fn["import_blocks_device"](self._h, int(n), d_block_pos or None, d_voxels or None),
+               "import_blocks_device")
 
     # -- test hooks ------------------------------------------------------------------------
     @staticmethod

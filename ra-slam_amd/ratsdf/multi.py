@@ -509,6 +509,102 @@ def _gather_arrays(arrays, world, device):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The same exchange with the voxel data staying in device memory (ratsdf_export_blocks_device /
+# ratsdf_import_blocks_device): under RCCL the all-gather's buffers are device tensors anyway, so the owner's engine
+# writes its seam / frustum blocks straight into the send buffer and the receiver's scratch engine reads the rows it
+# needs straight out of the receive buffer -- 6 KiB per block that never visit host memory (the host path above is
+# what the gloo tests and the CPU oracle use).  Records: 1536 int32 words per block, tsdf | rgbw | prob.
+# ---------------------------------------------------------------------------------------------------------------
+def device_exchange(engine, device):
+    """True when the across-shard exports can keep voxel data on the device: HIP engine + a cuda device for the
+    collectives' buffers"""
+    return device is not None and str(device).startswith("cuda") and engine.lib.backend().startswith("hip")
+
+
+def _pos_tensor(positions, device):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(np.array(positions, dtype=np.int16).reshape(-1, 3))).to(device)
+
+
+def export_blocks_device(engine, positions, rows, device):
+    """[rows, 1536] int32 tensor on `device`: record i = the voxels of block positions[i] of the engine's map (rows
+    beyond len(positions) are zero).  Every listed block must exist."""
+    import torch
+    n = len(positions)
+    out = torch.zeros((max(rows, n, 1), 1536), dtype=torch.int32, device=device)
+    if n:
+        pos = _pos_tensor(positions, device)
+        missing = torch.zeros(1, dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)           # (the buffers exist and are zeroed before the engine's stream writes)
+        engine.export_blocks_device(n, pos.data_ptr(), out.data_ptr(), missing.data_ptr())
+        engine.synchronize()
+        if int(missing.item()) != 0:
+            raise RuntimeError(f"export_blocks_device: {int(missing.item())} of {n} listed blocks are not in the map")
+    return out
+
+
+def import_blocks_device(scratch, positions, records, chunk=4096):
+    """`records` ([n, 1536] int32 device tensor, contiguous) into `scratch` as blocks `positions`"""
+    import torch
+    n = len(positions)
+    if n == 0:
+        return
+    assert records.is_contiguous() and records.shape[0] >= n and records.shape[1] == 1536
+    pos = _pos_tensor(positions, records.device)
+    torch.cuda.synchronize(records.device)       # (whatever produced the records has finished)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        scratch.import_blocks_device(m, pos.data_ptr() + lo * 6, records.data_ptr() + lo * 1536 * 4)
+
+
+def copy_blocks_device(src, dst, positions, device, chunk=4096):
+    """blocks `positions` of engine `src` into engine `dst` (same device), `chunk` blocks (24 MiB) at a time"""
+    for lo in range(0, len(positions), chunk):
+        part = positions[lo:lo + chunk]
+        import_blocks_device(dst, part, export_blocks_device(src, part, len(part), device))
+
+
+def _all_gather_rows(send, world):
+    """[world, rows, 1536]: every rank's send buffer (one all_gather_into_tensor on the buffers' device)"""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return send.unsqueeze(0)
+    recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(recv.reshape(-1), send.reshape(-1))
+    return recv
+
+
+def _import_plan_rows(scratch, recv, out_lists, plan, rank, skip_self=True):
+    """what the plan says rank `rank` needs from every other rank, out of the gathered buffers into `scratch`"""
+    import torch
+    for q in range(len(out_lists)):
+        if (skip_self and q == rank) or not plan[q][rank]:
+            continue
+        row_of = {pp: i for i, pp in enumerate(out_lists[q])}
+        rows = torch.tensor([row_of[pp] for pp in plan[q][rank]], dtype=torch.int64, device=recv.device)
+        import_blocks_device(scratch, plan[q][rank], recv[q].index_select(0, rows).contiguous())
+
+
+def mesh_rank_device(engine, scratch, recv, out_lists, plan, rank, device):
+    """One rank's share of mesh_across_shards with the voxel data on the device: own blocks engine -> scratch, halo rows
+    recv -> scratch, mesh.  `recv` = _all_gather_rows of every rank's export_blocks_device(out_lists[q])."""
+    _, blocks = engine.dump_directory()
+    own = list(zip(blocks["x"].tolist(), blocks["y"].tolist(), blocks["z"].tolist()))
+    copy_blocks_device(engine, scratch, own, device)
+    _import_plan_rows(scratch, recv, out_lists, plan, rank)
+    return scratch.gather_valid_mesh()
+
+
+def raycast_rank_device(engine, scratch, recv, out_lists, plan, rank, device, intrinsics, height, width, pose,
+                        max_depth, rows):
+    """One rank's strip of raycast_across_shards with the voxel data on the device"""
+    copy_blocks_device(engine, scratch, plan[rank][rank], device)
+    _import_plan_rows(scratch, recv, out_lists, plan, rank)
+    return scratch.raycast_rows(intrinsics, height, width, pose, max_depth, rows[0], rows[1])
+
+
 def mesh_with_halo(engine, scratch, halo):
     """The mesh of the blocks `engine` owns, with the cells on its subvolume's +x seam closed: `scratch` (a fresh
     engine with the same voxel size and shard parameters) receives the engine's own blocks and the neighbours'
@@ -541,6 +637,14 @@ def mesh_across_shards(engine, make_scratch, per_rank, device=None):
     # what I send to anybody, once; everybody knows everybody's list, so the buffers have agreed sizes
     out_lists = [sorted(set(p for r in range(world) for p in plan[q][r])) for q in range(world)]
     nmax = max(1, max(len(l) for l in out_lists))
+    if device_exchange(engine, device):  # voxel data stays in device memory
+        recv = _all_gather_rows(export_blocks_device(engine, out_lists[rank], nmax, device), world)
+        scratch = make_scratch()
+        try:
+            v, tri, vp = mesh_rank_device(engine, scratch, recv, out_lists, plan, rank, device)
+        finally:
+            scratch.close()
+        return _merge_meshes(v, tri, vp, world, device)
     recv = _gather_block_data(export_blocks(engine, out_lists[rank]), nmax, world, device)
     hp, ht, hc, hprob = [], [], [], []
     for q in range(world):
@@ -563,6 +667,11 @@ def mesh_across_shards(engine, make_scratch, per_rank, device=None):
         v, tri, vp = mesh_with_halo(engine, scratch, halo)
     finally:
         scratch.close()
+    return _merge_meshes(v, tri, vp, world, device)
+
+
+def _merge_meshes(v, tri, vp, world, device):
+    """every rank's mesh on every rank, vertex indices shifted (one all-gather of the three arrays)"""
     if world == 1:
         return v, tri, vp
     parts = _gather_arrays([np.asarray(v, dtype=np.float32).reshape(-1), np.asarray(tri, dtype=np.int32).reshape(-1),
@@ -678,6 +787,19 @@ def raycast_across_shards(engine, make_scratch, per_rank, intrinsics, height, wi
     # what I send to the others, once; everybody knows everybody's list, so the buffers have agreed sizes
     out_lists = [sorted(set(p for r in range(world) if r != q for p in plan[q][r])) for q in range(world)]
     nmax = max(1, max(len(l) for l in out_lists))
+    if device_exchange(engine, device):  # voxel data stays in device memory
+        recv = _all_gather_rows(export_blocks_device(engine, out_lists[rank], nmax, device), world)
+        scratch = make_scratch()
+        try:
+            mine = raycast_rank_device(engine, scratch, recv, out_lists, plan, rank, device, intrinsics, height, width,
+                                       pose, max_depth, strips[rank])
+        finally:
+            scratch.close()
+        if world == 1:
+            return mine
+        got = _gather_arrays([mine[0].reshape(-1), mine[1].reshape(-1)], world, device)
+        return (np.concatenate([g[0].reshape(-1, width, 4) for g in got], axis=0),
+                np.concatenate([g[1].reshape(-1, width, 4) for g in got], axis=0))
     recv = _gather_block_data(export_blocks(engine, out_lists[rank]), nmax, world, device)
     parts = [export_blocks(engine, plan[rank][rank])]
     for q in range(world):

@@ -193,3 +193,96 @@ def test_raycast_across_shards_on_the_hip_engine(make_engine, make_oracle):
     assert np.array_equal(np.concatenate(rgba), ref_rgba) and np.array_equal(np.concatenate(normal), ref_normal)
     own, _ = sh[0].raycast(K, H, W, T, 4.0)
     assert not np.array_equal(own, ref_rgba)                       # own blocks alone render something else
+
+
+@pytest.mark.gpu
+def test_block_exchange_in_device_memory(make_engine):
+    """ratsdf_export_blocks_device / ratsdf_import_blocks_device: the records an engine writes into a device buffer are
+    the voxels dump_voxels() reports (tsdf | rgbw | prob per block), a listed block the map lacks is counted and left
+    zero, and a scratch engine that imports the records holds the same blocks -- no host copy of voxel data."""
+    import torch
+    from ratsdf import multi
+    vs = 0.02
+    src = make_engine(vs, 6 * vs)
+    for f in synthetic.stream("room", 3, scale=0.25):
+        src.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+    _, b = src.dump_directory()
+    pos = list(zip(b["x"].tolist(), b["y"].tolist(), b["z"].tolist()))
+    host = multi.export_blocks(src, pos)
+    rec = multi.export_blocks_device(src, pos, len(pos) + 3, "cuda")
+    got = rec.cpu().numpy()
+    assert np.array_equal(got[:len(pos), 0:512], host[1].view(np.int32))
+    assert np.array_equal(got[:len(pos), 512:1024], np.ascontiguousarray(host[2]).view(np.int32).reshape(-1, 512))
+    assert np.array_equal(got[:len(pos), 1024:1536], host[3].view(np.int32))
+    assert not got[len(pos):].any()
+    # a position the map does not hold: counted, record of zeros
+    absent = [(30000, 30000, 30000)]
+    with pytest.raises(RuntimeError, match="1 of 2 listed blocks"):
+        multi.export_blocks_device(src, [pos[0]] + absent, 2, "cuda")
+    p_t = multi._pos_tensor([pos[0]] + absent, "cuda")
+    out = torch.full((2, 1536), 7, dtype=torch.int32, device="cuda")
+    missing = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    src.export_blocks_device(2, p_t.data_ptr(), out.data_ptr(), missing.data_ptr())
+    src.synchronize()
+    assert int(missing.item()) == 1 and not out[1].any().item() and np.array_equal(out[0].cpu().numpy(), got[0])
+    # into a scratch engine whose shard filter would refuse half of them; twice (present already: overwritten)
+    dst = make_engine(vs, 6 * vs, shard_rank=1, shard_count=4, shard_slab_bits=1)
+    multi.import_blocks_device(dst, pos, rec[:len(pos)].contiguous(), chunk=100)
+    multi.copy_blocks_device(src, dst, pos[:5], "cuda")
+    assert dst.num_active_blocks() == len(pos)
+    back = multi.export_blocks(dst, pos)
+    assert np.array_equal(back[1], host[1]) and np.array_equal(back[2], host[2]) and np.array_equal(back[3], host[3])
+    assert src.num_active_blocks() == len(pos)
+
+
+@pytest.mark.gpu
+def test_across_shard_exports_with_voxel_data_on_the_device(make_engine):
+    """The device form of multi.mesh_across_shards / raycast_across_shards (what they do under RCCL: device_exchange)
+    on two HIP shard engines in one process -- the all-gather is stood in for by stacking the two send buffers: same
+    triangles and same image as the host-memory form."""
+    import torch
+    from ratsdf import multi
+    vs = 0.02
+    kw = [dict(shard_rank=r, shard_count=2, shard_slab_bits=1) for r in range(2)]
+    sh = [make_engine(vs, 6 * vs, **k) for k in kw]
+    frames = [synthetic.frame("room", 0, scale=0.25) for _ in range(12)] + synthetic.stream("room", 4, scale=0.25)
+    for f in frames:
+        for e in sh:
+            e.integrate(f["rgb"], f["depth"], f["ht"], f["lt"], 4.0, f["intrinsics"], f["pose"])
+    dirs = [e.dump_directory()[1] for e in sh]
+    assert multi.device_exchange(sh[0], "cuda") and not multi.device_exchange(sh[0], None)
+    # -- mesh
+    plan = multi.halo_plan(dirs)
+    out_lists = [sorted(set(p for r in range(2) for p in plan[q][r])) for q in range(2)]
+    nmax = max(1, max(len(l) for l in out_lists))
+    assert all(len(l) > 0 for l in out_lists)
+    recv = torch.stack([multi.export_blocks_device(sh[q], out_lists[q], nmax, "cuda") for q in range(2)])
+    for r in range(2):
+        dev = _tri_rows(*multi.mesh_rank_device(sh[r], make_engine(vs, 6 * vs, **kw[r]), recv, out_lists, plan, r, "cuda"))
+        host = _tri_rows(*multi.mesh_with_halo(sh[r], make_engine(vs, 6 * vs, **kw[r]),
+                                               multi.export_blocks(sh[1 - r], plan[1 - r][r])))
+        assert dev.shape == host.shape and len(dev) > 0 and np.array_equal(dev, host)
+        assert sh[r].num_active_blocks() == len(dirs[r])
+    # -- ray cast
+    view = frames[-1]
+    H, W = view["depth"].shape
+    K, T = view["intrinsics"], view["pose"]
+    plan = multi.raycast_plan(dirs, K, H, W, T, 4.0, vs)
+    strips = multi.strip_rows(H, 2)
+    out_lists = [sorted(set(p for r in range(2) if r != q for p in plan[q][r])) for q in range(2)]
+    nmax = max(1, max(len(l) for l in out_lists))
+    recv = torch.stack([multi.export_blocks_device(sh[q], out_lists[q], nmax, "cuda") for q in range(2)])
+    for r in range(2):
+        dev = multi.raycast_rank_device(sh[r], make_engine(vs, 6 * vs), recv, out_lists, plan, r, "cuda", K, H, W, T, 4.0,
+                                        strips[r])
+        host = multi.raycast_strip(make_engine(vs, 6 * vs), [multi.export_blocks(sh[q], plan[q][r]) for q in range(2)],
+                                   K, H, W, T, 4.0, strips[r])
+        assert np.array_equal(dev[0], host[0]) and np.array_equal(dev[1], host[1]) and (dev[0][..., 3] == 255).any()
+    # -- the entry points themselves, one rank (no process group: world 1)
+    v, tri, vp = multi.mesh_across_shards(sh[0], lambda: make_engine(vs, 6 * vs, **kw[0]), [dirs[0]], device="cuda")
+    v2, tri2, vp2 = multi.mesh_across_shards(sh[0], lambda: make_engine(vs, 6 * vs, **kw[0]), [dirs[0]])
+    assert np.array_equal(_tri_rows(v, tri, vp), _tri_rows(v2, tri2, vp2))
+    a = multi.raycast_across_shards(sh[0], lambda: make_engine(vs, 6 * vs), [dirs[0]], K, H, W, T, 4.0, vs, device="cuda")
+    b = multi.raycast_across_shards(sh[0], lambda: make_engine(vs, 6 * vs), [dirs[0]], K, H, W, T, 4.0, vs)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
