@@ -658,8 +658,13 @@ def main():
     # one-GPU box (all ranks on device 0, gloo instead of RCCL); the driver never sets them.
     dev_index = int(os.environ.get("RATSDF_BENCH_DEVICE", local_rank))
     backend = os.environ.get("RATSDF_BENCH_BACKEND", "nccl")
+    # RATSDF_BENCH_ONE_RANK_GROUP=1 (rehearsal only, like the two above): take the N > 1 code path with a process group
+    # of ONE rank -- RCCL refuses two ranks on one device, so this is how the very calls an 8-GPU run makes
+    # (init_process_group("nccl"), the directory all-gather on device tensors, barrier, all_reduce, the frame broadcast
+    # of --shard) are exercised over RCCL on a one-GPU box (tests/test_bench_launch.py)
+    grouped = world > 1 or os.environ.get("RATSDF_BENCH_ONE_RANK_GROUP") == "1"
     dist = None
-    if world == 1 and not a.with_torch:
+    if not grouped and not a.with_torch:
         # N = 1 needs device memory and nothing else of PyTorch: hipMalloc / hipMemcpy through the runtime libratsdf.so
         # links (ratsdf.devmem).  A process has ONE HIP runtime: with torch imported (first, or it finds no GPU) that is
         # the one bundled with the PyTorch wheel; without, the system ROCm runtime a C / C++ caller of the library links.
@@ -674,15 +679,22 @@ def main():
                 raise SystemExit("bench.py needs an MI355X: the TSDF engine has no CPU path")
         else:   # (no HIP runtime library to bind by name: PyTorch's allocator then -- decided before anything is loaded)
             a.with_torch = True
-    if world > 1 or a.with_torch:
+    if grouped or a.with_torch:
         import torch
         import torch.distributed as dist
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the TSDF engine has no CPU path")
         torch.cuda.set_device(dev_index)
         dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # (the one-rank rehearsal, started without a launcher)
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -716,7 +728,7 @@ def main():
             a.cpu_frames = 8             # parity on the first frames only (the CPU runs ~30 frames/s)
         a.host_frames = 0
         a.streams = 0
-    if a.shard and world > 1:   # BASELINE configs[3]: one stream, N subvolumes, frames broadcast from rank 0
+    if a.shard and grouped:   # BASELINE configs[3]: one stream, N subvolumes, frames broadcast from rank 0
         out = bench_sharded_stream(a, rank, world, dev, dev_index, backend, torch, dist, ratsdf)
         if rank == 0:
             print(json.dumps(out))
@@ -737,13 +749,13 @@ def main():
     pose = [ratsdf.Pose(*f["pose"]) for f in frames]
     torch.cuda.synchronize()
 
-    shard_kw = dict(shard_rank=rank, shard_count=world, shard_slab_bits=2) if (a.shard and world > 1) else {}
+    shard_kw = dict(shard_rank=rank, shard_count=world, shard_slab_bits=2) if (a.shard and grouped) else {}
     eng = ratsdf.TSDFGrid(vs, 6 * vs, device=dev_index, **shard_kw)
 
     # ---- parity + CPU baseline on a bounded prefix (rank 0, N = 1) ---------------------------
     cpu_baseline = None
     parity = None
-    if rank == 0 and world == 1 and a.cpu_frames > 0:
+    if rank == 0 and not grouped and a.cpu_frames > 0:
         from oracle_binding import load_oracle
         from parity import assert_maps_equal
         from ratsdf._abi import Engine
@@ -783,7 +795,7 @@ def main():
 
     # ---- directory all-gather (N > 1): one exchange per step (ratsdf/multi.py) -------------------
     ex = None
-    if world > 1:
+    if grouped:
         from ratsdf import multi
         if backend == "nccl":
             # deltas of the block directories: what a rank added / deleted since the previous
@@ -818,13 +830,13 @@ def main():
                     eng.synchronize()
         else:
             eng.integrate_device_batch(batch)  # one C call enqueues the step's frames in order
-        if world > 1:
+        if grouped:
             exchange()
 
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -844,7 +856,7 @@ def main():
             step()
         fence()
         d = time.perf_counter() - t0
-        if world > 1:
+        if grouped:
             t = torch.tensor([d], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             d = float(t.item())
@@ -888,7 +900,7 @@ def main():
     # system ROCm runtime a C / C++ caller links, whatever this process runs on.)
     host_path = None
     pinned_path = None
-    if rank == 0 and world == 1 and a.host_frames > 0:
+    if rank == 0 and not grouped and a.host_frames > 0:
         import subprocess
         r = subprocess.run([sys.executable, str(ROOT / "tools" / "host_paths.py"), "--cam", a.cam, "--scene", a.scene,
                             "--voxel", str(vs), "--max-depth", str(a.max_depth), "--frames", str(len(frames)),
@@ -902,7 +914,7 @@ def main():
 
     # ---- S streams on this GPU through one launch triple per frame step ------------------------
     multi = None
-    if rank == 0 and world == 1 and a.streams > 1 and not a.shard:
+    if rank == 0 and not grouped and a.streams > 1 and not a.shard:
         multi = bench_streams(ratsdf, torch, dev, dev_index, a.streams, a.scene, a.cam, vs, a.max_depth,
                               min(60, len(frames)), max(a.steps // 2, 4), 3,
                               cpu_threads=min(len(os.sched_getaffinity(0)), 16))
@@ -912,7 +924,7 @@ def main():
     flythrough = None
     system_path = None
     tsdf_only = None
-    if rank == 0 and world == 1 and a.config == "vga5mm" and not a.no_secondary and a.cpu_frames > 0:
+    if rank == 0 and not grouped and a.config == "vga5mm" and not a.no_secondary and a.cpu_frames > 0:
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         nthr = min(avail, int(os.environ.get("RATSDF_CPU_THREADS", "16")))
         secondary = [bench_secondary(ratsdf, torch, dev, dev_index, a.max_depth, nthr, "hd2mm"),
@@ -942,12 +954,12 @@ def main():
             "value_min_max": [round((1 if a.shard else world) * nframes / max(rep_dt), 1),
                               round((1 if a.shard else world) * nframes / min(rep_dt), 1)],
             "higher_is_better": True,
-            "scaling": "strong" if (a.shard and world > 1) else "weak",
+            "scaling": "strong" if (a.shard and grouped) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "hip_runtime": ("the system ROCm runtime libratsdf.so links (no PyTorch in this process: device memory "
-                            "through ratsdf.devmem)" if (world == 1 and not a.with_torch) else
+                            "through ratsdf.devmem)" if (not grouped and not a.with_torch) else
                             "the HIP runtime bundled with the PyTorch wheel (torch.distributed / RCCL need torch in the process)"),
             "config": {
                 "workload": f"synthetic '{a.scene}' RGB-D+ht/lt stream, {a.cam} intrinsics {W}x{H}, "
@@ -955,11 +967,11 @@ def main():
                             f"{a.max_depth:g} m, 1 deg/frame ping-pong sweep, 1 mm depth noise, 1% holes",
                 "frames_per_step": len(frames),
                 "streams": 1 if a.shard else world,
-                "sharding": ("block ownership: floormod(block.x >> 2, N)" if (a.shard and world > 1) else None),
-                "directory_allgather_every_frames": len(frames) if world > 1 else None,
+                "sharding": ("block ownership: floormod(block.x >> 2, N)" if (a.shard and grouped) else None),
+                "directory_allgather_every_frames": len(frames) if grouped else None,
             },
-            "directory_blocks_all_ranks": (int(sum(len(x) for x in ex.result())) if world > 1 else None),
-            "directory_delta_entries_last_step_rank0": (list(ex.last_sent) if world > 1 else None),
+            "directory_blocks_all_ranks": (int(sum(len(x) for x in ex.result())) if grouped else None),
+            "directory_delta_entries_last_step_rank0": (list(ex.last_sent) if grouped else None),
             "frame": {"avg_visible_blocks": round(V, 1), "avg_updated_voxels": round(U, 1),
                       "alg_bytes": round(b_alg), "alg_gbps_whole_frame": round(b_alg * fps / world / 1e9, 1),
                       "active_blocks": stats["active_blocks"],
@@ -984,7 +996,7 @@ def main():
         }
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -74,3 +74,28 @@ def test_one_stream_over_two_subvolume_ranks_through_the_plain_entry_point():
     assert len(d["shards"]) == 2 and all(s["active_blocks"] > 0 for s in d["shards"])
     assert sum(s["active_blocks"] for s in d["shards"]) == d["directory_union_blocks"]
     assert d["parity"]["frames"] == 4 and d["parity"]["max_abs_tsdf"] == 0.0 and d["parity"]["max_abs_prob"] < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["streams", "shard"])
+def test_the_multi_rank_code_path_over_rccl_with_a_group_of_one(mode):
+    """The calls an 8-GPU run makes, over RCCL itself: RCCL refuses two ranks on one device, so the one-GPU box takes
+    bench.py's N > 1 path with a process group of ONE rank (RATSDF_BENCH_ONE_RANK_GROUP=1): init_process_group("nccl",
+    device_id=...), the directory exchange on device tensors (all_gather_into_tensor), barrier, all_reduce(MAX) of the
+    step time -- and, with --shard, the frame broadcast on its side stream and all_gather_object of the shard table."""
+    args = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--reps", "1", "--frames-per-step", "12", "--cpu-frames", "4"]
+    args += ["--shard", "--bcast-chunk", "4"] if mode == "shard" else ["--host-frames", "0", "--no-secondary", "--streams", "0"]
+    r = _run(args, {"RATSDF_BENCH_ONE_RANK_GROUP": "1"}, 600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["directory_blocks_all_ranks"] > 0          # the RCCL all-gather of the directory ran
+    if mode == "shard":
+        assert d["scaling"] == "strong" and d["frame_broadcast"]["backend"] == "nccl"
+        assert d["frame_broadcast"]["in_timed_region"] and d["frame_broadcast"]["broadcast_gbps"] > 0
+        assert d["directory_union_blocks"] == d["directory_blocks_all_ranks"] and len(d["shards"]) == 1
+        assert d["parity"]["frames"] == 4 and d["parity"]["max_abs_tsdf"] == 0.0
+    else:
+        assert d["config"]["streams"] == 1 and d["config"]["directory_allgather_every_frames"] == 12
