@@ -188,7 +188,8 @@ int ratsdf_integrate_batch(ratsdf_engine* e, int n, const uint8_t* const* rgb,
 int ratsdf_host_alloc(size_t bytes, void** out);
 int ratsdf_host_free(void* p);
 /* cudaStreamSynchronize(stream_), voxel_tsdf.cu:450; also surfaces sticky device-side errors
- * (pool exhausted, work-list overflow). */
+ * (pool exhausted, work-list overflow).  A stream synchronisation and a read of a page-locked flag the kernels raise
+ * on error: no device-to-host copy, no launch. */
 int ratsdf_synchronize(ratsdf_engine* e);
 /* Native handle of the engine's stream (hipStream_t) so callers can order their own work / events. */
 int ratsdf_stream(ratsdf_engine* e, void** out_stream);

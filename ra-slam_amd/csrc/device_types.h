@@ -134,7 +134,8 @@ struct Ctl {
   unsigned long long totals[5];  // frames, sum V, sum U, sum allocated, sum deleted
   // frames by where their serial role ran: tail of k_front | in k_integrate: ordinary, resolver, general path
   unsigned long long paths[4];
-  uint32_t pad1[4];
+  uint32_t* err_flag;     // page-locked host word: non-zero once any error has been recorded (kernels_alloc.h: set_error)
+  uint32_t pad1[2];
   unsigned long long stamps[32];  // diagnostic build only
   unsigned long long tstamps[16];  // diagnostic build only: wall-clock timeline of k_front's tail (kernels_frame.h)
   unsigned long long* debug_buf;  // diagnostic build only: per-wave stamps of k_integrate

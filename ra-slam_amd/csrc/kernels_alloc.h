@@ -30,10 +30,14 @@ namespace ratsdf {
 
 // (the operands are pinned to the call site: hoisted out of a hot loop as loop invariants they were
 // the first thing the register allocator spilled to scratch memory, for a path that is never taken)
+// The first error sticks in Ctl::error (device memory).  Every error is ALSO flagged in a word of page-locked host
+// memory (Ctl::err_flag, system-scope store): a synchronising call reads that word after the stream has drained and
+// fetches the device word only when it is set -- the ordinary call pays for no device-to-host copy (engine: sticky()).
 __device__ inline void set_error(Ctl* ctl, uint32_t code) {
   uint32_t expect = 0u, value = code;
   asm volatile("" : "+v"(expect), "+v"(value));
   atomicCAS(&ctl->error, expect, value);
+  __hip_atomic_store(ctl->err_flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // one thread: the words of a FrameCtl that are in use
 __device__ inline void zero_frame_ctl(FrameCtl* F, bool tail_on) {

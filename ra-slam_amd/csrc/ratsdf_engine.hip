@@ -185,6 +185,7 @@ struct ratsdf_engine {
   Pool pool{};
   Ctl* ctl = nullptr;
   ratsdf_frame_stats* d_stats = nullptr;
+  uint32_t* h_err = nullptr;  // page-locked landing place of the sticky error word (sticky())
   EngineDev* d_eng = nullptr;  // device copy of the engine record (device_types.h)
 
   // image-sized scratch
@@ -394,6 +395,8 @@ int ratsdf_engine::free_all() {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h_stage) (void)hipHostFree(h_stage);
+  if (h_err) (void)hipHostFree(h_err);
+  h_err = nullptr;
   if (dl_dev) (void)hipFree(dl_dev);
   if (dl_host) (void)hipHostFree(dl_host);
   for (auto& ev : stage_ev)
@@ -830,11 +833,18 @@ int ratsdf_engine::drain_profile(bool final) {
   return RATSDF_OK;
 }
 
+// The sticky error word, after everything enqueued so far.  No device-to-host copy in the ordinary call: set_error
+// (kernels_alloc.h) also raises a flag in page-locked host memory (h_err[0], through Ctl::err_flag), which is read
+// once the stream has drained; only when it is set is the device word -- the FIRST error -- fetched (into h_err[1]:
+// page-locked as well; a copy into pageable memory goes through the runtime's staging path).  A synchronising call on
+// an idle engine went from 20 - 25 us to a stream synchronisation; the per-frame convention of TSDFGrid::Integrate
+// (ratsdf_integrate_device + ratsdf_synchronize) from 59 - 61 us per frame to the figure in profiles/r05_sync_path.txt.
 int ratsdf_engine::sticky() {
-  uint32_t err = 0;
-  HIPCHK(hipMemcpyAsync(&err, &ctl->error, sizeof(err), hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
-  return (int)err;
+  if (*(volatile uint32_t*)h_err == 0u) return RATSDF_OK;
+  HIPCHK(hipMemcpyAsync(h_err + 1, &ctl->error, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  return (int)((volatile uint32_t*)h_err)[1];
 }
 
 // Non-finite camera parameters are refused at the boundary (RATSDF_ERR_BAD_ARGUMENT).  The reference
@@ -1073,6 +1083,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->pool.heap, (size_t)t.num_block * 4));
   CREATE_CHK(hipMalloc(&e->ctl, sizeof(Ctl)));
   CREATE_CHK(hipMalloc(&e->d_stats, sizeof(ratsdf_frame_stats)));
+  CREATE_CHK(hipHostMalloc(&e->h_err, 64, hipHostMallocDefault));
   CREATE_CHK(hipMalloc(&e->d_eng, sizeof(EngineDev)));
   CREATE_CHK(hipMalloc(&e->slow, (size_t)kSlowCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->xlocks, (size_t)kXLockCap * sizeof(XLock)));
@@ -1118,6 +1129,12 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   const int32_t nf = t.num_block;
   CREATE_CHK(hipMemcpyAsync(&e->ctl->num_free, &nf, 4, hipMemcpyHostToDevice, e->stream));
   CREATE_CHK(hipMemcpyAsync(&e->ctl->free_low, &nf, 4, hipMemcpyHostToDevice, e->stream));
+  {  // the error flag's home in page-locked host memory, as the device addresses it (sticky())
+    e->h_err[0] = e->h_err[1] = 0u;
+    void* flag_dev = nullptr;
+    CREATE_CHK(hipHostGetDevicePointer(&flag_dev, e->h_err, 0));
+    CREATE_CHK(hipMemcpyAsync(&e->ctl->err_flag, &flag_dev, sizeof(flag_dev), hipMemcpyHostToDevice, e->stream));
+  }
   CREATE_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_alloc_rank),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
   hipLaunchKernelGGL(k_check_block_threads, dim3(3), dim3(192), 0, e->stream, &e->ctl->n_sel);
@@ -1509,7 +1526,10 @@ int ratsdf_synchronize(ratsdf_engine* e) {
   DeviceGuard guard(e ? e->device : -1);
   if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
-  { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
+  // (no k_settle here: what the last frame's carve pass still owes -- pool releases, its statistics -- is done by the
+  // next frame's launches, or by the entry point that reads the map, the free list or the statistics: each of them
+  // settles first.  A caller that synchronises after every frame, TSDFGrid::Integrate's convention, paid a fourth
+  // launch per frame for it.)
   return e->sticky();
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long parity soak (GPU box): batched frames through the pipelined engine vs the frame-at-a-time CPU
 oracle, with a small directory so that chained buckets, slow deletes and pool reuse all occur.
-tools/soak.py [frames] [bucket_bits]"""
+tools/soak.py [frames] [bucket_bits] [voxel_size]   (bucket_bits 9 + voxel 0.01: ~1 600 blocks in 512 buckets, chains everywhere)"""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -16,7 +16,7 @@ from parity import assert_maps_equal
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 bb = int(sys.argv[2]) if len(sys.argv) > 2 else 13
 kw = dict(bucket_bits=bb, block_bits=14)
-vs, md = 0.02, 4.0
+vs, md = (float(sys.argv[3]) if len(sys.argv) > 3 else 0.02), 4.0
 gpu = ratsdf.TSDFGrid(vs, 6 * vs, **kw)
 cpu = Engine(load_oracle(), vs, 6 * vs, threads=8, **kw)
 dev = torch.device("cuda", 0)
