@@ -6,6 +6,26 @@
 // directory probes and voxel reads share cache lines; every lane keeps the reference's one-entry
 // block cache (the last directory lookup) so consecutive samples inside a block cost no probe.
 // Output goes to plain device buffers (uchar4 per pixel) instead of CUDA-GL interop textures.
+//
+// The march is a chain of dependent memory round trips: a sample's tsdf decides the step to the next sample, whose
+// address (directory probe, then the voxel) is only known then.  What round 5 measured (profiles/r05_raycast.txt;
+// per-wave records of the diagnostic build, tools/raycast_probe.py): a 640x480 rendering is 130 us of vector issue
+// but took 450 - 520 us; half of the waves are through after 90 us; the kernel lasts as long as its slowest waves,
+// and those hold a ray that runs its FULL length (534 samples: it leaves through a gap, or grazes a surface), every
+// sample of it a directory probe that finds nothing -- 64 % of such a lane's cycles were probes, one after the other
+// (find_block branches on what it loaded, so four probes in a row are four round trips of ~0.7 us), 32 % the judging
+// code, 5 % the voxel loads.  Hence:
+//   * block-level occupancy in LDS: k_occupancy_build hashes every live block into a 32 KiB bitmap before the
+//     rendering (a scan of Table::active), every workgroup copies it into LDS; a clear bit proves the block absent, so
+//     empty space costs an LDS read per block instead of a directory probe (set bits may be collisions: probed);
+//   * the march SPECULATES: the step almost always stays what it was, so the positions of the next kAhead samples are
+//     computed assuming that, their lookups and voxel loads are issued together, and the samples are then judged one
+//     by one exactly as the plain loop would; the first sample that changes the step ends the group, what was fetched
+//     beyond it is dropped.  Positions come from the same additions in the same order: every sample that counts is
+//     bit for bit the plain march's;
+//   * the zero crossing's interpolation, colour and normal (:318-357, two thirds of the loop's code) run once, after
+//     the loop, not as a branch of every unrolled sample.
+// (Tried first and dropped: an exact skip over provably empty 8^3-block cells -- half the iterations, the same tail.)
 #pragma once
 #include "kernels_integrate.h"
 
@@ -17,16 +37,40 @@ struct BlockCache {  // VoxelBlock cache of RetrieveMutable, voxel_hash.cuh:124-
   bool valid;
 };
 
-// pool voxel index of integer voxel (px,py,pz) or -1 (block absent)
-__device__ inline long voxel_index(const Table& tab, int px, int py, int pz, BlockCache& c) {
+// hashed occupancy of the map's blocks, built before a rendering and held in LDS (see the header)
+// (TWO bits per block, a Bloom filter: a wave looks up ~130 blocks per group of samples, so with one bit per block and
+// 2 % of the bits set some lane of nearly every group ran into a collision and sent the whole wave to the directory)
+constexpr uint32_t kOccWords = 8192;               // 32 KiB = 262 144 bits
+// (any spreading of neighbouring blocks will do: 24-bit multiply-adds of the coordinates' low 16 bits -- the directory
+// hash's three full 32-bit multiplications issue at a quarter of the rate, and a lookup is on the march's critical path)
+__device__ inline uint32_t occ_bit(int bx, int by, int bz) {
+  const uint32_t x = (uint32_t)bx & 0xFFFFu, y = (uint32_t)by & 0xFFFFu, z = (uint32_t)bz & 0xFFFFu;
+  return (__umul24(x, 0x9E5u) + __umul24(y, 0x1F35Bu) + __umul24(z, 0x6A7C1u)) & (kOccWords * 32u - 1u);
+}
+__device__ inline uint32_t occ_bit2(int bx, int by, int bz) {
+  const uint32_t x = (uint32_t)bx & 0xFFFFu, y = (uint32_t)by & 0xFFFFu, z = (uint32_t)bz & 0xFFFFu;
+  return ((__umul24(x, 0x2C1B3u) + __umul24(y, 0x5D3u) + __umul24(z, 0x1B873u)) >> 3) & (kOccWords * 32u - 1u);
+}
+__device__ inline bool occ_maybe(const uint32_t* occ, int bx, int by, int bz) {
+  const uint32_t h = occ_bit(bx, by, bz), g = occ_bit2(bx, by, bz);
+  return (((occ[h >> 5] >> (h & 31u)) & (occ[g >> 5] >> (g & 31u))) & 1u) != 0u;
+}
+
+// pool voxel index of integer voxel (px,py,pz) or -1 (block absent).  `occ`: the occupancy bits (LDS) -- a clear bit
+// proves the block absent and saves the directory probe.
+__device__ inline long voxel_index(const Table& tab, int px, int py, int pz, BlockCache& c, const uint32_t* occ) {
   const int bx = px >> 3, by = py >> 3, bz = pz >> 3;
   if (!(c.valid && c.bx == bx && c.by == by && c.bz == bz)) {
-    EntryWords w;
-    const uint32_t e = find_block(tab, bx, by, bz, &w);
+    int32_t idx = -1;
+    if (occ_maybe(occ, bx, by, bz)) {
+      EntryWords w;
+      const uint32_t e = find_block(tab, bx, by, bz, &w);
+      idx = e == kInf ? -1 : w.idx;
+    }
     c.bx = bx;
     c.by = by;
     c.bz = bz;
-    c.idx = e == kInf ? -1 : w.idx;
+    c.idx = idx;
     c.valid = true;
   }
   if (c.idx < 0) return -1;
@@ -34,14 +78,14 @@ __device__ inline long voxel_index(const Table& tab, int px, int py, int pz, Blo
 }
 
 __device__ inline float tsdf_at(const Table& tab, const Pool& pool, int px, int py, int pz,
-                                BlockCache& c) {
-  const long vi = voxel_index(tab, px, py, pz, c);
+                                BlockCache& c, const uint32_t* occ) {
+  const long vi = voxel_index(tab, px, py, pz, c, occ);
   return vi >= 0 ? pool.tsdf[vi] : -10.f;  // VoxelTSDF(): -10, voxel_types.cu:8
 }
 
 // VoxelHashTable::RetrieveTSDF, voxel_hash.cu:161-188 (corner / weight pairing as written there)
 __device__ inline float retrieve_tsdf(const Table& tab, const Pool& pool, const V3& pt,
-                                      BlockCache& c) {
+                                      BlockCache& c, const uint32_t* occ) {
   const V3 pl{floorf(pt.x), floorf(pt.y), floorf(pt.z)};
   const V3 ph{pl.x + 1.f, pl.y + 1.f, pl.z + 1.f};
   const V3 al{ph.x - pt.x, ph.y - pt.y, ph.z - pt.z};
@@ -51,7 +95,7 @@ __device__ inline float retrieve_tsdf(const Table& tab, const Pool& pool, const 
     const int cx = (int16_t)f2i((i >> 2) & 1 ? pl.x : ph.x);
     const int cy = (int16_t)f2i((i >> 1) & 1 ? pl.y : ph.y);
     const int cz = (int16_t)f2i((i >> 0) & 1 ? pl.z : ph.z);
-    t[i] = tsdf_at(tab, pool, cx, cy, cz, c);
+    t[i] = tsdf_at(tab, pool, cx, cy, cz, c, occ);
   }
   const float t00 = t[0] * al.z + t[1] * (1 - al.z);
   const float t01 = t[2] * al.z + t[3] * (1 - al.z);
@@ -62,9 +106,34 @@ __device__ inline float retrieve_tsdf(const Table& tab, const Pool& pool, const 
   return t0 * al.x + t1 * (1 - al.x);
 }
 
+// the occupancy bits (kOccWords words, zeroed by the caller) from the live blocks: one lane per slot of Table::active
+// that has ever been in use
+__global__ __launch_bounds__(256) void k_occupancy_build(Table tab, const Ctl* ctl, uint32_t* bits) {
+  int32_t lo = ctl->free_low;
+  if (lo < 0) lo = 0;
+  const uint32_t n = (uint32_t)(tab.num_block - lo);
+  for (uint32_t i = blockIdx.x * block_threads() + threadIdx.x; i < n; i += gridDim.x * block_threads()) {
+    const uint4 a = reinterpret_cast<const uint4*>(tab.active)[(uint32_t)lo + i];  // {x | y << 16, z, idx, entry}
+    if ((int32_t)a.z < 0) continue;  // the slot is empty
+    const int bx = (int16_t)(a.x & 0xFFFFu), by = (int16_t)(a.x >> 16), bz = (int16_t)(a.y & 0xFFFFu);
+    const uint32_t h = occ_bit(bx, by, bz), g = occ_bit2(bx, by, bz);
+    atomicOr(&bits[h >> 5], 1u << (h & 31u));
+    atomicOr(&bits[g >> 5], 1u << (g & 31u));
+  }
+}
+
 __global__ __launch_bounds__(256) void k_raycast(Table tab, Pool pool, FrameParams P,
                                                  float step_size, int max_step, uint32_t* out_rgba,
-                                                 uint32_t* out_normal, int row0, int row1) {
+                                                 uint32_t* out_normal, int row0, int row1, const uint32_t* occ_bits,
+                                                 Ctl* ctl) {
+  // the occupancy bits in LDS (every wave of the workgroup takes part, whatever its pixels)
+  __shared__ __attribute__((aligned(16))) uint32_t occ[kOccWords];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(occ_bits);
+    uint4* dst = reinterpret_cast<uint4*>(occ);
+    for (uint32_t i = threadIdx.x; i < kOccWords / 4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
   // rows [row0, row1) of the P.H x P.W image (the whole image: 0, P.H); the output buffers hold those rows only
   const int x = blockIdx.x * 16 + (threadIdx.x & 15);
   const int y = row0 + blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -80,59 +149,125 @@ __global__ __launch_bounds__(256) void k_raycast(Table tab, Pool pool, FramePara
   }
   const V3 dw = quat_rotate(P.Ti.q, dc);                                      // :292-293
   const V3 full{dw.x * step_size / P.vs, dw.y * step_size / P.vs, dw.z * step_size / P.vs};  // :297
+  // (:361-367 divides the full step by 10 at every sample that chooses the fine step: the same three quotients every
+  // time -- thirty instructions of IEEE division per sample, here once)
+  const V3 fine_step{full.x / 10, full.y / 10, full.z / 10};
   V3 stepv = full;
+  bool is_fine = false;
   V3 p{P.Ti.t.x / P.vs, P.Ti.t.y / P.vs, P.Ti.t.z / P.vs};                    // :299
   BlockCache cache{0, 0, 0, -1, false};
-  auto gi = [](float v) { return (int)(int16_t)f2i(roundf(v)); };
-  float prev = tsdf_at(tab, pool, gi(p.x), gi(p.y), gi(p.z), cache);           // :302-303
+  // (short)roundf(v): the four-instruction form (device_math.h: round_to_int) wherever the ray can get -- it equals the
+  // long one for |v| < 2^31; one decision for the wave
+  const float reach = (float)max_step;
+  const bool small = __all(fabsf(p.x) + reach * fabsf(full.x) < 1e9f && fabsf(p.y) + reach * fabsf(full.y) < 1e9f &&
+                           fabsf(p.z) + reach * fabsf(full.z) < 1e9f);  // uniform
+  auto gi = [small](float v) { return small ? (int)(int16_t)round_to_int(v) : (int)(int16_t)f2i(roundf(v)); };
+  float prev = tsdf_at(tab, pool, gi(p.x), gi(p.y), gi(p.z), cache, occ);           // :302-303
   p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
-  for (int i = 1; i < max_step; ++i) {                                        // :305
-    const int gx = gi(p.x), gy = gi(p.y), gz = gi(p.z);
-    const long vi = voxel_index(tab, gx, gy, gz, cache);
-    const float cur = vi >= 0 ? pool.tsdf[vi] : -10.f;
-    const uint32_t wcur = vi >= 0 ? (pool.rgbw[vi] >> 24) : 0u;               // :308-309
-    if (wcur < 10) {                                                          // :312-316
-      p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
+  constexpr int kAhead = 4;
+  int i = 1;
+  bool done = false;
+#ifdef RATSDF_STAMPS
+  // per-wave record (tools/raycast_probe.py): [0] start, [1] end of the march, [2] end (10 ns ticks); [3] groups of the
+  // slowest lane, [4] samples of the slowest lane, [5] lanes that hit
+  unsigned long long* ws = ctl && ctl->debug_buf
+      ? ctl->debug_buf + (size_t)((((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) & 16383u)) * 8 : nullptr;
+  if (ws) atomicMin(&ws[0], wall_clock64());
+  unsigned long long n_groups = 0, ph[4] = {0, 0, 0, 0};
+#define RC_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); ph[k] += t_ - t_last; t_last = t_; } while (0)
+  unsigned long long t_last = clock64();
+#else
+#define RC_STAMP(k) do { } while (0)
+#endif
+  while (!done && i < max_step) {                                             // :305
+#ifdef RATSDF_STAMPS
+    ++n_groups;
+#endif
+    // the next kAhead samples if the step stays what it is: positions, then every probe and voxel load together
+    V3 q[kAhead];
+    long vis[kAhead];
+    float ts[kAhead];
+    uint32_t wsv[kAhead];
+    q[0] = p;
+#pragma unroll
+    for (int k = 1; k < kAhead; ++k) q[k] = V3{q[k - 1].x + stepv.x, q[k - 1].y + stepv.y, q[k - 1].z + stepv.z};
+    RC_STAMP(0);
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) vis[k] = voxel_index(tab, gi(q[k].x), gi(q[k].y), gi(q[k].z), cache, occ);
+    RC_STAMP(1);
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+      ts[k] = vis[k] >= 0 ? pool.tsdf[vis[k]] : -10.f;
+      wsv[k] = vis[k] >= 0 ? (pool.rgbw[vis[k]] >> 24) : 0u;                    // :308-309
+    }
+    RC_STAMP(2);
+    // ... judged one by one, as the plain loop would (p == q[k] bit for bit while the step has not changed)
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+      if (done || i >= max_step) break;
+      const float cur = ts[k];
+      if (wsv[k] < 10) {                                                      // :312-316
+        p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
+        prev = cur;
+        ++i;
+        continue;
+      }
+      if (prev > 0 && cur <= 0 && prev - cur <= 2.0f) {                       // :318: the zero crossing (below)
+        done = true;
+        break;
+      }
       prev = cur;
-      continue;
+      const bool want_fine = cur < 0.5f;                                      // :361-367
+      const bool changed = want_fine != is_fine;
+      is_fine = want_fine;
+      stepv = want_fine ? fine_step : full;
+      p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
+      ++i;
+      if (changed) break;  // what was fetched beyond this sample assumed the old step
     }
-    if (prev > 0 && cur <= 0 && prev - cur <= 2.0f) {                         // :318
-      const V3 p1{p.x - stepv.x, p.y - stepv.y, p.z - stepv.z};
-      const float ac = retrieve_tsdf(tab, pool, p, cache);                    // :323-324
-      const float ap = retrieve_tsdf(tab, pool, p1, cache);
-      const float f = ac / (ap - ac);                                         // :327-328
-      const V3 pi{p.x + f * stepv.x, p.y + f * stepv.y, p.z + f * stepv.z};
-      const int fx = gi(pi.x), fy = gi(pi.y), fz = gi(pi.z);                  // :329-330
-      const long fi = voxel_index(tab, fx, fy, fz, cache);
-      const uint32_t c = fi >= 0 ? pool.rgbw[fi] : 0u;                        // :333-334
-      const float prob = fi >= 0 ? pool.segm[fi] : 0.f;
-      auto at = [&](int dx, int dy, int dz) {
-        return tsdf_at(tab, pool, (int16_t)(fx + dx), (int16_t)(fy + dy), (int16_t)(fz + dz), cache);
-      };
-      const V3 nr{at(1, 0, 0) - at(-1, 0, 0), at(0, 1, 0) - at(0, -1, 0),
-                  at(0, 0, 1) - at(0, 0, -1)};                                // :337-348
-      const float dotv = nr.x * (-dw.x) + (nr.y * (-dw.y) + nr.z * (-dw.z));
-      const float nn = sqrtf(nr.x * nr.x + (nr.y * nr.y + nr.z * nr.z));
-      const float diff = fmaxf(dotv / nn, 0);                                 // :349
-      const float alpha = fmaxf(prob - 0.5f, 0) / .5f;                        // :350
-      const float cr = (float)(c & 0xFFu), cg = (float)((c >> 8) & 0xFFu),
-                  cb = (float)((c >> 16) & 0xFFu);
-      o_c = ((uint32_t)f2i(alpha * 255 + (1 - alpha) * cr) & 0xFFu) |
-            (((uint32_t)f2i((1 - alpha) * cg) & 0xFFu) << 8) |
-            (((uint32_t)f2i((1 - alpha) * cb) & 0xFFu) << 16) | 0xFF000000u;  // :351-353
-      const uint32_t n0 = (uint32_t)f2i(alpha * 255 + (1 - alpha) * diff * 255) & 0xFFu;
-      const uint32_t n1 = (uint32_t)f2i((1 - alpha) * diff * 255) & 0xFFu;
-      o_n = n0 | (n1 << 8) | (n1 << 16) | 0xFF000000u;                        // :354-356
-      break;
-    }
-    prev = cur;
-    if (cur < 0.5f) {                                                         // :361-367
-      stepv = V3{full.x / 10, full.y / 10, full.z / 10};
-    } else {
-      stepv = full;
-    }
-    p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
+    RC_STAMP(3);
   }
+  if (done) {  // :318-357 at the crossing sample: p and the step are that sample's
+    const V3 p1{p.x - stepv.x, p.y - stepv.y, p.z - stepv.z};
+    const float ac = retrieve_tsdf(tab, pool, p, cache, occ);                 // :323-324
+    const float ap = retrieve_tsdf(tab, pool, p1, cache, occ);
+    const float f = ac / (ap - ac);                                           // :327-328
+    const V3 pi{p.x + f * stepv.x, p.y + f * stepv.y, p.z + f * stepv.z};
+    const int fx = gi(pi.x), fy = gi(pi.y), fz = gi(pi.z);                    // :329-330
+    const long fi = voxel_index(tab, fx, fy, fz, cache, occ);
+    const uint32_t c = fi >= 0 ? pool.rgbw[fi] : 0u;                          // :333-334
+    const float prob = fi >= 0 ? pool.segm[fi] : 0.f;
+    auto at = [&](int dx, int dy, int dz) {
+      return tsdf_at(tab, pool, (int16_t)(fx + dx), (int16_t)(fy + dy), (int16_t)(fz + dz), cache, occ);
+    };
+    const V3 nr{at(1, 0, 0) - at(-1, 0, 0), at(0, 1, 0) - at(0, -1, 0),
+                at(0, 0, 1) - at(0, 0, -1)};                                  // :337-348
+    const float dotv = nr.x * (-dw.x) + (nr.y * (-dw.y) + nr.z * (-dw.z));
+    const float nn = sqrtf(nr.x * nr.x + (nr.y * nr.y + nr.z * nr.z));
+    const float diff = fmaxf(dotv / nn, 0);                                   // :349
+    const float alpha = fmaxf(prob - 0.5f, 0) / .5f;                          // :350
+    const float cr = (float)(c & 0xFFu), cg = (float)((c >> 8) & 0xFFu),
+                cb = (float)((c >> 16) & 0xFFu);
+    o_c = ((uint32_t)f2i(alpha * 255 + (1 - alpha) * cr) & 0xFFu) |
+          (((uint32_t)f2i((1 - alpha) * cg) & 0xFFu) << 8) |
+          (((uint32_t)f2i((1 - alpha) * cb) & 0xFFu) << 16) | 0xFF000000u;    // :351-353
+    const uint32_t n0 = (uint32_t)f2i(alpha * 255 + (1 - alpha) * diff * 255) & 0xFFu;
+    const uint32_t n1 = (uint32_t)f2i((1 - alpha) * diff * 255) & 0xFFu;
+    o_n = n0 | (n1 << 8) | (n1 << 16) | 0xFF000000u;                          // :354-356
+  }
+#ifdef RATSDF_STAMPS
+  if (ws) {
+    atomicMax(&ws[2], wall_clock64());
+    atomicMax(&ws[3], n_groups);
+    atomicMax(&ws[4], (unsigned long long)i);
+    if (done) atomicAdd(&ws[5], 1ull);
+    if (i >= max_step) {  // a ray that ran its full length: cycles in positions | probes | voxel loads | judging
+      ws[6] = ph[1];
+      ws[7] = ph[2];
+      ws[1] = ph[0] + ph[3];
+    }
+  }
+#endif
   if (out_rgba) out_rgba[idx] = o_c;
   if (out_normal) out_normal[idx] = o_n;
 }

@@ -185,6 +185,7 @@ struct ratsdf_engine {
   Pool pool{};
   Ctl* ctl = nullptr;
   ratsdf_frame_stats* d_stats = nullptr;
+  uint32_t* d_occ = nullptr;  // ray casting: hashed occupancy of the blocks (kernels_raycast.h), built per rendering
   uint32_t* h_err = nullptr;  // page-locked landing place of the sticky error word (sticky())
   EngineDev* d_eng = nullptr;  // device copy of the engine record (device_types.h)
 
@@ -384,7 +385,7 @@ int ratsdf_engine::free_all() {
                   req, req_k, win_ranks, abitmap, asummary, aprefix,
                   slow, xlocks,
                   sort_scratch, masks, wg_count, vis, del_list[0], del_list[1], upd_wg[0],
-                  upd_wg[1], tab.dclaim, dbitmap, dsummary, dprefix, slowdel[0], slowdel[1], d_stage, d_mc, serial_scratch};
+                  upd_wg[1], tab.dclaim, dbitmap, dsummary, dprefix, slowdel[0], slowdel[1], d_stage, d_mc, serial_scratch, d_occ};
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   if (copy_stream2) (void)hipStreamSynchronize(copy_stream2);
   if (stream) (void)hipStreamSynchronize(stream);
@@ -1693,6 +1694,21 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
   return RATSDF_OK;
 }
 
+// diagnostic (stamps build only): the raw per-wave record buffer ratsdf_debug_wave_stamps(e, 1) attached (16 384 x 8
+// words), copied out and zeroed -- k_raycast's per-wave timeline (tools/raycast_probe.py)
+extern "C" int ratsdf_debug_wave_records(ratsdf_engine* e, unsigned long long* out, size_t words) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e || !out || words > 16384 * 8) return RATSDF_ERR_BAD_ARGUMENT;
+  unsigned long long* buf = nullptr;
+  HIPCHK(hipMemcpyAsync(&buf, &e->ctl->debug_buf, sizeof(buf), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (!buf) return RATSDF_ERR_BAD_ARGUMENT;
+  HIPCHK(hipMemcpyAsync(out, buf, words * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RATSDF_OK;
+}
+
 // diagnostic (stamps build only): Ctl::dbg -- RATSDF_DEBUG=30 counts update waves that changed no voxel:
 // [0] such waves, [1] waves, [2] blocks without an update, [3] blocks; read and reset
 extern "C" int ratsdf_debug_counters(ratsdf_engine* e, unsigned long long* out8) {
@@ -1924,8 +1940,13 @@ static int raycast_rows_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int
   const float step_size = e->trunc / 2;         // voxel_tsdf.cu:892
   const float ms = ceilf(max_depth / step_size);
   const int max_step = ms >= 2147483648.f ? 2147483647 : (int)ms;  // voxel_tsdf.cu:298
+  // block-level occupancy of the map as it is now (kernels_raycast.h: empty space costs no directory probes)
+  if (!e->d_occ) HIPCHK(hipMalloc(&e->d_occ, kOccWords * 4));
+  HIPCHK(hipMemsetAsync(e->d_occ, 0, kOccWords * 4, e->stream));
+  hipLaunchKernelGGL(k_occupancy_build, dim3(256), dim3(256), 0, e->stream, e->tab, (const Ctl*)e->ctl, e->d_occ);
   hipLaunchKernelGGL(k_raycast, dim3((width + 15) / 16, (row1 - row0 + 15) / 16), dim3(256), 0, e->stream,
-                     e->tab, e->pool, P, step_size, max_step, (uint32_t*)d_rgba, (uint32_t*)d_normal, row0, row1);
+                     e->tab, e->pool, P, step_size, max_step, (uint32_t*)d_rgba, (uint32_t*)d_normal, row0, row1,
+                     (const uint32_t*)e->d_occ, e->ctl);
   HIPCHK(hipGetLastError());
   return RATSDF_OK;
 }

@@ -429,6 +429,12 @@ class Engine:
                "raycast")
         return rgba, normal
 
+    def raycast_device(self, intrinsics, height, width, pose, max_depth, d_rgba, d_normal):
+        """raycast() into DEVICE buffers (H x W x 4 uint8 each; either may be 0), asynchronous on the engine's stream"""
+        k, p = _as_intr(intrinsics), _as_pose(pose)
+        _check(self.lib.fn["raycast_device"](self._h, C.byref(k), height, width, C.byref(p), float(max_depth),
+                                             d_rgba or None, d_normal or None), "raycast_device")
+
     def raycast_rows(self, intrinsics, height, width, pose, max_depth, row0, row1):
         """rows [row0, row1) of raycast(): (rgba, normal), (row1 - row0) x W x 4 uint8 each"""
         k, p = _as_intr(intrinsics), _as_pose(pose)
