@@ -192,8 +192,33 @@ __global__ __launch_bounds__(256) void k_raycast(Table tab, Pool pool, FramePara
 #pragma unroll
     for (int k = 1; k < kAhead; ++k) q[k] = V3{q[k - 1].x + stepv.x, q[k - 1].y + stepv.y, q[k - 1].z + stepv.z};
     RC_STAMP(0);
+    {  // the group's lookups: the filter bits of all four blocks first (eight LDS reads in flight together; one after
+       // the other inside voxel_index they were four LDS round trips between four divergent branches), then the cache /
+       // directory logic sample by sample
+      int gxs[kAhead], gys[kAhead], gzs[kAhead];
+      bool maybe[kAhead];
 #pragma unroll
-    for (int k = 0; k < kAhead; ++k) vis[k] = voxel_index(tab, gi(q[k].x), gi(q[k].y), gi(q[k].z), cache, occ);
+      for (int k = 0; k < kAhead; ++k) {
+        gxs[k] = gi(q[k].x);
+        gys[k] = gi(q[k].y);
+        gzs[k] = gi(q[k].z);
+        maybe[k] = occ_maybe(occ, gxs[k] >> 3, gys[k] >> 3, gzs[k] >> 3);
+      }
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        const int bx = gxs[k] >> 3, by = gys[k] >> 3, bz = gzs[k] >> 3;
+        if (!(cache.valid && cache.bx == bx && cache.by == by && cache.bz == bz)) {
+          int32_t idx = -1;
+          if (maybe[k]) {
+            EntryWords w;
+            const uint32_t e = find_block(tab, bx, by, bz, &w);
+            idx = e == kInf ? -1 : w.idx;
+          }
+          cache = BlockCache{bx, by, bz, idx, true};
+        }
+        vis[k] = cache.idx < 0 ? -1 : ((long)cache.idx << 9) + ((gxs[k] & 7) + (gys[k] & 7) * 8 + (gzs[k] & 7) * 64);
+      }
+    }
     RC_STAMP(1);
 #pragma unroll
     for (int k = 0; k < kAhead; ++k) {
