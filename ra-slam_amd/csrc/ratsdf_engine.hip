@@ -185,6 +185,8 @@ struct ratsdf_engine {
   Pool pool{};
   Ctl* ctl = nullptr;
   ratsdf_frame_stats* d_stats = nullptr;
+  uint8_t *d_render = nullptr, *h_render = nullptr;  // ray casting through the host entry points: output + page-locked copy
+  size_t render_cap = 0;
   uint32_t* d_occ = nullptr;  // ray casting: hashed occupancy of the blocks (kernels_raycast.h), built per rendering
   uint32_t* h_err = nullptr;  // page-locked landing place of the sticky error word (sticky())
   EngineDev* d_eng = nullptr;  // device copy of the engine record (device_types.h)
@@ -398,6 +400,10 @@ int ratsdf_engine::free_all() {
   if (h_stage) (void)hipHostFree(h_stage);
   if (h_err) (void)hipHostFree(h_err);
   h_err = nullptr;
+  if (d_render) (void)hipFree(d_render);
+  if (h_render) (void)hipHostFree(h_render);
+  d_render = h_render = nullptr;
+  render_cap = 0;
   if (dl_dev) (void)hipFree(dl_dev);
   if (dl_host) (void)hipHostFree(dl_host);
   for (auto& ev : stage_ev)
@@ -1965,19 +1971,27 @@ int ratsdf_raycast_rows(ratsdf_engine* e, const ratsdf_intrinsics* K, int height
   if (!e || height <= 0 || width <= 0 || row0 < 0 || row1 > height || row0 > row1) return RATSDF_ERR_BAD_ARGUMENT;
   const size_t bytes = (size_t)(row1 - row0) * width * 4;
   if (bytes == 0) return raycast_rows_device(e, K, height, width, T, max_depth, row0, row1, nullptr, nullptr);
-  uint8_t* d = nullptr;
-  HIPCHK(hipMalloc(&d, bytes * 2));
-  int st = raycast_rows_device(e, K, height, width, T, max_depth, row0, row1, d, d + bytes);
-  if (st == RATSDF_OK) {
-    hipError_t err = hipSuccess;
-    if (rgba) err = hipMemcpyAsync(rgba, d, bytes, hipMemcpyDeviceToHost, e->stream);
-    if (err == hipSuccess && normal)
-      err = hipMemcpyAsync(normal, d + bytes, bytes, hipMemcpyDeviceToHost, e->stream);
-    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);  // voxel_tsdf.cu:901
-    if (err != hipSuccess) st = RATSDF_ERR_DEVICE;
+  // The two images leave through buffers the engine keeps: device memory for the kernel's output and page-locked host
+  // memory for the copy out (until round 5: a hipMalloc / hipFree pair per call and two copies into the caller's
+  // pageable buffers through the runtime's staging path -- 0.84 ms per 640x480 rendering of which the kernel was half).
+  if (e->render_cap < bytes * 2) {
+    (void)hipStreamSynchronize(e->stream);
+    if (e->d_render) (void)hipFree(e->d_render);
+    if (e->h_render) (void)hipHostFree(e->h_render);
+    e->d_render = e->h_render = nullptr;
+    e->render_cap = 0;
+    HIPCHK(hipMalloc(&e->d_render, bytes * 2));
+    HIPCHK(hipHostMalloc(&e->h_render, bytes * 2, hipHostMallocDefault));
+    e->render_cap = bytes * 2;
   }
-  (void)hipFree(d);
-  return st;
+  uint8_t* d = e->d_render;
+  int st = raycast_rows_device(e, K, height, width, T, max_depth, row0, row1, d, d + bytes);
+  if (st != RATSDF_OK) return st;
+  HIPCHK(hipMemcpyAsync(e->h_render, d, bytes * 2, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));  // voxel_tsdf.cu:901
+  if (rgba) memcpy(rgba, e->h_render, bytes);
+  if (normal) memcpy(normal, e->h_render + bytes, bytes);
+  return RATSDF_OK;
 }
 
 int ratsdf_raycast(ratsdf_engine* e, const ratsdf_intrinsics* K, int height, int width,
