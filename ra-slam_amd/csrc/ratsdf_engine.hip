@@ -348,6 +348,7 @@ struct ratsdf_engine {
   CandJob cand_job(const FrameIn& in, const FrameParams& P, unsigned par) const;
   int frame(const FrameIn& cur, const FrameIn* next, int H, int W, float md);
   int sticky();
+  int read_small(void* dst, const void* dev_src, size_t bytes);
   int drain_profile(bool final = true);
   FrameParams base_params() const;
   struct Geom {
@@ -854,6 +855,17 @@ int ratsdf_engine::sticky() {
   return (int)((volatile uint32_t*)h_err)[1];
 }
 
+// A few words of device memory for the host, after everything enqueued so far: through the page-locked landing buffer
+// (h_err + 16 words on), not straight into the caller's pageable memory (the runtime's staging path: ~20 us per call,
+// and these are the calls a per-frame logger makes -- NumActiveBlock, the frame statistics).
+int ratsdf_engine::read_small(void* dst, const void* dev_src, size_t bytes) {
+  if (bytes > 384) return RATSDF_ERR_BAD_ARGUMENT;
+  HIPCHK(hipMemcpyAsync(h_err + 16, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  memcpy(dst, h_err + 16, bytes);
+  return RATSDF_OK;
+}
+
 // Non-finite camera parameters are refused at the boundary (RATSDF_ERR_BAD_ARGUMENT).  The reference
 // would integrate garbage (a NaN pose projects every voxel to pixel (0, 0): float -> int of NaN is 0 in
 // CUDA); the engine's short pixel pick (kernels_integrate.h) reproduces the reference for
@@ -1090,7 +1102,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   CREATE_CHK(hipMalloc(&e->pool.heap, (size_t)t.num_block * 4));
   CREATE_CHK(hipMalloc(&e->ctl, sizeof(Ctl)));
   CREATE_CHK(hipMalloc(&e->d_stats, sizeof(ratsdf_frame_stats)));
-  CREATE_CHK(hipHostMalloc(&e->h_err, 64, hipHostMallocDefault));
+  CREATE_CHK(hipHostMalloc(&e->h_err, 512, hipHostMallocDefault));
   CREATE_CHK(hipMalloc(&e->d_eng, sizeof(EngineDev)));
   CREATE_CHK(hipMalloc(&e->slow, (size_t)kSlowCap * sizeof(SlowRequest)));
   CREATE_CHK(hipMalloc(&e->xlocks, (size_t)kXLockCap * sizeof(XLock)));
@@ -1596,8 +1608,7 @@ int ratsdf_num_active_blocks(ratsdf_engine* e, int32_t* out) {
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   int32_t nf = 0;
-  HIPCHK(hipMemcpyAsync(&nf, &e->ctl->num_free, 4, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  { const int rs = e->read_small(&nf, &e->ctl->num_free, 4); if (rs != RATSDF_OK) return rs; }
   *out = e->tab.num_block - nf;
   return RATSDF_OK;
 }
@@ -1607,8 +1618,7 @@ int ratsdf_last_frame_stats(ratsdf_engine* e, ratsdf_frame_stats* out) {
   if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e || !out) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
-  HIPCHK(hipMemcpyAsync(out, e->d_stats, sizeof(*out), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  { const int rs = e->read_small(out, e->d_stats, sizeof(*out)); if (rs != RATSDF_OK) return rs; }
   return RATSDF_OK;
 }
 
@@ -1790,9 +1800,8 @@ int ratsdf_totals(ratsdf_engine* e, int64_t* out5, int reset) {
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   { const int st0 = e->settle(); if (st0 != RATSDF_OK) return st0; }
   unsigned long long t[5] = {0, 0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(t, e->ctl->totals, sizeof(t), hipMemcpyDeviceToHost, e->stream));
+  { const int rs = e->read_small(t, e->ctl->totals, sizeof(t)); if (rs != RATSDF_OK) return rs; }
   if (reset) HIPCHK(hipMemsetAsync(e->ctl->totals, 0, sizeof(t), e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
   if (out5)
     for (int i = 0; i < 5; ++i) out5[i] = (int64_t)t[i];
   return RATSDF_OK;
@@ -1803,9 +1812,8 @@ int ratsdf_pipeline_counters(ratsdf_engine* e, int64_t* out4, int reset) {
   if (!guard.ok()) return RATSDF_ERR_DEVICE;
   if (!e) return RATSDF_ERR_BAD_ARGUMENT;
   unsigned long long t[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(t, e->ctl->paths, sizeof(t), hipMemcpyDeviceToHost, e->stream));
+  { const int rs = e->read_small(t, e->ctl->paths, sizeof(t)); if (rs != RATSDF_OK) return rs; }
   if (reset) HIPCHK(hipMemsetAsync(e->ctl->paths, 0, sizeof(t), e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
   if (out4)
     for (int i = 0; i < 4; ++i) out4[i] = (int64_t)t[i];
   return RATSDF_OK;
@@ -1830,8 +1838,7 @@ static int ensure_download_buffers(ratsdf_engine* e, size_t bytes) {
 
 static int download_selected(ratsdf_engine* e, bool semantic, void** out, size_t* n) {
   uint32_t cnt = 0;
-  HIPCHK(hipMemcpyAsync(&cnt, &e->ctl->n_sel, 4, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  { const int rs = e->read_small(&cnt, &e->ctl->n_sel, 4); if (rs != RATSDF_OK) return rs; }
   const size_t rec = semantic ? sizeof(ratsdf_voxel_segm) : sizeof(ratsdf_voxel_tsdf);
   const size_t total = (size_t)cnt * RATSDF_BLOCK_VOLUME;
   void* host = malloc(total ? total * rec : 1);
