@@ -44,5 +44,9 @@ timeout -k 10 200 rocprofv3 --memory-copy-trace --output-format csv -d gpurun_ou
 { grep "pinned path" gpurun_out/r5_copytrace.log; python3 tools/copy_gaps.py "$(ls gpurun_out/r5_copytrace/*/*memory_copy_trace.csv | head -1)" 19660800; } > $O/${TAG}_pinned_path_copy_gaps.txt 2>&1
 timeout -k 10 120 python tools/pinned_probe.py >> $O/${TAG}_pinned_path_copy_gaps.txt 2>&1
 cp gpurun_out/r5_pmc_check.log $O/${TAG}_pmc_check.txt 2>/dev/null
+# (gpurun copies back at most 64 MiB of gpurun_out/: the raw rocprofv3 trees -- kernel traces of thousands of launches --
+# stay on the box, the summaries above are what is kept)
+rm -rf gpurun_out/kstats_*/ gpurun_out/sq_*/ gpurun_out/traffic*/ gpurun_out/r5_copytrace/ gpurun_out/tr_*/ 2>/dev/null
+du -sh gpurun_out | tail -1
 ls -la $O | tail -40
 echo "collect done"
