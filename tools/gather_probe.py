@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""The C call behind TSDFGrid::GatherValid on the bench map (41 MB of records), without the binding's hand-over:
+tools/gather_probe.py   (GPU box; RATSDF_LIB selects the library)"""
 import sys, time, ctypes as C
-sys.path.insert(0, "/root/repo/ra-slam_amd")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "ra-slam_amd"))
 import numpy as np, ratsdf
 from ratsdf import synthetic
 gpu = ratsdf.TSDFGrid(0.005, 0.03)
