@@ -7,8 +7,9 @@
 // wave and touches no map state, so it does not have to sit on the frame's critical path: when the
 // caller hands over a batch of frames (ratsdf_integrate_device_batch = the queue of
 // TSDFSystem::Run, modules/tsdf_module.cc:88-115), the candidate pass of frame f+1 runs as extra
-// workgroups inside frame f's k_front and k_integrate (kernels_frame.h).  A single
-// frame (ratsdf_integrate_device) runs it as its own launch.
+// workgroups inside frame f's k_front and k_integrate (kernels_frame.h).  A frame nobody looked
+// ahead for (a single ratsdf_integrate_device call, the first frame of a batch) runs both halves in the workgroups of
+// its own k_front (cand_inline_role / k_front_inline; until round 5 the pixel half was a launch of its own, k_cand).
 //
 // Output of the pass = the frame's candidate list: (block, raster rank = pixel * S + sample) pairs,
 // deduplicated per workgroup with the SMALLEST rank kept.  Only the first request for a block
@@ -96,7 +97,10 @@ __device__ inline bool cand_lds_insert(CandLds& L, unsigned long long key, uint3
 
 // block_allocate_kernel up to (not including) the directory lookup, one lane per pixel, one 16x4
 // tile per wave.  `wg` counts workgroups inside the job.
-__device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg, Ctl* ctl, uint32_t reserved_at) {
+// `overflow(bx, by, bz, k0, k1, rank)`: what happens to a candidate that finds the workgroup's LDS set full.
+template <typename Overflow>
+__device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg, Ctl* ctl, uint32_t reserved_at,
+                                       Overflow overflow) {
   const FrameParams& P = J.P;
   // (the tile's place in the image is the same for the whole wave: scalar arithmetic, and the division by the
   // row length as a multiplication -- as vector code with a run-time divisor it was 33 instructions per lane)
@@ -257,8 +261,7 @@ __device__ inline void cand_pixel_work(const CandJob& J, CandLds& L, uint32_t wg
       const unsigned long long key = (unsigned long long)k0 | ((unsigned long long)k1 << 32);
       // (slot of the workgroup's set: any spreading of neighbouring blocks will do -- two 24-bit multiply-adds
       // instead of the directory hash's three full 32-bit multiplications, which issue at a quarter of the rate)
-      if (!cand_lds_insert(L, key, (uint32_t)(bx + by * 17 + bz * 41), rank))
-        cand_append(J.set, (J.first_tile + wg) & (kCandSegs - 1), k0, k1, rank, ctl);
+      if (!cand_lds_insert(L, key, (uint32_t)(bx + by * 17 + bz * 41), rank)) overflow(bx, by, bz, k0, k1, rank);
     }
     if (act) {
       prev0 = k0;
@@ -320,7 +323,10 @@ __device__ inline void cand_pixels_role(const CandJob& J, uint32_t wg, Ctl* ctl,
 #ifdef RATSDF_STAMPS
   cs[1] = clock64();
 #endif
-  if ((threadIdx.x >> 6) < J.tiles_per_wg) cand_pixel_work(J, L, wg, ctl, reserved_at);  // whole waves in or out
+  if ((threadIdx.x >> 6) < J.tiles_per_wg)  // whole waves in or out
+    cand_pixel_work(J, L, wg, ctl, reserved_at, [&](int, int, int, uint32_t k0, uint32_t k1, uint32_t rank) {
+      cand_append(J.set, (J.first_tile + wg) & (kCandSegs - 1), k0, k1, rank, ctl);  // straight to the global list
+    });
 #ifdef RATSDF_STAMPS
   cs[2] = clock64();
 #endif
@@ -464,6 +470,63 @@ __device__ inline void cand_consume_role(const Table& tab, const FrameParams& P,
     const bool want = wave_block_visible_full(absent, bx, by, bz, P);
     alloc_request_absent_wave(want, tab, bx, by, bz, item.z, ea, eb, req, req_cap, slow, slow_cap, ctl,
                               F, B);
+  }
+  req_buf_flush(B, req, req_cap, ctl, F, tab.tail_on != 0);
+}
+
+// Both halves in ONE workgroup, for a frame nobody looked ahead for (a single ratsdf_integrate_device call, the first
+// frame of a batch): the workgroup's pixels fill its LDS set as above, and the same workgroup then looks its OWN
+// candidates up and files their requests -- no candidate list, no consumer workgroups, no launch of its own for the
+// pixel half (until round 5: k_cand, then k_front; a caller that synchronises after every frame -- TSDFGrid::Integrate's
+// convention -- paid three launches per frame).  Duplicates between workgroups are settled by the claims, as ever.
+// A candidate that finds the LDS set full (never seen; 512 slots for the few dozen blocks a 16x16-pixel patch asks
+// for) files its request on the spot.  `lds`: sizeof(CandLds) rounded up to 16 bytes + sizeof(ReqBuf) bytes.
+constexpr uint32_t kInlineReqOffsetWords = ((uint32_t)sizeof(CandLds) + 15u) / 16u * 4u;
+template <typename Gate>
+__device__ inline void cand_inline_role(const CandJob& J, uint32_t wg, const Table& tab, Request* req, uint32_t req_cap,
+                                        SlowRequest* slow, uint32_t slow_cap, Ctl* ctl, FrameCtl* F, Gate gate,
+                                        uint32_t* lds) {
+  CandLds& L = *reinterpret_cast<CandLds*>(lds);
+  ReqBuf& B = *reinterpret_cast<ReqBuf*>(lds + kInlineReqOffsetWords);
+  const FrameParams& P = J.P;
+  for (uint32_t i = threadIdx.x; i < kCandLdsSlots; i += 256) {
+    L.keys[i] = kCandEmpty;
+    L.ranks[i] = kInf;
+  }
+  if (threadIdx.x == 0) {
+    L.n = 0;
+    B.n = 0;
+  }
+  // the previous frame's queued deletes have happened before anything here reads the directory (the overflow path
+  // below may, in the middle of the pixel half)
+  const bool open = gate() != kGateExpired;  // uniform; expired: the sticky error is set, the frame is incomplete
+  __syncthreads();
+  if ((threadIdx.x >> 6) < J.tiles_per_wg)  // whole waves in or out
+    cand_pixel_work(J, L, wg, ctl, 0u, [&](int bx, int by, int bz, uint32_t, uint32_t, uint32_t rank) {
+      if (open && block_visible<true>(bx, by, bz, P)) alloc_request(tab, bx, by, bz, rank, req, req_cap, slow, slow_cap, ctl, F);
+    });
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS-only barrier: the set is complete
+  if (!open) return;
+  // the directory half over the workgroup's own set: one lane per slot (cand_consume_role's loop body)
+  for (uint32_t base = 0; base < kCandLdsSlots; base += 256) {  // uniform
+    const uint32_t i = base + threadIdx.x;
+    const unsigned long long key = L.keys[i];
+    const bool have = key != kCandEmpty;
+    int bx = 0, by = 0, bz = 0;
+    EntryWords ea{0, 0, -1}, eb{0, 0, -1};
+    bool absent = false;
+    if (have) {
+      const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+      bx = (int16_t)(k0 & 0xFFFFu);
+      by = (int16_t)(k0 >> 16);
+      bz = (int16_t)(k1 & 0xFFFFu);
+      const uint32_t e0 = block_hash(bx, by, bz, tab.bucket_mask) << 1;
+      ea = load_entry(tab.entries, e0);
+      eb = load_entry(tab.entries, e0 + 1);
+      absent = !block_present_pre(tab, k0, k1, e0, ea, eb);
+    }
+    const bool want = wave_block_visible_full(absent, bx, by, bz, P);
+    alloc_request_absent_wave(want, tab, bx, by, bz, L.ranks[i], ea, eb, req, req_cap, slow, slow_cap, ctl, F, B);
   }
   req_buf_flush(B, req, req_cap, ctl, F, tab.tail_on != 0);
 }

@@ -445,6 +445,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
                     ctl, par, stats, tail, [&]() { return ahead; }, role_lds);
 }
 
+// k_front for a frame nobody looked ahead for (kernels_cand.h: cand_inline_role): the frame's own candidate pass rides
+// in the launch, every pixel workgroup its own consumer.
+//   workgroups [0, n_vis_wg)            visible list
+//   workgroups [.., +n_now_wg)          this frame's pixels -> candidates -> requests
+//   workgroups [.., +kReleaseWGs)       pool releases of the previous frame
+//   workgroups beyond                   look-ahead candidate pass of the next frame (`ahead`), if the caller named one
+// A kernel of its own so that the steady-state k_front carries none of this (its scalar registers are all in use).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8))) void k_front_inline(
+    Table tab, uint32_t n_vis_wg, uint32_t n_now_wg, Request* req, uint32_t req_cap, SlowRequest* slow,
+    uint32_t slow_cap, VisItem* vis, uint32_t seg_cap, Pool pool, CarveBufs cb, Ctl* ctl, uint32_t par, CandJob now,
+    CandJob ahead) {
+  static_assert((kInlineReqOffsetWords * 4u + sizeof(ReqBuf)) <= kFrontLdsWords * 4u, "role LDS");
+  __shared__ __attribute__((aligned(16))) uint32_t role_lds[kFrontLdsWords];
+  const uint32_t n_dir_wg = n_vis_wg + n_now_wg + kReleaseWGs;
+  if (blockIdx.x >= n_dir_wg) {
+    cand_pixels_role(ahead, blockIdx.x - n_dir_wg, ctl, *reinterpret_cast<CandLds*>(role_lds));
+    return;
+  }
+  FrameCtl* F = &ctl->fr[par];
+  FrameCtl* Fp = &ctl->fr[par ^ 1u];
+  auto gate = [&]() { return carve_resolve_gate(tab, cb, ctl, Fp, RATSDF_DBG(now.P, 20)); };
+  if (blockIdx.x >= n_vis_wg + n_now_wg) {
+    if (gate() != kGateExpired)
+      carve_release_role(tab, pool, cb, ctl, Fp, blockIdx.x - n_vis_wg - n_now_wg, role_lds);
+  } else if (blockIdx.x >= n_vis_wg) {
+    cand_inline_role(now, blockIdx.x - n_vis_wg, tab, req, req_cap, slow, slow_cap, ctl, F, gate, role_lds);
+  } else {
+    visible_append_role(tab, now.P, blockIdx.x, n_vis_wg, vis, seg_cap, ctl, F, gate, role_lds);
+  }
+}
+
 // the same launch for several engines: engine blockIdx.y, operands from its record and its job
 template <bool kTail>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8))) void k_front_g(

@@ -222,6 +222,7 @@ struct ratsdf_engine {
   // role is ~7 us of dependent round trips wherever it runs, and inside k_integrate it hides behind the update.
   bool front_tail = false;
   uint32_t front_prio = 0u;              // 2: k_front's directory workgroups run at raised wave priority (+1 %)
+  bool inline_off = false;               // diagnostic build, RATSDF_INLINE_CAND=0: k_cand + k_front for frames without look-ahead
   int commit_rot_env = -1;               // RATSDF_COMMIT_ROT: first committing workgroup (measurements)
   // With the serial role in the launch: which update workgroups take the frame's commits.  A grid of
   // at most two rounds of resident workgroups (256 CUs x 8): the first ones, which wait for the role
@@ -705,10 +706,18 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
   const FrameParams P = frame_params(cur, H, W, md);
   const unsigned par = parity;
 
-  if (!cand_ready) {  // nobody looked ahead: this frame's candidate pass runs in line
+  // nobody looked ahead (a single frame, the first of a batch): this frame's candidate pass rides in k_front, every
+  // pixel workgroup its own consumer (k_front_inline)
+  const bool inline_cand = !cand_ready;
+#ifdef RATSDF_STAMPS
+  const bool inline_kernel = inline_cand && !tab.tail_on && !inline_off;  // (RATSDF_INLINE_CAND=0: k_cand + k_front, for A/B)
+  if (inline_cand && !inline_kernel) {
     const CandJob job = cand_job(cur, P, par);
     hipLaunchKernelGGL(k_cand, dim3((job.n_tiles + 3) / 4), dim3(256), 0, stream, job, ctl);
   }
+#else
+  const bool inline_kernel = inline_cand;
+#endif
   // Where the NEXT frame's candidate pass rides (interleaved A/B, profiles/r02_split_ab.txt): at
   // 640x480 10 % in k_front (20 % until round 5) and the rest at the head of k_integrate's grid (10-30 % measured the same,
   // 0 and 40 % are ~2.5 % slower: k_front is a chain of dependent round trips that a few riders do not
@@ -742,6 +751,13 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
 
   // fr[par] was zeroed when the frame before last was finalised (or at creation)
   const bool fused = fused_serial && vpl != 1;
+  if (inline_kernel) {
+    const CandJob now = cand_job(cur, P, par);
+    const unsigned n_now_wg = (now.n_tiles + 3) / 4;
+    hipLaunchKernelGGL(k_front_inline, dim3(g.n_vis_wg + n_now_wg + kReleaseWGs + (g.a.n_tiles + 3) / 4), dim3(256), 0,
+                       stream, tab, (uint32_t)g.n_vis_wg, (uint32_t)n_now_wg, req, req_cap, slow, kSlowCap,
+                       vis + kFreshCap, seg_cap, pool, carve_bufs(par ^ 1u), ctl, (uint32_t)par, now, ahead_a);
+  } else
 #ifdef RATSDF_STAMPS
   if (tab.tail_on)
     hipLaunchKernelGGL(k_front<true>, dim3(g.n_front_wg), dim3(256), 0, stream, tab, P, g.n_vis_wg, cand[par],
@@ -1044,6 +1060,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   if (const char* v = getenv("RATSDF_FUSED_SERIAL")) e->fused_serial = atoi(v) != 0;  // 0: k_alloc_rank launch
   if (const char* v = getenv("RATSDF_FRONT_TAIL")) e->front_tail = atoi(v) != 0;  // 0: the role always in k_integrate
   if (const char* v = getenv("RATSDF_FRONT_PRIO")) e->front_prio = atoi(v) ? 2u : 0u;
+  if (const char* v = getenv("RATSDF_INLINE_CAND")) e->inline_off = atoi(v) == 0;
   if (const char* v = getenv("RATSDF_SERIAL_LDS")) {
     const int x = atoi(v);
     if (x >= kSerialLdsBytes && x <= 160 * 1024) e->serial_lds = (unsigned)x;
