@@ -571,3 +571,30 @@ def test_tsdf_only_frames_skip_the_probability_only_while_it_is_untouched(make_e
     gpu2.integrate_device_batch(make_batch(gpu2, nosem, dev, 6, 12, md))
     oracle_run(cpu2, nosem[6:12], md)
     assert_maps_equal(gpu2, cpu2)
+
+
+@pytest.mark.parametrize("mode", ["single frames", "one batch"])
+def test_more_candidates_than_a_workgroups_lds_set_holds(mode, make_engine, make_oracle):
+    """A 16x16-pixel patch that asks for more than 512 distinct blocks: the candidates that find the workgroup's LDS set
+    full leave by the overflow paths -- straight into the frame's global list in the look-ahead form (cand_append), a
+    request filed on the spot in the form that runs inside k_front (cand_inline_role: single frames, the first frame of
+    a batch).  A coarse image on 2 mm voxels: neighbouring pixels' rays are 17 voxels apart, so every pixel brings its own
+    four or five blocks."""
+    vs, trunc, md = 0.002, 0.03, 4.0
+    kw = dict(block_bits=16)
+    gpu, cpu = make_engine(vs, trunc, **kw), make_oracle(vs, trunc, threads=8, **kw)
+    frames = synthetic.stream("room", 3, scale=0.1)
+    dev = device_frames(frames)
+    h, w = frames[0]["depth"].shape
+    if mode == "single frames":
+        for f, d in zip(frames, dev):
+            gpu.integrate_device(d["rgb"].data_ptr(), d["depth"].data_ptr(), d["ht"].data_ptr(), d["lt"].data_ptr(), h, w,
+                                 md, f["intrinsics"], f["pose"])
+    else:
+        gpu.integrate_device_batch(make_batch(gpu, frames, dev, 0, len(frames), md))
+    oracle_run(cpu, frames, md)
+    assert_maps_equal(gpu, cpu)
+    check_totals(gpu, cpu)
+    # the premise: far more blocks per 16x16 patch than the 512 slots of a workgroup's set
+    patches = ((h + 15) // 16) * ((w + 15) // 16)
+    assert cpu.num_active_blocks() > 512 * patches, (cpu.num_active_blocks(), patches)
