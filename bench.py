@@ -893,8 +893,8 @@ def main():
     # look-ahead candidate pass and no graph -- three launches and a stream synchronisation per frame.  What a tracking
     # loop that needs the map between frames gets; reported separately, never the headline value.
     sync_path = None
-    if rank == 0 and not grouped and not a.sync_every:
-        lat = []
+    if rank == 0 and not grouped and not a.sync_every and a.host_frames > 0:   # (--host-frames 0, what the profiling
+        lat = []                                                                # scripts pass: none of the caller-path legs)
         n_sync = min(4 * len(frames), 360)
         eng.synchronize()
         t_all = time.perf_counter()
