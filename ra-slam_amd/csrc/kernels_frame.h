@@ -12,6 +12,8 @@
 // k_front leaves most of the chip idle and k_integrate is latency-bound, so when the caller has already
 // handed over frame f+1 (ratsdf_integrate_device_batch) its directory-independent candidate pass
 // (cand_pixels_role) rides along as extra workgroups: `ahead` describes the share each launch takes.
+// A frame nobody looked ahead for (a single call, the first frame of a batch) is two launches as well: its own
+// candidate pass runs inside k_front_inline, every pixel workgroup its own consumer (cand_inline_role).
 //
 // k_alloc_rank is the serial role as a launch of its own (1024 threads, its scratch in LDS): what the
 // stand-alone test hooks run, and RATSDF_FUSED_SERIAL=0 puts it back between the two launches for A/B
