@@ -135,8 +135,13 @@ def roofline_block(b_alg_per_launch, k_ms, k_n, config, kernel="k_integrate", en
                                          "tools/sq.sh + tools/issue_json.py)")
         except Exception:
             issue = None
+    # (the counters' bytes over the same launch duration: what the memory system moved, as a rate -- `achieved` / `frac`
+    # stay the contract's algorithmic-bytes figures)
+    moved = (traffic / k_avg_s / 1e9) if traffic else None
     return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src, issue=issue,
+                frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src,
+                traffic_gbps=(round(moved, 1) if moved else None),
+                traffic_frac=(round(moved / HBM_PEAK_GBPS, 4) if moved else None), issue=issue,
                 timed_launches=("every 4th frame of every 4th batch of the timed region is launched by itself with "
                                 "HIP events attached to the dispatch (k_integrate<2, false>); the other batches are HIP-graph "
                                 "replays of the same frames (k_integrate_g<2, false>, one member: the same body)"
