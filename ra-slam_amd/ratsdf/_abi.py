@@ -89,9 +89,12 @@ class _OwnedBuffer:
         self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (address, False), "version": 3}
 
     def __del__(self):
-        if self._address:
-            self._lib.fn["free_buffer"](C.c_void_p(self._address))
-            self._address = 0
+        try:
+            if self._address:
+                self._lib.fn["free_buffer"](C.c_void_p(self._address))
+                self._address = 0
+        except Exception:   # (interpreter shutdown: the library object may be gone already)
+            pass
 
 
 def _ptr(a, ctype):
