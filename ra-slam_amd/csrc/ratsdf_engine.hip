@@ -222,6 +222,7 @@ struct ratsdf_engine {
   // role is ~7 us of dependent round trips wherever it runs, and inside k_integrate it hides behind the update.
   bool front_tail = false;
   uint32_t front_prio = 0u;              // 2: k_front's directory workgroups run at raised wave priority (+1 %)
+  bool sort_lists = false;               // diagnostic build, RATSDF_SORT_LISTS=1: work lists sorted by image tile on the host (experiment)
   bool inline_off = false;               // diagnostic build, RATSDF_INLINE_CAND=0: k_cand + k_front for frames without look-ahead
   int commit_rot_env = -1;               // RATSDF_COMMIT_ROT: first committing workgroup (measurements)
   // With the serial role in the launch: which update workgroups take the frame's commits.  A grid of
@@ -769,6 +770,38 @@ int ratsdf_engine::frame(const FrameIn& cur, const FrameIn* next, int H, int W, 
                        (uint32_t)g.parts, req, req_cap, slow, kSlowCap, vis + kFreshCap, seg_cap, pool,
                        carve_bufs(par ^ 1u), ctl, (uint32_t)par, d_stats, 0u, ahead_a);
 #ifdef RATSDF_STAMPS
+  // (experiment, RATSDF_SORT_LISTS=1: every work list put into image-tile order on the HOST between the two launches --
+  // an upper bound for what tile-ordered lists would buy the update; the engine waits for k_front here, so only the
+  // update's own time means anything in such a run)
+  if (sort_lists) {
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<uint32_t> fc(sizeof(FrameCtl) / 4);
+    HIPCHK(hipMemcpy(fc.data(), &ctl->fr[par], sizeof(FrameCtl), hipMemcpyDeviceToHost));
+    const FrameCtl* hf = reinterpret_cast<const FrameCtl*>(fc.data());
+    const double qx = P.T.q.x, qy = P.T.q.y, qz = P.T.q.z, qw = P.T.q.w;
+    for (int l = 0; l < kNumLists; ++l) {
+      uint32_t n = hf->n_list[l * kListStride];
+      if (n > seg_cap - kFreshCap) n = seg_cap - kFreshCap;
+      if (n < 2) continue;
+      std::vector<VisItem> items(n);
+      VisItem* dl = vis + kFreshCap + (size_t)l * seg_cap;
+      HIPCHK(hipMemcpy(items.data(), dl, (size_t)n * sizeof(VisItem), hipMemcpyDeviceToHost));
+      auto key = [&](const VisItem& it) {
+        const double x = (it.x * 8 + 4) * (double)P.vs, y = (it.y * 8 + 4) * (double)P.vs, z = (it.z * 8 + 4) * (double)P.vs;
+        // rotate by the quaternion, translate, project
+        const double ux = 2 * (qy * z - qz * y), uy = 2 * (qz * x - qx * z), uz = 2 * (qx * y - qy * x);
+        const double cx = x + qw * ux + (qy * uz - qz * uy) + P.T.t.x, cy = y + qw * uy + (qz * ux - qx * uz) + P.T.t.y,
+                     cz = z + qw * uz + (qx * uy - qy * ux) + P.T.t.z;
+        double u = (P.K.fx * cx + P.K.cx * cz) / cz, v = (P.K.fy * cy + P.K.cy * cz) / cz;
+        u = std::min(std::max(u, 0.0), (double)(P.W - 1));
+        v = std::min(std::max(v, 0.0), (double)(P.H - 1));
+        // finer than the 8x8 tiles: 32x32 cells in raster order of cells
+        return (int)(v * 32.0 / P.H) * 32 + (int)(u * 32.0 / P.W);
+      };
+      std::stable_sort(items.begin(), items.end(), [&](const VisItem& a, const VisItem& b) { return key(a) < key(b); });
+      HIPCHK(hipMemcpy(dl, items.data(), (size_t)n * sizeof(VisItem), hipMemcpyHostToDevice));
+    }
+  }
   if (!fused) {  // (the serial role as a launch of its own: the round-1 layout, kept for A/B in the diagnostic build)
     st = alloc_rank((uint32_t)(npix * (size_t)S), par, next ? &ahead_b : nullptr, true);
     if (st != RATSDF_OK) return st;
@@ -1061,6 +1094,7 @@ int ratsdf_create_ex(const ratsdf_config* cfg, ratsdf_engine** out) {
   if (const char* v = getenv("RATSDF_FRONT_TAIL")) e->front_tail = atoi(v) != 0;  // 0: the role always in k_integrate
   if (const char* v = getenv("RATSDF_FRONT_PRIO")) e->front_prio = atoi(v) ? 2u : 0u;
   if (const char* v = getenv("RATSDF_INLINE_CAND")) e->inline_off = atoi(v) == 0;
+  if (const char* v = getenv("RATSDF_SORT_LISTS")) e->sort_lists = atoi(v) != 0;
   if (const char* v = getenv("RATSDF_SERIAL_LDS")) {
     const int x = atoi(v);
     if (x >= kSerialLdsBytes && x <= 160 * 1024) e->serial_lds = (unsigned)x;
