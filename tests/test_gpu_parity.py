@@ -202,6 +202,24 @@ def test_raycast_matches_oracle(make_engine, make_oracle):
         for r0, r1 in ((0, hh), (5, 22), (hh - 17, hh), (9, 9)):
             ra, rn = gpu.raycast_rows(k, hh, ww, pose, 8.0, r0, r1)
             assert np.array_equal(ra, ga[r0:r1]) and np.array_equal(rn, gn[r0:r1]), (r0, r1)
+        # ratsdf_raycast_device: the same images left in device memory (what a renderer that displays from the GPU takes)
+        import torch
+        d_a = torch.zeros((hh, ww, 4), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros((hh, ww, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        gpu.raycast_device(k, hh, ww, pose, 8.0, d_a.data_ptr(), d_n.data_ptr())
+        gpu.synchronize()
+        assert np.array_equal(d_a.cpu().numpy(), ga) and np.array_equal(d_n.cpu().numpy(), gn)
+    # a far longer ray than the map is deep (most of its samples in empty space) and a map the occupancy filter of the
+    # march has to be rebuilt for: delete nothing, integrate more, render again -- still the oracle's images
+    for fr in synthetic.stream("sphere", 3, scale=0.25):
+        for e in (gpu, cpu):
+            e.integrate(fr["rgb"], fr["depth"], fr["ht"], fr["lt"], 4.0, fr["intrinsics"], fr["pose"])
+    ga, gn = gpu.raycast(f["intrinsics"], h, w, f["pose"], 40.0)
+    ca, cn = cpu.raycast(f["intrinsics"], h, w, f["pose"], 40.0)
+    for a, b in ((ga, ca), (gn, cn)):
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
 
 
 def _frame_like(depth, seed=0, pose=None, intr=(300.0, 300.0, 0.0, 0.0)):
