@@ -18,14 +18,14 @@
 //   * block-level occupancy in LDS: k_occupancy_build hashes every live block into a 32 KiB bitmap before the
 //     rendering (a scan of Table::active), every workgroup copies it into LDS; a clear bit proves the block absent, so
 //     empty space costs an LDS read per block instead of a directory probe (set bits may be collisions: probed);
-//   * the march SPECULATES: the step almost always stays what it was, so the positions of the next kAhead samples are
-//     computed assuming that, their lookups and voxel loads are issued together, and the samples are then judged one
-//     by one exactly as the plain loop would; the first sample that changes the step ends the group, what was fetched
-//     beyond it is dropped.  Positions come from the same additions in the same order: every sample that counts is
-//     bit for bit the plain march's;
 //   * the zero crossing's interpolation, colour and normal (:318-357, two thirds of the loop's code) run once, after
-//     the loop, not as a branch of every unrolled sample.
-// (Tried first and dropped: an exact skip over provably empty 8^3-block cells -- half the iterations, the same tail.)
+//     the loop, not as a branch inside it;
+//   * the three divisions of the full step by 10 (:361-367, at every sample that picks the fine step) are done once, and
+//     (short)roundf() takes its four-instruction form.
+// Tried and dropped, with their numbers in the same file: an exact skip over provably empty 8^3-block cells (the positions of
+// skipped samples still produced by the same additions: half the iterations, the same tail), and fetching the next 2 / 3 /
+// 4 / 8 samples speculatively under the assumption that the step does not change (depth 1, i.e. none, is fastest: the
+// lookups that remain are LDS reads, and a group's extra samples only lengthen the slowest wave's instruction stream).
 #pragma once
 #include "kernels_integrate.h"
 
@@ -38,8 +38,8 @@ struct BlockCache {  // VoxelBlock cache of RetrieveMutable, voxel_hash.cuh:124-
 };
 
 // hashed occupancy of the map's blocks, built before a rendering and held in LDS (see the header)
-// (TWO bits per block, a Bloom filter: a wave looks up ~130 blocks per group of samples, so with one bit per block and
-// 2 % of the bits set some lane of nearly every group ran into a collision and sent the whole wave to the directory)
+// (TWO bits per block, a Bloom filter: the 64 rays of a wave enter ~30 blocks per sample, so with one bit per block and
+// 2 % of the bits set some lane runs into a collision every other sample and sends the whole wave to the directory)
 constexpr uint32_t kOccWords = 8192;               // 32 KiB = 262 144 bits
 // (any spreading of neighbouring blocks will do: 24-bit multiply-adds of the coordinates' low 16 bits -- the directory
 // hash's three full 32-bit multiplications issue at a quarter of the rate, and a lookup is on the march's critical path)
@@ -153,7 +153,6 @@ __global__ __launch_bounds__(256) void k_raycast(Table tab, Pool pool, FramePara
   // time -- thirty instructions of IEEE division per sample, here once)
   const V3 fine_step{full.x / 10, full.y / 10, full.z / 10};
   V3 stepv = full;
-  bool is_fine = false;
   V3 p{P.Ti.t.x / P.vs, P.Ti.t.y / P.vs, P.Ti.t.z / P.vs};                    // :299
   BlockCache cache{0, 0, 0, -1, false};
   // (short)roundf(v): the four-instruction form (device_math.h: round_to_int) wherever the ray can get -- it equals the
@@ -164,94 +163,41 @@ __global__ __launch_bounds__(256) void k_raycast(Table tab, Pool pool, FramePara
   auto gi = [small](float v) { return small ? (int)(int16_t)round_to_int(v) : (int)(int16_t)f2i(roundf(v)); };
   float prev = tsdf_at(tab, pool, gi(p.x), gi(p.y), gi(p.z), cache, occ);           // :302-303
   p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
-  constexpr int kAhead = 4;
-  int i = 1;
   bool done = false;
 #ifdef RATSDF_STAMPS
-  // per-wave record (tools/raycast_probe.py): [0] start, [1] end of the march, [2] end (10 ns ticks); [3] groups of the
-  // slowest lane, [4] samples of the slowest lane, [5] lanes that hit
+  // per-wave record (tools/raycast_probe.py): [0] start, [2] end (10 ns ticks); [3] / [4] samples of the slowest lane,
+  // [5] lanes that hit; a full-length lane's cycles: [1] stepping + judging, [6] lookups, [7] voxel loads
   unsigned long long* ws = ctl && ctl->debug_buf
       ? ctl->debug_buf + (size_t)((((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) & 16383u)) * 8 : nullptr;
   if (ws) atomicMin(&ws[0], wall_clock64());
-  unsigned long long n_groups = 0, ph[4] = {0, 0, 0, 0};
+  unsigned long long ph[4] = {0, 0, 0, 0};
 #define RC_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); ph[k] += t_ - t_last; t_last = t_; } while (0)
   unsigned long long t_last = clock64();
 #else
 #define RC_STAMP(k) do { } while (0)
 #endif
-  while (!done && i < max_step) {                                             // :305
-#ifdef RATSDF_STAMPS
-    ++n_groups;
-#endif
-    // the next kAhead samples if the step stays what it is: positions, then every probe and voxel load together
-    V3 q[kAhead];
-    long vis[kAhead];
-    float ts[kAhead];
-    uint32_t wsv[kAhead];
-    q[0] = p;
-#pragma unroll
-    for (int k = 1; k < kAhead; ++k) q[k] = V3{q[k - 1].x + stepv.x, q[k - 1].y + stepv.y, q[k - 1].z + stepv.z};
+  int i = 1;
+  for (; i < max_step; ++i) {                                                 // :305
     RC_STAMP(0);
-    {  // the group's lookups: the filter bits of all four blocks first (eight LDS reads in flight together; one after
-       // the other inside voxel_index they were four LDS round trips between four divergent branches), then the cache /
-       // directory logic sample by sample
-      int gxs[kAhead], gys[kAhead], gzs[kAhead];
-      bool maybe[kAhead];
-#pragma unroll
-      for (int k = 0; k < kAhead; ++k) {
-        gxs[k] = gi(q[k].x);
-        gys[k] = gi(q[k].y);
-        gzs[k] = gi(q[k].z);
-        maybe[k] = occ_maybe(occ, gxs[k] >> 3, gys[k] >> 3, gzs[k] >> 3);
-      }
-#pragma unroll
-      for (int k = 0; k < kAhead; ++k) {
-        const int bx = gxs[k] >> 3, by = gys[k] >> 3, bz = gzs[k] >> 3;
-        if (!(cache.valid && cache.bx == bx && cache.by == by && cache.bz == bz)) {
-          int32_t idx = -1;
-          if (maybe[k]) {
-            EntryWords w;
-            const uint32_t e = find_block(tab, bx, by, bz, &w);
-            idx = e == kInf ? -1 : w.idx;
-          }
-          cache = BlockCache{bx, by, bz, idx, true};
-        }
-        vis[k] = cache.idx < 0 ? -1 : ((long)cache.idx << 9) + ((gxs[k] & 7) + (gys[k] & 7) * 8 + (gzs[k] & 7) * 64);
-      }
-    }
+    const long vi = voxel_index(tab, gi(p.x), gi(p.y), gi(p.z), cache, occ);
     RC_STAMP(1);
-#pragma unroll
-    for (int k = 0; k < kAhead; ++k) {
-      ts[k] = vis[k] >= 0 ? pool.tsdf[vis[k]] : -10.f;
-      wsv[k] = vis[k] >= 0 ? (pool.rgbw[vis[k]] >> 24) : 0u;                    // :308-309
-    }
+    const float cur = vi >= 0 ? pool.tsdf[vi] : -10.f;
+    const uint32_t wcur = vi >= 0 ? (pool.rgbw[vi] >> 24) : 0u;               // :308-309
     RC_STAMP(2);
-    // ... judged one by one, as the plain loop would (p == q[k] bit for bit while the step has not changed)
-#pragma unroll
-    for (int k = 0; k < kAhead; ++k) {
-      if (done || i >= max_step) break;
-      const float cur = ts[k];
-      if (wsv[k] < 10) {                                                      // :312-316
-        p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
-        prev = cur;
-        ++i;
-        continue;
-      }
-      if (prev > 0 && cur <= 0 && prev - cur <= 2.0f) {                       // :318: the zero crossing (below)
-        done = true;
-        break;
-      }
-      prev = cur;
-      const bool want_fine = cur < 0.5f;                                      // :361-367
-      const bool changed = want_fine != is_fine;
-      is_fine = want_fine;
-      stepv = want_fine ? fine_step : full;
+    if (wcur < 10) {                                                          // :312-316
       p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
-      ++i;
-      if (changed) break;  // what was fetched beyond this sample assumed the old step
+      prev = cur;
+      continue;
     }
-    RC_STAMP(3);
+    if (prev > 0 && cur <= 0 && prev - cur <= 2.0f) {                         // :318: the zero crossing (below)
+      done = true;
+      break;
+    }
+    prev = cur;
+    stepv = cur < 0.5f ? fine_step : full;                                    // :361-367
+    p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
   }
+  RC_STAMP(3);
   if (done) {  // :318-357 at the crossing sample: p and the step are that sample's
     const V3 p1{p.x - stepv.x, p.y - stepv.y, p.z - stepv.z};
     const float ac = retrieve_tsdf(tab, pool, p, cache, occ);                 // :323-324
@@ -283,7 +229,7 @@ __global__ __launch_bounds__(256) void k_raycast(Table tab, Pool pool, FramePara
 #ifdef RATSDF_STAMPS
   if (ws) {
     atomicMax(&ws[2], wall_clock64());
-    atomicMax(&ws[3], n_groups);
+    atomicMax(&ws[3], (unsigned long long)i);
     atomicMax(&ws[4], (unsigned long long)i);
     if (done) atomicAdd(&ws[5], 1ull);
     if (i >= max_step) {  // a ray that ran its full length: cycles in positions | probes | voxel loads | judging
