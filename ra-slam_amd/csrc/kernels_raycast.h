@@ -15,15 +15,18 @@
 // sample of it a directory probe that finds nothing -- 64 % of such a lane's cycles were probes, one after the other
 // (find_block branches on what it loaded, so four probes in a row are four round trips of ~0.7 us), 32 % the judging
 // code, 5 % the voxel loads.  Hence:
-//   * block-level occupancy in LDS: k_occupancy_build hashes every live block into a 32 KiB bitmap before the
-//     rendering (a scan of Table::active), every workgroup copies it into LDS; a clear bit proves the block absent, so
-//     empty space costs an LDS read per block instead of a directory probe (set bits may be collisions: probed);
+//   * occupancy in LDS, two levels: k_occupancy_build hashes every live block into a 16 KiB Bloom filter (two bits per
+//     block) and its super-cell of 4^3 blocks into a 4 KiB bitmap before the rendering (a scan of Table::active), every
+//     workgroup copies both into LDS.  A clear cell bit proves the whole cell empty: its samples cost a compare of the
+//     cell's coordinates and the three additions of the step.  Inside an occupied cell a clear block bit proves the block
+//     absent: an LDS read instead of a directory probe (set bits may be collisions: probed);
 //   * the zero crossing's interpolation, colour and normal (:318-357, two thirds of the loop's code) run once, after
 //     the loop, not as a branch inside it;
 //   * the three divisions of the full step by 10 (:361-367, at every sample that picks the fine step) are done once, and
 //     (short)roundf() takes its four-instruction form.
-// Tried and dropped, with their numbers in the same file: an exact skip over provably empty 8^3-block cells (the positions of
-// skipped samples still produced by the same additions: half the iterations, the same tail), and fetching the next 2 / 3 /
+// Tried and dropped, with their numbers in the same file: skipping AHEAD inside an empty cell (a conservative count of
+// the samples that stay in it, their positions still produced by the same additions in a tight loop: half the
+// iterations, slower every time -- the count costs more than the samples it saves), and fetching the next 2 / 3 /
 // 4 / 8 samples speculatively under the assumption that the step does not change (depth 1, i.e. none, is fastest: the
 // lookups that remain are LDS reads, and a group's extra samples only lengthen the slowest wave's instruction stream).
 #pragma once
@@ -40,7 +43,12 @@ struct BlockCache {  // VoxelBlock cache of RetrieveMutable, voxel_hash.cuh:124-
 // hashed occupancy of the map's blocks, built before a rendering and held in LDS (see the header)
 // (TWO bits per block, a Bloom filter: the 64 rays of a wave enter ~30 blocks per sample, so with one bit per block and
 // 2 % of the bits set some lane runs into a collision every other sample and sends the whole wave to the directory)
-constexpr uint32_t kOccWords = 8192;               // 32 KiB = 262 144 bits
+constexpr uint32_t kOccWords = 4096;               // blocks: 16 KiB = 131 072 bits
+constexpr uint32_t kCellWords = 1024;              // super-cells of 4^3 blocks (32^3 voxels), one bit each: 4 KiB
+#ifndef RATSDF_CELL_BITS
+#define RATSDF_CELL_BITS 5  // (same-box A/B of 16 / 32 / 64 / 128 voxels: 269 / 201 / 206 / 281 us per rendering)
+#endif
+constexpr int kCellVoxelBits = RATSDF_CELL_BITS;
 // (any spreading of neighbouring blocks will do: 24-bit multiply-adds of the coordinates' low 16 bits -- the directory
 // hash's three full 32-bit multiplications issue at a quarter of the rate, and a lookup is on the march's critical path)
 __device__ inline uint32_t occ_bit(int bx, int by, int bz) {
@@ -50,6 +58,10 @@ __device__ inline uint32_t occ_bit(int bx, int by, int bz) {
 __device__ inline uint32_t occ_bit2(int bx, int by, int bz) {
   const uint32_t x = (uint32_t)bx & 0xFFFFu, y = (uint32_t)by & 0xFFFFu, z = (uint32_t)bz & 0xFFFFu;
   return ((__umul24(x, 0x2C1B3u) + __umul24(y, 0x5D3u) + __umul24(z, 0x1B873u)) >> 3) & (kOccWords * 32u - 1u);
+}
+__device__ inline uint32_t cell_bit(int cx, int cy, int cz) {
+  const uint32_t x = (uint32_t)cx & 0xFFFFu, y = (uint32_t)cy & 0xFFFFu, z = (uint32_t)cz & 0xFFFFu;
+  return (__umul24(x, 0x9E5u) + __umul24(y, 0x1F35Bu) + __umul24(z, 0x6A7C1u)) & (kCellWords * 32u - 1u);
 }
 __device__ inline bool occ_maybe(const uint32_t* occ, int bx, int by, int bz) {
   const uint32_t h = occ_bit(bx, by, bz), g = occ_bit2(bx, by, bz);
@@ -106,7 +118,7 @@ __device__ inline float retrieve_tsdf(const Table& tab, const Pool& pool, const 
   return t0 * al.x + t1 * (1 - al.x);
 }
 
-// the occupancy bits (kOccWords words, zeroed by the caller) from the live blocks: one lane per slot of Table::active
+// the occupancy bits (kOccWords + kCellWords words, zeroed by the caller) from the live blocks: one lane per slot of Table::active
 // that has ever been in use
 __global__ __launch_bounds__(256) void k_occupancy_build(Table tab, const Ctl* ctl, uint32_t* bits) {
   int32_t lo = ctl->free_low;
@@ -119,6 +131,8 @@ __global__ __launch_bounds__(256) void k_occupancy_build(Table tab, const Ctl* c
     const uint32_t h = occ_bit(bx, by, bz), g = occ_bit2(bx, by, bz);
     atomicOr(&bits[h >> 5], 1u << (h & 31u));
     atomicOr(&bits[g >> 5], 1u << (g & 31u));
+    const uint32_t c = cell_bit(bx >> (kCellVoxelBits - 3), by >> (kCellVoxelBits - 3), bz >> (kCellVoxelBits - 3));
+    atomicOr(&bits[kOccWords + (c >> 5)], 1u << (c & 31u));
   }
 }
 
@@ -127,11 +141,11 @@ __global__ __launch_bounds__(256) void k_raycast(Table tab, Pool pool, FramePara
                                                  uint32_t* out_normal, int row0, int row1, const uint32_t* occ_bits,
                                                  Ctl* ctl) {
   // the occupancy bits in LDS (every wave of the workgroup takes part, whatever its pixels)
-  __shared__ __attribute__((aligned(16))) uint32_t occ[kOccWords];
+  __shared__ __attribute__((aligned(16))) uint32_t occ[kOccWords + kCellWords];
   {
     const uint4* src = reinterpret_cast<const uint4*>(occ_bits);
     uint4* dst = reinterpret_cast<uint4*>(occ);
-    for (uint32_t i = threadIdx.x; i < kOccWords / 4; i += 256) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < (kOccWords + kCellWords) / 4; i += 256) dst[i] = src[i];
   }
   __syncthreads();
   // rows [row0, row1) of the P.H x P.W image (the whole image: 0, P.H); the output buffers hold those rows only
@@ -177,9 +191,29 @@ __global__ __launch_bounds__(256) void k_raycast(Table tab, Pool pool, FramePara
 #define RC_STAMP(k) do { } while (0)
 #endif
   int i = 1;
+  int cell_x = 0, cell_y = 0, cell_z = 0;
+  bool cell_known = false, cell_empty = false;
   for (; i < max_step; ++i) {                                                 // :305
     RC_STAMP(0);
-    const long vi = voxel_index(tab, gi(p.x), gi(p.y), gi(p.z), cache, occ);
+    const int gx = gi(p.x), gy = gi(p.y), gz = gi(p.z);
+    {  // a sample inside a super-cell that provably holds no block reads "no voxel" whatever its block (:312-316: it is
+       // skipped, the step stays as it is): no hash, no LDS read while the ray stays in the cell
+      const int cx = gx >> kCellVoxelBits, cy = gy >> kCellVoxelBits, cz = gz >> kCellVoxelBits;
+      if (!(cell_known && cx == cell_x && cy == cell_y && cz == cell_z)) {
+        const uint32_t h = cell_bit(cx, cy, cz);
+        cell_empty = ((occ[kOccWords + (h >> 5)] >> (h & 31u)) & 1u) == 0u;
+        cell_x = cx;
+        cell_y = cy;
+        cell_z = cz;
+        cell_known = true;
+      }
+      if (cell_empty) {
+        p = V3{p.x + stepv.x, p.y + stepv.y, p.z + stepv.z};
+        prev = -10.f;
+        continue;
+      }
+    }
+    const long vi = voxel_index(tab, gx, gy, gz, cache, occ);
     RC_STAMP(1);
     const float cur = vi >= 0 ? pool.tsdf[vi] : -10.f;
     const uint32_t wcur = vi >= 0 ? (pool.rgbw[vi] >> 24) : 0u;               // :308-309

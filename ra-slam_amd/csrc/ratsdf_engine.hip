@@ -2021,8 +2021,8 @@ static int raycast_rows_device(ratsdf_engine* e, const ratsdf_intrinsics* K, int
   const float ms = ceilf(max_depth / step_size);
   const int max_step = ms >= 2147483648.f ? 2147483647 : (int)ms;  // voxel_tsdf.cu:298
   // block-level occupancy of the map as it is now (kernels_raycast.h: empty space costs no directory probes)
-  if (!e->d_occ) HIPCHK(hipMalloc(&e->d_occ, kOccWords * 4));
-  HIPCHK(hipMemsetAsync(e->d_occ, 0, kOccWords * 4, e->stream));
+  if (!e->d_occ) HIPCHK(hipMalloc(&e->d_occ, (kOccWords + kCellWords) * 4));
+  HIPCHK(hipMemsetAsync(e->d_occ, 0, (kOccWords + kCellWords) * 4, e->stream));
   hipLaunchKernelGGL(k_occupancy_build, dim3(256), dim3(256), 0, e->stream, e->tab, (const Ctl*)e->ctl, e->d_occ);
   hipLaunchKernelGGL(k_raycast, dim3((width + 15) / 16, (row1 - row0 + 15) / 16), dim3(256), 0, e->stream,
                      e->tab, e->pool, P, step_size, max_step, (uint32_t*)d_rgba, (uint32_t*)d_normal, row0, row1,
