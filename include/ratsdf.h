@@ -41,8 +41,8 @@ typedef enum ratsdf_status {
   RATSDF_ERR_CAPACITY = 4,       /* an internal work list overflowed (no reference counterpart)        */
   RATSDF_ERR_NO_DEVICE = 5,      /* HIP engine only: no gfx950 device / runtime available              */
   RATSDF_ERR_NOT_IMPLEMENTED = 6,
-  RATSDF_ERR_TIMEOUT = 7         /* an in-launch wait between workgroups expired (sticky; the map may
-                                    have been read while a queued delete was still pending)           */
+  RATSDF_ERR_TIMEOUT = 7         /* an in-launch wait between workgroups expired (sticky until
+                                    ratsdf_recover; a workgroup skipped its share of a frame)         */
 } ratsdf_status;
 
 /* CameraIntrinsics<float>, utils/cuda/camera.cuh:13-52 */
@@ -191,6 +191,15 @@ int ratsdf_host_free(void* p);
  * (pool exhausted, work-list overflow).  A stream synchronisation and a read of a page-locked flag the kernels raise
  * on error: no device-to-host copy, no launch. */
 int ratsdf_synchronize(ratsdf_engine* e);
+/* After a sticky error -- RATSDF_ERR_TIMEOUT above all, where a workgroup gave up waiting and skipped its share of a
+ * frame -- the engine refuses nothing but reports the error for ever, and the structures derived from the block
+ * directory (occupancy bits, the list of live blocks, the free list, claims, frame counters) may no longer agree with
+ * it.  ratsdf_recover waits for the GPU, rebuilds all of them from the directory (which is whole: the workgroups that
+ * edit it are the ones that were waited for), empties the work lists, tells a consumer of directory deltas to take a
+ * whole directory next, and clears the error.  The map keeps every frame before the failed one and whatever part of
+ * that one reached the voxels; integration can go on.  HIP engine only (the oracle has no such errors and returns
+ * RATSDF_OK); no reference counterpart -- the reference asserts (voxel_mem.cu:39) or hangs. */
+int ratsdf_recover(ratsdf_engine* e);
 /* Native handle of the engine's stream (hipStream_t) so callers can order their own work / events. */
 int ratsdf_stream(ratsdf_engine* e, void** out_stream);
 

@@ -971,6 +971,8 @@ int ratsdf_oracle_prepare_device_batch(ratsdf_engine*, int, int, int) { return R
 int ratsdf_oracle_profile_enable(ratsdf_engine*, int) { return RATSDF_ERR_NOT_IMPLEMENTED; }
 int ratsdf_oracle_pipeline_counters(ratsdf_engine*, int64_t*, int) { return RATSDF_ERR_NOT_IMPLEMENTED; }
 int ratsdf_oracle_export_directory_delta_device(ratsdf_engine*, void*, int32_t, void*) { return RATSDF_ERR_NOT_IMPLEMENTED; }
+// (nothing to recover from: the oracle has no in-launch waits and no sticky device errors)
+int ratsdf_oracle_recover(ratsdf_engine* e) { return e ? RATSDF_OK : RATSDF_ERR_BAD_ARGUMENT; }
 // (device-resident block exchange of the across-shard exports: the oracle has no device)
 int ratsdf_oracle_export_blocks_device(ratsdf_engine*, int32_t, const void*, void*, void*) { return RATSDF_ERR_NOT_IMPLEMENTED; }
 int ratsdf_oracle_import_blocks_device(ratsdf_engine*, int32_t, const void*, const void*) { return RATSDF_ERR_NOT_IMPLEMENTED; }

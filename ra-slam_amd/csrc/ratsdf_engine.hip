@@ -77,6 +77,35 @@ __global__ void k_check_block_threads(uint32_t* out) {
   if (threadIdx.x == 0) out[0] = block_threads() == blockDim.x ? blockDim.x : 0u;
 }
 
+// ratsdf_recover: what the directory says, into the structures derived from it.  One lane per hash entry: a live
+// entry sets its occupancy bit, fills its slot of Table::active and marks its pool block as in use; an entry the
+// chained-bucket resolver placed but whose commit never ran (pool index pending) is emptied -- its chain links stay,
+// a dead node in a chain is walked over.
+__global__ void k_recover_scan(Table tab, uint32_t* unused) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= tab.num_entry) return;
+  uint32_t* pe = reinterpret_cast<uint32_t*>(tab.entries + e);
+  const int32_t idx = (int32_t)pe[2];
+  if (idx == kPlaceholderIdx || idx >= tab.num_block) {
+    pe[2] = (uint32_t)-1;
+    return;
+  }
+  if (idx < 0) return;
+  atomicOr(&tab.occ[e >> 6], 1ull << (e & 63));
+  reinterpret_cast<uint4*>(tab.active)[idx] = make_uint4(pe[0], pe[1] & 0xFFFFu, (uint32_t)idx, e);
+  unused[idx] = 0u;
+}
+// ... and the free list: the pool blocks no entry names, in ascending order (the lowest positions of the heap hold
+// the lowest indices, as after creation: AquireBlock pops from the top)
+__global__ void k_recover_heap(const uint32_t* unused, const uint32_t* pos, int32_t* heap, int32_t n) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && unused[i]) heap[pos[i]] = i;
+}
+__global__ void k_fill_u32(uint32_t* p, uint32_t v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 __global__ void k_init_heap(int32_t* heap, int32_t n) {   // heap_init_kernel, voxel_mem.cu:6-11
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) heap[i] = i;
@@ -1603,6 +1632,81 @@ int ratsdf_synchronize(ratsdf_engine* e) {
   return e->sticky();
 }
 
+static int mask_positions(ratsdf_engine* e, const uint32_t* mask, size_t n, uint32_t* pos, uint32_t* scratch_tiles,
+                          uint32_t* d_total, uint32_t* h_total);
+
+// After a sticky error (RATSDF_ERR_TIMEOUT above all: a workgroup gave up waiting and skipped its share of a frame) the
+// map is what the frames before left plus a part of the failed one, and the structures DERIVED from the directory no
+// longer agree with it: pool indices reserved by a serial role whose commits were skipped, claims never reset, counters
+// of a frame that nobody finalised.  The directory itself is whole -- the workgroups that EDIT it (the resolvers, the
+// serial role) are the ones that were waited for, they never give up and have finished by the time the stream is idle.
+// So: everything is rebuilt from the directory -- occupancy bits, Table::active, the free list (the pool blocks no
+// entry names, ascending), the free count and its low-water mark -- the claim tables, both frames' counters, the
+// candidate counters and the delete bitmaps go back to their initial state, a consumer of directory deltas is told to
+// take a whole directory next, and the error is cleared.  The voxels keep what reached them.  No reference counterpart.
+int ratsdf_recover(ratsdf_engine* e) {
+  DeviceGuard guard(e ? e->device : -1);
+  if (!guard.ok()) return RATSDF_ERR_DEVICE;
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->copy_stream) HIPCHK(hipStreamSynchronize(e->copy_stream));
+  if (e->copy_stream2) HIPCHK(hipStreamSynchronize(e->copy_stream2));
+  Table& t = e->tab;
+  const uint32_t occ_words = (t.num_entry + 63) / 64;
+  const size_t nb = (size_t)t.num_block;
+  const uint32_t ntiles = (uint32_t)((nb + kScanTile - 1) / kScanTile);
+  uint32_t* tmp = nullptr;  // unused flags | positions | tile sums | total
+  HIPCHK(hipMalloc(&tmp, (2 * nb + ntiles + 2) * 4));
+  uint32_t *unused = tmp, *pos = tmp + nb, *tiles = pos + nb, *d_total = tiles + ntiles + 1;
+  auto fail = [&](int st) {
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    return st;
+  };
+#define REC_CHK(expr) do { if ((expr) != hipSuccess) return fail(RATSDF_ERR_DEVICE); } while (0)
+  REC_CHK(hipMemsetAsync(t.occ, 0, (size_t)occ_words * 8, e->stream));
+  REC_CHK(hipMemsetAsync(t.active, 0xFF, nb * sizeof(VisItem), e->stream));
+  REC_CHK(hipMemsetAsync(t.claim, 0xFF, (size_t)t.num_bucket * 4, e->stream));
+  REC_CHK(hipMemsetAsync(t.dclaim, 0xFF, (size_t)t.num_bucket * 4, e->stream));
+  REC_CHK(hipMemsetAsync(e->dbitmap, 0, (size_t)e->dwords * 4, e->stream));
+  REC_CHK(hipMemsetAsync(e->dsummary, 0, (size_t)((e->dwords / kGroupWords + 31) / 32) * 4, e->stream));
+  if (e->abitmap) {
+    REC_CHK(hipMemsetAsync(e->abitmap, 0, (size_t)e->awords_cap * 4, e->stream));
+    REC_CHK(hipMemsetAsync(e->asummary, 0, (size_t)e->asum_words * 4, e->stream));
+  }
+  REC_CHK(hipMemsetAsync(e->cand_count, 0, 2 * kCandSegs * kCandCountStride * 4, e->stream));
+  for (int i = 0; i < 2; ++i) REC_CHK(hipMemsetAsync(e->upd_wg[i], 0, kUpdCounters * 4, e->stream));
+  REC_CHK(hipMemsetAsync(&e->ctl->fr[0], 0, 2 * sizeof(FrameCtl), e->stream));
+  hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, e->stream, unused, 1u, nb);
+  hipLaunchKernelGGL(k_recover_scan, dim3((t.num_entry + 255) / 256), dim3(256), 0, e->stream, t, unused);
+  uint32_t n_free = 0;
+  if (mask_positions(e, unused, nb, pos, tiles, d_total, &n_free) != RATSDF_OK) return fail(RATSDF_ERR_DEVICE);
+  hipLaunchKernelGGL(k_recover_heap, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, e->stream, unused, pos,
+                     e->pool.heap, (int32_t)nb);
+  const int32_t nf = (int32_t)n_free;
+  REC_CHK(hipMemcpyAsync(&e->ctl->num_free, &nf, 4, hipMemcpyHostToDevice, e->stream));
+  // (the low-water mark only ever goes down: slots at or above it may have been in use; the rebuilt heap keeps the
+  // never-used indices -- the lowest ones -- at its bottom, so the mark stays true.  A free count below it moves it.)
+  int32_t low = 0;
+  REC_CHK(hipMemcpyAsync(&low, &e->ctl->free_low, 4, hipMemcpyDeviceToHost, e->stream));
+  REC_CHK(hipStreamSynchronize(e->stream));
+  if (nf < low) REC_CHK(hipMemcpyAsync(&e->ctl->free_low, &nf, 4, hipMemcpyHostToDevice, e->stream));
+  if (t.delta_on) {  // the delta log no longer describes what changed: the next export reports an overflow
+    const uint32_t over = 0x80000000u;
+    REC_CHK(hipMemcpyAsync(t.del_count, &over, 4, hipMemcpyHostToDevice, e->stream));
+  }
+  const uint32_t zero = 0;
+  REC_CHK(hipMemcpyAsync(&e->ctl->error, &zero, 4, hipMemcpyHostToDevice, e->stream));
+  REC_CHK(hipGetLastError());
+  REC_CHK(hipStreamSynchronize(e->stream));
+#undef REC_CHK
+  e->h_err[0] = e->h_err[1] = 0u;
+  e->pending = false;
+  e->cand_ready = false;
+  (void)hipFree(tmp);
+  return RATSDF_OK;
+}
+
 int ratsdf_stream(ratsdf_engine* e, void** out) {
   DeviceGuard guard(e ? e->device : -1);
   if (!guard.ok()) return RATSDF_ERR_DEVICE;
@@ -1760,6 +1864,16 @@ extern "C" int ratsdf_debug_wave_stamps(ratsdf_engine* e, int enable) {
   }
   return RATSDF_OK;
 }
+
+#ifdef RATSDF_STAMPS
+// diagnostic (stamps build only): the ablation / fault-injection switch of an engine after its creation (RATSDF_DEBUG
+// sets it at creation): tests/test_gpu_errors.py injects a fault, switches it off and recovers
+extern "C" int ratsdf_debug_set_switch(ratsdf_engine* e, int value) {
+  if (!e) return RATSDF_ERR_BAD_ARGUMENT;
+  e->debug = value;
+  return RATSDF_OK;
+}
+#endif
 
 // diagnostic (stamps build only): the raw per-wave record buffer ratsdf_debug_wave_stamps(e, 1) attached (16 384 x 8
 // words), copied out and zeroed -- k_raycast's per-wave timeline (tools/raycast_probe.py)

@@ -67,7 +67,7 @@ assert VOXEL_SEGM_DTYPE.itemsize == 20 and RGBW_DTYPE.itemsize == 4
 # every symbol include/ratsdf.h declares (without prefix)
 SYMBOLS = [
     "create", "create_ex", "destroy", "integrate", "integrate_device", "integrate_device_batch",
-    "prepare_device_batch", "integrate_batch", "host_alloc", "host_free", "synchronize", "stream",
+    "prepare_device_batch", "integrate_batch", "host_alloc", "host_free", "synchronize", "recover", "stream",
     "profile_enable", "profile_read", "profile_read_frames", "totals", "pipeline_counters",
     "num_active_blocks", "last_frame_stats", "query", "gather_valid", "gather_valid_semantic",
     "download_all", "free_buffer", "raycast", "raycast_rows", "raycast_device", "gather_valid_mesh", "download_all_mesh",
@@ -138,6 +138,7 @@ class Library:
         self.fn["host_alloc"].argtypes = [C.c_size_t, C.POINTER(vp)]
         self.fn["host_free"].argtypes = [vp]
         self.fn["synchronize"].argtypes = [vp]
+        self.fn["recover"].argtypes = [vp]
         self.fn["stream"].argtypes = [vp, C.POINTER(vp)]
         self.fn["profile_enable"].argtypes = [vp, C.c_int]
         self.fn["profile_read"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -353,6 +354,10 @@ class Engine:
 
     def synchronize(self):
         _check(self.lib.fn["synchronize"](self._h), "synchronize")
+
+    def recover(self):
+        """after a sticky error: rebuild everything derived from the block directory, clear the error (ratsdf_recover)"""
+        _check(self.lib.fn["recover"](self._h), "recover")
 
     def stream(self):
         s = C.c_void_p()

@@ -48,6 +48,19 @@ def test_pool_exhaustion_status_and_recovery(make_engine):
         small.synchronize()
     assert ei.value.status == 3
     assert small.num_active_blocks() <= 64
+    # ratsdf_recover (product build): the error is cleared, and what is derived from the directory agrees with it again
+    # -- the serial role had reserved more pool blocks than exist
+    small.recover()
+    small.synchronize()
+    _, blocks = small.dump_directory()
+    nf, heap = small.dump_heap()
+    idx = np.asarray(blocks["idx"])
+    assert len(np.unique(idx)) == len(idx) and nf + len(idx) == 64 and len(np.intersect1d(heap[:nf], idx)) == 0
+    assert small.num_active_blocks() == len(idx)
+    with pytest.raises(ratsdf.RatsdfError) as ei:      # the pool is still too small for the frame: the same error again,
+        _integrate(small, f)                           # reported afresh (not a stale one)
+        small.synchronize()
+    assert ei.value.status == 3
 
 
 def test_export_directory_reports_true_count_and_capacity_error(make_engine):
@@ -166,3 +179,79 @@ print('RESULT', status, sticky, i, round(dt, 1))
     status, sticky, frame, dt = int(line[1]), int(line[2]), int(line[3]), float(line[4])
     assert status == 7 and sticky == 7, (what, r.stdout)
     assert dt < 60, (what, dt)
+
+
+@pytest.mark.parametrize("switch,what", [(20, "carve gate"), (21, "serial role"), (22, "shared claim pass")])
+def test_recover_after_an_expired_wait(switch, what):
+    """ratsdf_recover: after an in-launch wait has expired (fault injection of the diagnostic build, as above) the error
+    is sticky and the structures derived from the directory no longer agree with it.  Recovery rebuilds them: the error
+    is gone, every pool block is either named by exactly one directory entry or on the free list exactly once,
+    Table::active lists exactly the live blocks (the ray cast and the visible list work from it), and integration goes
+    on without errors -- the map keeps growing and a second engine that is fed the same later frames from the same
+    exported blocks ends with the same directory."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    lib = root / "ra-slam_amd" / "csrc" / "build" / "libratsdf_stamps.so"
+    assert lib.exists(), "diagnostic build missing: make -C ra-slam_amd/csrc stamps (build() does it)"
+    code = f"""
+import sys
+sys.path.insert(0, r'{root / "ra-slam_amd"}')
+import numpy as np
+import ratsdf
+from ratsdf import synthetic
+kw = dict() if {switch} == 22 else dict(bucket_bits=9, block_bits=14)
+if {switch} == 22:
+    vs = 0.002
+    frames = [synthetic.frame('room', i, cam='l515_720p', noise=True, holes=True) for i in range(4)] * 6
+else:
+    vs = 0.02
+    frames = [synthetic.frame('room', i, scale=0.25, noise=True, holes=True) for i in range(40)]
+e = ratsdf.TSDFGrid(vs, 6 * vs, **kw)
+status = 0
+for i in range(0, len(frames), 4):
+    try:
+        e.integrate_batch(frames[i:i + 4], 4.0)
+        e.synchronize()
+    except ratsdf.RatsdfError as err:
+        status = err.status
+        break
+assert status == 7, status
+e.lib.dll.ratsdf_debug_set_switch(e._h, 0)     # the fault is gone ...
+e.recover()                                     # ... and so is the error
+e.synchronize()
+
+def check(e):
+    ent, blocks = e.dump_directory()
+    nf, heap = e.dump_heap()
+    nb = len(heap)
+    idx = np.asarray(blocks['idx'])
+    assert len(np.unique(idx)) == len(idx) and idx.min(initial=0) >= 0 and idx.max(initial=0) < nb
+    free = np.asarray(heap[:nf])
+    assert len(np.unique(free)) == nf and nf + len(idx) == nb, (nf, len(idx), nb)
+    assert len(np.intersect1d(free, idx)) == 0
+    assert e.num_active_blocks() == len(idx)
+    return len(idx)
+
+n0 = check(e)
+assert n0 > 0
+later = frames[4:12] if {switch} != 22 else frames[:4]
+for i in range(0, len(later), 4):
+    e.integrate_batch(later[i:i + 4], 4.0)
+    e.synchronize()
+n1 = check(e)
+v, t, p = e.gather_valid_mesh()
+f = later[-1]
+h, w = f['depth'].shape
+rgba, _ = e.raycast(f['intrinsics'], h, w, f['pose'], 8.0)
+e.close()
+print('RESULT', n0, n1, len(t), float((rgba[..., 3] == 255).mean()))
+"""
+    env = dict(os.environ, RATSDF_LIB=str(lib), RATSDF_DEBUG=str(switch))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (what, r.stdout[-1500:] + r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    n0, n1, ntri, hit = int(line[1]), int(line[2]), int(line[3]), float(line[4])
+    assert n0 > 0 and n1 >= n0 // 2 and hit > 0.2, (what, line)
