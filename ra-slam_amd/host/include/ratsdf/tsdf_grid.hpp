@@ -25,6 +25,7 @@ struct Api {
   int (*host_alloc)(size_t, void**) = nullptr;
   int (*host_free)(void*) = nullptr;
   int (*synchronize)(ratsdf_engine*) = nullptr;
+  int (*recover)(ratsdf_engine*) = nullptr;
   int (*query)(ratsdf_engine*, const ratsdf_bounds*, ratsdf_voxel_tsdf**, size_t*) = nullptr;
   int (*gather_valid)(ratsdf_engine*, ratsdf_voxel_tsdf**, size_t*) = nullptr;
   int (*gather_valid_semantic)(ratsdf_engine*, ratsdf_voxel_segm**, size_t*) = nullptr;
@@ -80,6 +81,9 @@ class TSDFGrid {
   // cudaStreamSynchronize(stream_), voxel_tsdf.cu:450: the Integrate* calls do not wait for their frames; this does,
   // and it is where a device error of those frames surfaces (last_status())
   void Synchronize();
+  // ratsdf_recover: after a sticky engine error (last_status() != 0 for good) rebuild what is derived from the block
+  // directory and clear the error; true when the engine is usable again.  No reference counterpart (it asserts).
+  bool Recover();
   int last_status() const { return status_; }
   ratsdf_engine* handle() { return engine_; }
   const Api& api() const { return *api_; }

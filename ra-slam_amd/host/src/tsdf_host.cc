@@ -58,6 +58,7 @@ const Api& Api::Load(const char* path, const char* prefix) {
   api.host_alloc = reinterpret_cast<decltype(api.host_alloc)>(sym("host_alloc"));
   api.host_free = reinterpret_cast<decltype(api.host_free)>(sym("host_free"));
   api.synchronize = reinterpret_cast<decltype(api.synchronize)>(sym("synchronize"));
+  api.recover = reinterpret_cast<decltype(api.recover)>(sym("recover"));
   api.query = reinterpret_cast<decltype(api.query)>(sym("query"));
   api.gather_valid = reinterpret_cast<decltype(api.gather_valid)>(sym("gather_valid"));
   api.gather_valid_semantic =
@@ -197,6 +198,12 @@ void TSDFGrid::DownloadAll(const std::string& path) {
 
 void TSDFGrid::Synchronize() {
   if (engine_) note(api_->synchronize(engine_), "Synchronize");
+}
+
+bool TSDFGrid::Recover() {
+  if (!engine_) return false;
+  status_ = api_->recover(engine_);
+  return status_ == RATSDF_OK;
 }
 
 int TSDFGrid::NumActiveBlock() {

@@ -72,6 +72,11 @@ int main(int argc, char** argv) {
   TSDFGrid grid(vs, tr, 0, &api);
   CHECK(grid.last_status() == 0);
   for (auto& f : frames) grid.Integrate(img(f.rgb), img(f.depth), img(f.ht), img(f.lt), md, K, f.pose);
+  {  // Recover() on a healthy engine changes nothing observable (what it rebuilds is derived from the directory)
+    const int before = grid.NumActiveBlock();
+    CHECK(grid.Recover());
+    CHECK(grid.last_status() == 0 && grid.NumActiveBlock() == before);
+  }
   {
     TSDFSystem sys(vs, tr, md, K, SE3<float>::Identity(), 0, &api);
     for (auto& f : frames) {
